@@ -1,0 +1,154 @@
+/*
+ * ssdr.h -- C ABI of libssdr.so: the MI355X (gfx950) implementation of the SuperSDR
+ * DSP hot path (batched 1024-pt FFT waterfall + 12 kHz IQ audio chain).
+ *
+ * The reference (mcogoni/supersdr) is pure Python and has no FFI for this path; its
+ * boundary is two worker classes and one callback hierarchy.
+ * Each entry point below names the reference interface it sits behind.  The Python
+ * host (supersdr_amd/) binds these with ctypes; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 (SSDR_OK) or
+ * a negative SSDR_E* code and never throws or aborts; the caller owns every host
+ * buffer; a ctx owns its device memory, stream and per-channel state; one ctx per
+ * GPU, single-owner (not thread-safe), used from the thread that created it.
+ *
+ * Data layouts (all little-endian, channel-major):
+ *   IQ in   : int16 [n_ch][n_frames*512][2]  interleaved I,Q -- the sample type of
+ *             KiwiSDRStream._process_aud's IQ branch (kiwi/client.py:443-454) before
+ *             its float conversion (host byte-swaps the wire's big-endian once).
+ *   WF out  : int16 [n_lines_out][n_ch][1024] -- SUM of `averaging` consecutive byte
+ *             lines, ascending frequency; float32(sum)/float32(N) is bit-identical to
+ *             the reference's np.mean time binning (utils_supersdr.py:881-888) and the
+ *             bytes carry the reference's wire semantics dBm = byte - 255
+ *             (utils_supersdr.py:780-791).
+ *   PCM out : int16 [n_ch][n_frames*512] -- what kiwi_sound.process_audio_stream
+ *             returns per SND frame (utils_supersdr.py:1044-1076).
+ *   RSSI out: float [n_ch][n_frames] dBm -- replaces the SND header's smeter field
+ *             (rssi = 0.1*smeter - 127, utils_supersdr.py:1068-1069).
+ */
+#ifndef SSDR_H
+#define SSDR_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSDR_NFFT 1024          /* kiwi_waterfall.WF_BINS        utils_supersdr.py:596 */
+#define SSDR_FRAME 512          /* KIWI_SAMPLES_PER_FRAME        utils_supersdr.py:909 */
+#define SSDR_RATE 12000         /* KIWI_RATE                     utils_supersdr.py:906 */
+#define SSDR_NTAP_MAX 128
+#define SSDR_HIST 128
+
+enum {
+    SSDR_OK = 0,
+    SSDR_EINVAL = -1,           /* bad argument                                         */
+    SSDR_ENOMEM = -2,           /* host or device allocation failed                     */
+    SSDR_EHIP = -3,             /* HIP runtime error (ssdr_last_hip_error has the text) */
+    SSDR_ENODEV = -4,           /* no such GPU                                          */
+    SSDR_ESTATE = -5            /* call out of order (e.g. run before push)             */
+};
+
+/* demodulator selection: "SET mod=%s" (utils_supersdr.py:1028; kiwi/client.py:217-249) */
+enum { SSDR_MODE_AM = 0, SSDR_MODE_LSB = 1, SSDR_MODE_USB = 2, SSDR_MODE_CW = 3, SSDR_MODE_NBFM = 4 };
+
+/* Per-channel parameters: the reference's a13 parameter surface:
+ *   "SET mod=%s low_cut=%d high_cut=%d freq=%.3f"              utils_supersdr.py:1028
+ *   "SET agc=%d hang=%d thresh=%d slope=%d decay=%d manGain=%d" utils_supersdr.py:1023 */
+typedef struct ssdr_chan_params {
+    int32_t mode;               /* SSDR_MODE_*                                          */
+    int32_t agc_on;             /* kiwi_sound.on      (utils_supersdr.py:937)           */
+    int32_t agc_hang;           /* kiwi_sound.hang    (:938)                            */
+    int32_t reserved;
+    double f_shift_hz;          /* tuning offset inside the 12 kHz IQ band              */
+    double low_cut, high_cut;   /* passband Hz (kiwi_sound.lc/hc, :932; change_passband)*/
+    double agc_thresh;          /* dBm  (:939, UI range -135..-20 supersdr.py:551-564)  */
+    double agc_slope;           /* dB   (:940)                                          */
+    double agc_decay;           /* ms   (:941-944)                                      */
+    double agc_man_gain;        /* dB   (:942)                                          */
+    double wf_cal_db;           /* additive waterfall calibration                       */
+    double smeter_cal_db;       /* dBFS->dBm offset (Kiwi default -13, :790)            */
+} ssdr_chan_params;
+
+/* Kernel-side constants derived from ssdr_chan_params (read back for tests). 64 B. */
+typedef struct ssdr_chan_consts {
+    uint32_t mode, ntap8, dphi1, dphi2;
+    float wf_cal_lin, smeter_cal_db;
+    float agc_c0, agc_c1, agc_knee, agc_delta8;
+    uint32_t hang_frames, ntap;
+    uint32_t pad[4];
+} ssdr_chan_consts;
+
+/* Per-channel carried state (read back / restored for tests and checkpointing). 64 B. */
+typedef struct ssdr_chan_state {
+    uint32_t phi1, phi2;
+    float dc, agc_d;
+    float agc_m[8];
+    float prev_re, prev_im;
+    uint32_t pad[2];
+} ssdr_chan_state;
+
+typedef struct ssdr_ctx ssdr_ctx;
+
+/* -- lifetime.  Stands where kiwi_waterfall.__init__/kiwi_sound.__init__ open their
+ *    server connections (utils_supersdr.py:606-745, :911-1007): one ctx serves
+ *    n_channels receivers.  nfft must be 1024 and frame 512. */
+int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t frame, ssdr_ctx **out);
+void ssdr_destroy(ssdr_ctx *ctx);
+
+/* -- control plane: the SET commands listed above.  Changing parameters keeps the
+ *    carried state (NCO phase, FIR history, AGC envelope), as a Kiwi server does. */
+int ssdr_set_params(ssdr_ctx *ctx, uint32_t first, uint32_t count, const ssdr_chan_params *p);
+int ssdr_default_params(int mode, ssdr_chan_params *out);      /* reference defaults, utils:42-50,936-944 */
+int ssdr_reset_state(ssdr_ctx *ctx, uint32_t first, uint32_t count);
+/* kiwi_waterfall.averaging_n (utils_supersdr.py:616, 881-886; supersdr.py:376-385), 1..100 */
+int ssdr_set_averaging(ssdr_ctx *ctx, uint32_t n);
+
+/* -- data plane.  ssdr_push_iq is the IQ ingest hook: KiwiSDRStream._process_iq_samples
+ *    (kiwi/client.py:493-494).  iq may be a host pointer (copied) or a device pointer
+ *    (referenced, must stay valid until the run_* calls on it have completed). */
+int ssdr_push_iq(ssdr_ctx *ctx, const int16_t *iq, uint32_t n_frames, int is_device);
+/* Fills what kiwi_waterfall.receive_spectrum leaves in self.spectrum (utils:780-785),
+ * for every channel and every completed averaging group of the pushed batch
+ * (n_frames must be even: one line per 1024 samples).  wf_sum_out may be NULL (results
+ * stay in the ctx's device buffer, see ssdr_wf_device). */
+int ssdr_run_wf(ssdr_ctx *ctx, int16_t *wf_sum_out, uint32_t *lines_ready, int out_is_device);
+/* Fills what kiwi_sound.process_audio_stream returns (utils:1044-1076): int16 PCM and
+ * rssi per 512-sample frame.  Either output may be NULL. */
+int ssdr_run_audio(ssdr_ctx *ctx, int16_t *pcm_out, float *rssi_out, int out_is_device);
+int ssdr_sync(ssdr_ctx *ctx);
+
+/* -- device-resident results of the last run_* (for zero-copy consumers and bench) */
+int ssdr_wf_device(ssdr_ctx *ctx, int16_t **ptr, uint32_t *lines);
+int ssdr_audio_device(ssdr_ctx *ctx, int16_t **pcm, float **rssi);
+
+/* -- measurement */
+int ssdr_set_stream(ssdr_ctx *ctx, void *hip_stream);           /* NULL = ctx's own stream */
+int ssdr_set_profiling(ssdr_ctx *ctx, int on);                  /* HIP-event pair around every launch */
+enum { SSDR_K_WF = 0, SSDR_K_AUDIO = 1, SSDR_K_SYNTH = 2, SSDR_K_COUNT = 3 };
+int ssdr_kernel_stats(ssdr_ctx *ctx, int which, float *total_ms, uint32_t *launches, int reset);
+int ssdr_elapsed_ms(ssdr_ctx *ctx, float *ms);                  /* last run_* call, device time */
+
+/* -- synthetic input generated on the device (bench): makes a batch of
+ *    n_frames frames for all channels the current input, as ssdr_push_iq would. */
+int ssdr_synth_iq(ssdr_ctx *ctx, uint32_t n_frames, uint32_t seed, uint32_t first_channel_id);
+int ssdr_read_input(ssdr_ctx *ctx, uint32_t first, uint32_t count, int16_t *iq_out);
+
+/* -- introspection for tests */
+enum { SSDR_T_WINDOW = 0, SSDR_T_TWIDDLE_RE = 1, SSDR_T_TWIDDLE_IM = 2, SSDR_T_DB_THRESH = 3 };
+int ssdr_table(int which, float *out, uint32_t n);             /* 1024 / 512 / 512 / 256 floats */
+int ssdr_compile_params(const ssdr_chan_params *p, ssdr_chan_consts *consts, float *taps /*[128]*/);
+int ssdr_get_consts(ssdr_ctx *ctx, uint32_t first, uint32_t count, ssdr_chan_consts *consts, float *taps);
+int ssdr_get_state(ssdr_ctx *ctx, uint32_t first, uint32_t count, ssdr_chan_state *state, int16_t *hist);
+int ssdr_set_state(ssdr_ctx *ctx, uint32_t first, uint32_t count, const ssdr_chan_state *state, const int16_t *hist);
+int ssdr_selftest_quantiser(ssdr_ctx *ctx, uint64_t *mismatches);   /* all positive floats vs binary search */
+
+const char *ssdr_strerror(int code);
+const char *ssdr_last_hip_error(void);
+const char *ssdr_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,383 @@
+/*
+ * ssdr_twin.c -- fp32 CPU restatement ("twin") of the SuperSDR DSP hot path.
+ *
+ * *** TEST INFRASTRUCTURE ONLY. ***  Built into oracle/libssdr_twin.so by
+ * oracle/Makefile.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it.  Nothing under supersdr_amd/ links or calls it.
+ *
+ * Role: oracle/ssdr_oracle.py (NumPy float64) is the normative definition of the
+ * path; this file restates the SAME algorithm in float32 with every rounding
+ * step spelled out (explicit fmaf, -ffp-contract=off, no libm transcendentals),
+ * so that a correct HIP implementation is bit-identical to it.  It is written
+ * as plain scalar loops (textbook radix-2 FFT, direct-form FIR, sequential
+ * scans "as a 64-lane machine would"), independently of the kernels' tiling.
+ *
+ * What is pinned and what is not:
+ *   - time binning == integer sum of byte lines: reference utils_supersdr.py:881-888
+ *     (np.mean of float32 byte values == int sum / N; golden: tests/golden/binning.npz)
+ *   - byte semantics dBm = byte - 255: utils_supersdr.py:788-789
+ *   - FIR tap formula: utils_supersdr.py:334-344 (taps arrive pre-designed)
+ *   - FFT / log-mag / NCO / demod / AGC arithmetic: ABSENT from the reference
+ *     (server-side) -> PARITY UNPINNED, defined by
+ *     ssdr_oracle.py and checked against it with the guard-band / 1e-5 RMS rule.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+
+#define NFFT 1024
+#define FRAME 512
+#define HIST 128
+#define NTAP_MAX 128
+#define NLANE 64
+
+/* ---------------------------------------------------------------- helpers */
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+/* sin/cos of 2*pi*(phase>>12)/2^20 : quadrant reduction + cephes-style minimax
+ * polynomials on [-pi/4, pi/4].  No libm. */
+static void sincos20(uint32_t phase, float *c_out, float *s_out)
+{
+    const float C_2PI_20 = 0x1.921fb6p-18f;        /* float32(2*pi/2^20) */
+    const float S1 = -1.6666654611e-1f, S2 = 8.3321608736e-3f, S3 = -1.9515295891e-4f;
+    const float C1 = 4.166664568298827e-2f, C2 = -1.388731625493765e-3f, C3 = 2.443315711809948e-5f;
+    uint32_t p20 = phase >> 12;
+    uint32_t k = (p20 + (1u << 17)) >> 18;
+    int32_t ri = (int32_t)p20 - (int32_t)(k << 18);
+    float th = (float)ri * C_2PI_20;
+    float t2 = th * th;
+    float u = fmaf(t2, S3, S2);
+    u = fmaf(t2, u, S1);
+    float s = fmaf(th * t2, u, th);
+    float v = fmaf(t2, C3, C2);
+    v = fmaf(t2, v, C1);
+    float c = fmaf(t2 * t2, v, fmaf(-0.5f, t2, 1.0f));
+    switch (k & 3u) {
+    case 0: *c_out = c;  *s_out = s;  break;
+    case 1: *c_out = -s; *s_out = c;  break;
+    case 2: *c_out = -c; *s_out = -s; break;
+    default: *c_out = s; *s_out = -c; break;
+    }
+}
+
+/* log2(x), x > 0 normal.  atanh series in s=(m-1)/(m+1), m in [0.707,1.414]. */
+static float log2p(float x)
+{
+    const float K2 = 0x1.715476p+1f;                 /* float32(2/ln 2) */
+    const float L1 = 0.33333333333f, L2 = 0.2f, L3 = 0.14285714286f, L4 = 0.11111111111f;
+    uint32_t I = f2u(x);
+    int32_t e = (int32_t)(I >> 23) - 127;
+    float m = u2f((I & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float z = s * s;
+    float t = fmaf(z, L4, L3);
+    t = fmaf(z, t, L2);
+    t = fmaf(z, t, L1);
+    t = z * t;
+    float sk = s * K2;
+    return (float)e + fmaf(sk, t, sk);
+}
+
+/* 2^y for |y| <= 126 */
+static float exp2p(float y)
+{
+    const float E1 = 0.69314718056f, E2 = 0.24022650696f, E3 = 0.055504108665f,
+                E4 = 0.0096181291076f, E5 = 0.0013333558146f, E6 = 0.00015403530393f,
+                E7 = 0.000015252733805f;
+    y = fminf(fmaxf(y, -126.0f), 126.0f);
+    float n = rintf(y);
+    float f = y - n;
+    float r = fmaf(E7, f, E6);
+    r = fmaf(r, f, E5);
+    r = fmaf(r, f, E4);
+    r = fmaf(r, f, E3);
+    r = fmaf(r, f, E2);
+    r = fmaf(r, f, E1);
+    r = fmaf(r, f, 1.0f);
+    return u2f(f2u(r) + ((uint32_t)(int32_t)n << 23));
+}
+
+/* atan2(y, x), cephes atanf reduction; IEEE divides only. */
+static float atan2p(float y, float x)
+{
+    const float A0 = -3.33329491539e-1f, A1 = 1.99777106478e-1f,
+                A2 = -1.38776856032e-1f, A3 = 8.05374449538e-2f;
+    const float PI_4 = 0.78539816339744831f, PI_2 = 1.5707963267948966f, PI_1 = 3.14159265358979323f;
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    if (mx == 0.0f) return 0.0f;
+    float t = mn / mx;
+    float u = t, off = 0.0f;
+    if (t > 0.41421356237f) { u = (t - 1.0f) / (t + 1.0f); off = PI_4; }
+    float z = u * u;
+    float q = fmaf(A3, z, A2);
+    q = fmaf(q, z, A1);
+    q = fmaf(q, z, A0);
+    float r = off + fmaf(u * z, q, u);
+    if (ay > ax) r = PI_2 - r;
+    if (x < 0.0f) r = PI_1 - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+/* byte = #{k in 1..255 : T[k] <= p} */
+static int quantise(float p, const float *T)
+{
+    int lo = 0, hi = 255;          /* invariant: T[lo] <= p (lo=0 is a sentinel), T[hi+1] > p */
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (T[mid] <= p) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+int twin_quantise(float p, const float *T) { return quantise(p, T); }
+float twin_log2p(float x) { return log2p(x); }
+float twin_exp2p(float x) { return exp2p(x); }
+float twin_atan2p(float y, float x) { return atan2p(y, x); }
+void twin_sincos20(uint32_t ph, float *c, float *s) { sincos20(ph, c, s); }
+
+/* ------------------------------------------------------------------ tables */
+/* Restates the table definitions (double libm, rounded once to float32). */
+void twin_make_tables(float *win /*1024*/, float *wr /*512*/, float *wi /*512*/, float *thr /*256*/)
+{
+    const double PI = 3.14159265358979323846;
+    for (int n = 0; n < NFFT; n++) win[n] = (float)(0.5 - 0.5 * cos(2.0 * PI * n / NFFT));
+    for (int m = 0; m < 512; m++) {
+        wr[m] = (float)cos(2.0 * PI * m / NFFT);
+        wi[m] = (float)(-sin(2.0 * PI * m / NFFT));
+    }
+    wr[0] = 1.0f; wi[0] = 0.0f; wr[256] = 0.0f; wi[256] = -1.0f;
+    for (int k = 0; k < 256; k++) thr[k] = (float)(pow(10.0, (k - 255) / 10.0) * 281474976710656.0);
+}
+
+/* --------------------------------------------------------------- waterfall */
+static uint32_t bitrev10(uint32_t v)
+{
+    uint32_t r = 0;
+    for (int b = 0; b < 10; b++) r |= ((v >> b) & 1u) << (9 - b);
+    return r;
+}
+
+/* textbook iterative radix-2 DIT, fused-multiply-add butterflies */
+static void fft1024(float *re, float *im, const float *wr, const float *wi)
+{
+    for (uint32_t i = 0; i < NFFT; i++) {
+        uint32_t j = bitrev10(i);
+        if (j > i) {
+            float t = re[i]; re[i] = re[j]; re[j] = t;
+            t = im[i]; im[i] = im[j]; im[j] = t;
+        }
+    }
+    for (int s = 1; s <= 10; s++) {
+        int half = 1 << (s - 1), step = NFFT >> s;
+        for (int blk = 0; blk < NFFT; blk += 2 * half) {
+            for (int k = 0; k < half; k++) {
+                int m = k * step, i = blk + k, j = i + half;
+                float tr, ti;
+                if (m == 0) { tr = re[j]; ti = im[j]; }
+                else if (m == 256) { tr = im[j]; ti = -re[j]; }
+                else {
+                    float a = wr[m], b = wi[m];
+                    tr = fmaf(a, re[j], -(b * im[j]));
+                    ti = fmaf(a, im[j], b * re[j]);
+                }
+                float ur = re[i], ui = im[i];
+                re[i] = ur + tr; im[i] = ui + ti;
+                re[j] = ur - tr; im[j] = ui - ti;
+            }
+        }
+    }
+}
+
+/* one line: int16 IQ[1024][2] -> bytes[1024], ascending frequency (fftshift) */
+void twin_wf_line(const int16_t *iq, const float *win, const float *wr, const float *wi,
+                  const float *thr, float cal_lin, uint8_t *out)
+{
+    float re[NFFT], im[NFFT];
+    for (int n = 0; n < NFFT; n++) {
+        re[n] = (float)iq[2 * n] * win[n];
+        im[n] = (float)iq[2 * n + 1] * win[n];
+    }
+    fft1024(re, im, wr, wi);
+    for (int k = 0; k < NFFT; k++) {
+        float p = fmaf(re[k], re[k], im[k] * im[k]) * cal_lin;
+        out[(k + 512) & 1023] = (uint8_t)quantise(p, thr);
+    }
+}
+
+/* batch: iq[n_ch][n_lines*1024][2] -> out[n_lines/n_avg][n_ch][1024] int16 sums */
+void twin_wf(const int16_t *iq, uint32_t n_ch, uint32_t n_lines, uint32_t n_avg,
+             const float *cal_lin /*[n_ch]*/, const float *win, const float *wr, const float *wi,
+             const float *thr, int16_t *out)
+{
+    uint32_t n_out = n_lines / n_avg;
+    uint8_t b[NFFT];
+    for (uint32_t c = 0; c < n_ch; c++) {
+        for (uint32_t o = 0; o < n_out; o++) {
+            int16_t *dst = out + ((size_t)o * n_ch + c) * NFFT;
+            memset(dst, 0, NFFT * sizeof(int16_t));
+            for (uint32_t a = 0; a < n_avg; a++) {
+                const int16_t *src = iq + ((size_t)c * n_lines + (size_t)o * n_avg + a) * NFFT * 2;
+                twin_wf_line(src, win, wr, wi, thr, cal_lin[c], b);
+                for (int k = 0; k < NFFT; k++) dst[k] = (int16_t)(dst[k] + b[k]);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------- audio */
+typedef struct {            /* per-channel kernel constants; same layout as the product's */
+    uint32_t mode;          /* 0 am, 1 lsb, 2 usb, 3 cw, 4 nbfm */
+    uint32_t ntap8;         /* taps in use, rounded up to a multiple of 8 (zero padded) */
+    uint32_t dphi1, dphi2;  /* NCO steps: input mixer, SSB re-mixer */
+    float wf_cal_lin, smeter_cal_db;
+    float agc_c0, agc_c1, agc_knee, agc_delta8;
+    uint32_t hang_frames, ntap;
+    uint32_t pad[4];
+} twin_consts;              /* 64 bytes */
+
+typedef struct {
+    uint32_t phi1, phi2;
+    float dc, agc_d;
+    float agc_m[8];
+    float prev_re, prev_im;
+    uint32_t pad[2];
+} twin_state;               /* 64 bytes */
+
+static const float DC_A = 0.9921875f, DC_AL = 0.0078125f;
+/* float32((127/128)^(j+1)), j = 0..7 */
+static const float DC_APOW[8] = { 0x1.fcp-1f, 0x1.f808p-1f, 0x1.f417fp-1f, 0x1.f02fcp-1f,
+                                  0x1.ec4f6p-1f, 0x1.e876c2p-1f, 0x1.e4a5d4p-1f, 0x1.e0dc88p-1f };
+static const float KFM = 0x1.8723a2p+12f;   /* float32(16384*12000/(2*pi*5000)) = 6258.227 */
+static const float P_FLOOR = 9.5367431640625e-07f;   /* 2^-20 */
+
+static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, const float *taps,
+                        twin_state *st, int16_t *hist /*[HIST][2]*/, int16_t *pcm, float *rssi)
+{
+    static _Thread_local float z1r[HIST + FRAME], z1i[HIST + FRAME];
+    float z2r[FRAME], z2i[FRAME], p[FRAME], aud[FRAME];
+    /* 1. NCO mix of history + frame */
+    for (int i = -HIST; i < FRAME; i++) {
+        const int16_t *s = (i < 0) ? hist + 2 * (HIST + i) : iq + 2 * i;
+        float xr = (float)s[0], xi = (float)s[1], co, si;
+        sincos20(st->phi1 + (uint32_t)i * c->dphi1, &co, &si);
+        z1r[HIST + i] = fmaf(xr, co, xi * si);
+        z1i[HIST + i] = fmaf(xi, co, -(xr * si));
+    }
+    /* 2. FIR, taps ascending, fma chain from zero */
+    for (int n = 0; n < FRAME; n++) {
+        float ar = 0.0f, ai = 0.0f;
+        for (uint32_t k = 0; k < c->ntap8; k++) {
+            ar = fmaf(taps[k], z1r[HIST + n - (int)k], ar);
+            ai = fmaf(taps[k], z1i[HIST + n - (int)k], ai);
+        }
+        z2r[n] = ar; z2i[n] = ai;
+        p[n] = fmaf(ar, ar, ai * ai);
+    }
+    /* 3. demod */
+    if (c->mode == 0) {
+        float env[FRAME], loc[NLANE][8], A[NLANE], B[NLANE], An[NLANE], Bn[NLANE];
+        for (int n = 0; n < FRAME; n++) env[n] = sqrtf(p[n]);
+        for (int l = 0; l < NLANE; l++) {
+            float s = 0.0f;
+            for (int j = 0; j < 8; j++) { s = fmaf(DC_A, s, DC_AL * env[8 * l + j]); loc[l][j] = s; }
+            B[l] = s; A[l] = DC_APOW[7];
+        }
+        for (int d = 1; d < NLANE; d <<= 1) {       /* Kogge-Stone over lanes */
+            for (int l = 0; l < NLANE; l++) {
+                if (l >= d) { Bn[l] = fmaf(A[l], B[l - d], B[l]); An[l] = A[l] * A[l - d]; }
+                else { Bn[l] = B[l]; An[l] = A[l]; }
+            }
+            memcpy(A, An, sizeof A); memcpy(B, Bn, sizeof B);
+        }
+        for (int l = 0; l < NLANE; l++) {
+            float carry = (l == 0) ? st->dc : fmaf(A[l - 1], st->dc, B[l - 1]);
+            for (int j = 0; j < 8; j++) {
+                float m = fmaf(DC_APOW[j], carry, loc[l][j]);
+                aud[8 * l + j] = env[8 * l + j] - m;
+                if (l == NLANE - 1 && j == 7) st->dc = m;
+            }
+        }
+    } else if (c->mode <= 3) {
+        for (int n = 0; n < FRAME; n++) {
+            float co, si;
+            sincos20(st->phi2 + (uint32_t)n * c->dphi2, &co, &si);
+            aud[n] = fmaf(z2r[n], co, -(z2i[n] * si));
+        }
+    } else {
+        float pr = st->prev_re, pi = st->prev_im;
+        for (int n = 0; n < FRAME; n++) {
+            float dr = fmaf(z2r[n], pr, z2i[n] * pi);
+            float di = fmaf(z2i[n], pr, -(z2r[n] * pi));
+            aud[n] = atan2p(di, dr) * KFM;
+            pr = z2r[n]; pi = z2i[n];
+        }
+    }
+    st->prev_re = z2r[FRAME - 1]; st->prev_im = z2i[FRAME - 1];
+    /* 4. AGC per 8-sample block */
+    float a[NLANE], e[NLANE], psum[NLANE];
+    float amax = -3.0e38f;
+    for (int l = 0; l < NLANE; l++) {
+        float pm = p[8 * l], s = p[8 * l];
+        for (int j = 1; j < 8; j++) { pm = fmaxf(pm, p[8 * l + j]); s = s + p[8 * l + j]; }
+        psum[l] = s;
+        a[l] = log2p(fmaxf(pm, P_FLOOR));
+        amax = fmaxf(amax, a[l]);
+    }
+    uint32_t K = c->hang_frames;
+    float d8 = c->agc_delta8;
+    if (K == 0) {
+        float P = -3.0e38f;
+        for (int l = 0; l < NLANE; l++) {
+            P = fmaxf(P, fmaf((float)l, d8, a[l]));
+            e[l] = fmaxf(fmaf(-(float)l, d8, P), fmaf(-(float)(l + 1), d8, st->agc_d));
+        }
+        st->agc_d = e[NLANE - 1];
+    } else {
+        float maxM = st->agc_m[0], P = -3.0e38f;
+        for (uint32_t i = 1; i < K; i++) maxM = fmaxf(maxM, st->agc_m[i]);
+        for (int l = 0; l < NLANE; l++) {
+            P = fmaxf(P, a[l]);
+            e[l] = fmaxf(fmaxf(P, maxM), fmaf(-(float)(l + 1), d8, st->agc_d));
+        }
+        st->agc_d = fmaxf(fmaf(-64.0f, d8, st->agc_d), st->agc_m[K - 1]);
+        for (int i = 7; i > 0; i--) st->agc_m[i] = st->agc_m[i - 1];
+        st->agc_m[0] = amax;
+    }
+    for (int l = 0; l < NLANE; l++) {
+        float g = exp2p(fmaf(c->agc_c1, fmaxf(e[l], c->agc_knee), c->agc_c0));
+        for (int j = 0; j < 8; j++) {
+            float y = rintf(aud[8 * l + j] * g);
+            y = fminf(fmaxf(y, -32768.0f), 32767.0f);
+            pcm[8 * l + j] = (int16_t)(int32_t)y;
+        }
+    }
+    /* 5. rssi: xor-butterfly sum over lanes */
+    for (int d = 32; d >= 1; d >>= 1) {
+        float t[NLANE];
+        for (int l = 0; l < NLANE; l++) t[l] = psum[l] + psum[l ^ d];
+        memcpy(psum, t, sizeof t);
+    }
+    *rssi = fmaf(log2p(fmaxf(psum[0], 1e-20f)) - 39.0f, 0x1.815182p+1f /* 10*log10(2) */, c->smeter_cal_db);
+    /* 6. state carry */
+    st->phi1 += (uint32_t)FRAME * c->dphi1;
+    st->phi2 += (uint32_t)FRAME * c->dphi2;
+    /* HIST <= FRAME: the new history is the frame tail */
+    memcpy(hist, iq + 2 * (FRAME - HIST), HIST * 2 * sizeof(int16_t));
+}
+
+/* batch: iq[n_ch][n_frames*512][2]; consts[n_ch]; taps[n_ch][128]; state[n_ch]; hist[n_ch][128][2]
+ * -> pcm[n_ch][n_frames*512], rssi[n_ch][n_frames]; state and hist updated in place. */
+void twin_audio(const int16_t *iq, uint32_t n_ch, uint32_t n_frames, const twin_consts *consts,
+                const float *taps, twin_state *state, int16_t *hist, int16_t *pcm, float *rssi)
+{
+    for (uint32_t c = 0; c < n_ch; c++)
+        for (uint32_t f = 0; f < n_frames; f++)
+            audio_frame(iq + ((size_t)c * n_frames + f) * FRAME * 2, consts + c,
+                        taps + (size_t)c * NTAP_MAX, state + c, hist + (size_t)c * HIST * 2,
+                        pcm + ((size_t)c * n_frames + f) * FRAME, rssi + (size_t)c * n_frames + f);
+}

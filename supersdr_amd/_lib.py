@@ -1,0 +1,100 @@
+"""ctypes binding of libssdr.so (include/ssdr.h).
+
+The HIP library is the product: if it is missing this module raises ImportError
+loudly -- there is no CPU or NumPy fallback anywhere in supersdr_amd.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssdr.so")
+
+NFFT, FRAME, RATE, NTAP_MAX, HIST = 1024, 512, 12000, 128, 128
+OK, EINVAL, ENOMEM, EHIP, ENODEV, ESTATE = 0, -1, -2, -3, -4, -5
+MODE_AM, MODE_LSB, MODE_USB, MODE_CW, MODE_NBFM = range(5)
+MODE_BY_NAME = {"am": 0, "lsb": 1, "usb": 2, "cw": 3, "nbfm": 4, "nfm": 4}
+K_WF, K_AUDIO, K_SYNTH = 0, 1, 2
+T_WINDOW, T_TWIDDLE_RE, T_TWIDDLE_IM, T_DB_THRESH = range(4)
+
+
+class ChanParams(C.Structure):
+    """ssdr_chan_params: "SET mod=/low_cut=/high_cut=/freq=" and "SET agc=..." of
+    utils_supersdr.py:1023,1028."""
+    _fields_ = [("mode", C.c_int32), ("agc_on", C.c_int32), ("agc_hang", C.c_int32), ("reserved", C.c_int32),
+                ("f_shift_hz", C.c_double), ("low_cut", C.c_double), ("high_cut", C.c_double),
+                ("agc_thresh", C.c_double), ("agc_slope", C.c_double), ("agc_decay", C.c_double),
+                ("agc_man_gain", C.c_double), ("wf_cal_db", C.c_double), ("smeter_cal_db", C.c_double)]
+
+
+class ChanConsts(C.Structure):
+    _fields_ = [("mode", C.c_uint32), ("ntap8", C.c_uint32), ("dphi1", C.c_uint32), ("dphi2", C.c_uint32),
+                ("wf_cal_lin", C.c_float), ("smeter_cal_db", C.c_float),
+                ("agc_c0", C.c_float), ("agc_c1", C.c_float), ("agc_knee", C.c_float), ("agc_delta8", C.c_float),
+                ("hang_frames", C.c_uint32), ("ntap", C.c_uint32), ("pad", C.c_uint32 * 4)]
+
+
+class ChanState(C.Structure):
+    _fields_ = [("phi1", C.c_uint32), ("phi2", C.c_uint32), ("dc", C.c_float), ("agc_d", C.c_float),
+                ("agc_m", C.c_float * 8), ("prev_re", C.c_float), ("prev_im", C.c_float), ("pad", C.c_uint32 * 2)]
+
+
+assert C.sizeof(ChanConsts) == 64 and C.sizeof(ChanState) == 64 and C.sizeof(ChanParams) == 88
+
+_P = C.c_void_p
+_SIGS = {
+    "ssdr_create": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_P)]),
+    "ssdr_destroy": (None, [_P]),
+    "ssdr_set_params": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.POINTER(ChanParams)]),
+    "ssdr_default_params": (C.c_int, [C.c_int, C.POINTER(ChanParams)]),
+    "ssdr_reset_state": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "ssdr_set_averaging": (C.c_int, [_P, C.c_uint32]),
+    "ssdr_push_iq": (C.c_int, [_P, _P, C.c_uint32, C.c_int]),
+    "ssdr_run_wf": (C.c_int, [_P, _P, C.POINTER(C.c_uint32), C.c_int]),
+    "ssdr_run_audio": (C.c_int, [_P, _P, _P, C.c_int]),
+    "ssdr_sync": (C.c_int, [_P]),
+    "ssdr_wf_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32)]),
+    "ssdr_audio_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
+    "ssdr_set_stream": (C.c_int, [_P, _P]),
+    "ssdr_set_profiling": (C.c_int, [_P, C.c_int]),
+    "ssdr_kernel_stats": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_int]),
+    "ssdr_elapsed_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "ssdr_synth_iq": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
+    "ssdr_read_input": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
+    "ssdr_table": (C.c_int, [C.c_int, _P, C.c_uint32]),
+    "ssdr_compile_params": (C.c_int, [C.POINTER(ChanParams), C.POINTER(ChanConsts), _P]),
+    "ssdr_get_consts": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
+    "ssdr_get_state": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
+    "ssdr_set_state": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
+    "ssdr_selftest_quantiser": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "ssdr_strerror": (C.c_char_p, [C.c_int]),
+    "ssdr_last_hip_error": (C.c_char_p, []),
+    "ssdr_version": (C.c_char_p, []),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "supersdr_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C supersdr_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError here == header/library mismatch
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+class SsdrError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        detail = lib.ssdr_last_hip_error().decode() if code == EHIP else ""
+        super().__init__("%s: %s (%d) %s" % (where, lib.ssdr_strerror(code).decode(), code, detail))
+
+
+def check(code, where):
+    if code != OK:
+        raise SsdrError(code, where)

@@ -1,0 +1,555 @@
+// ssdr_api.cpp -- C-ABI of libssdr.so (see include/ssdr.h).  Host side only: owns the
+// device buffers, the per-channel state and the stream; launches the HIP kernels.
+// Never throws, never aborts: every failure is a negative return code.
+#include "ssdr_kernels.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+static thread_local char g_hip_err[256] = "";
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t e_ = (expr);                                                         \
+        if (e_ != hipSuccess) {                                                         \
+            snprintf(g_hip_err, sizeof g_hip_err, "%s: %s", #expr, hipGetErrorString(e_)); \
+            return e_ == hipErrorOutOfMemory ? SSDR_ENOMEM : SSDR_EHIP;                 \
+        }                                                                               \
+    } while (0)
+
+struct ssdr_ctx {
+    int device = 0;
+    uint32_t n_ch = 0;
+    uint32_t n_avg = 1, wf_phase = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // tables
+    float *d_win = nullptr, *d_thr = nullptr;
+    float2 *d_tw = nullptr;
+    // per-channel
+    ssdr_chan_consts *d_consts = nullptr;
+    float *d_taps = nullptr;
+    ssdr_chan_state *d_state = nullptr;
+    uint32_t *d_hist = nullptr;
+    int16_t *d_wf_acc = nullptr;
+    // input batch
+    uint32_t *d_iq_own = nullptr;
+    size_t iq_own_frames = 0;
+    const uint32_t *d_iq = nullptr;
+    uint32_t in_frames = 0;
+    bool have_input = false;
+    uint64_t synth_sample0 = 0;
+    // outputs
+    int16_t *d_wf_out = nullptr;
+    size_t wf_out_lines = 0;
+    uint32_t wf_lines_ready = 0;
+    int16_t *d_pcm = nullptr;
+    float *d_rssi = nullptr;
+    size_t audio_frames = 0;
+    // measurement
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;            // last launch (ssdr_elapsed_ms)
+    struct Pending { hipEvent_t e0, e1; int which; };
+    std::vector<Pending> pending;                       // profiling: resolved lazily, no sync per launch
+    std::vector<hipEvent_t> free_events;
+    float k_ms[SSDR_K_COUNT] = {0, 0, 0};
+    uint32_t k_n[SSDR_K_COUNT] = {0, 0, 0};
+    float last_ms = 0.0f;
+    uint32_t wf_grid = 0;
+    unsigned long long *d_scratch = nullptr;
+};
+
+static int get_event(ssdr_ctx *c, hipEvent_t *e)
+{
+    if (!c->free_events.empty()) { *e = c->free_events.back(); c->free_events.pop_back(); return SSDR_OK; }
+    HIP_TRY(hipEventCreate(e));
+    return SSDR_OK;
+}
+// HIP events on the stream the kernel is launched on, bracketing exactly one launch.
+static int timed_begin(ssdr_ctx *c)
+{
+    if (c->profiling) {
+        ssdr_ctx::Pending p{nullptr, nullptr, -1};
+        int rc;
+        if ((rc = get_event(c, &p.e0)) != SSDR_OK) return rc;
+        if ((rc = get_event(c, &p.e1)) != SSDR_OK) return rc;
+        c->pending.push_back(p);
+        HIP_TRY(hipEventRecord(p.e0, c->stream));
+    } else {
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    }
+    return SSDR_OK;
+}
+static int timed_end(ssdr_ctx *c, int which)
+{
+    if (c->profiling) {
+        c->pending.back().which = which;
+        HIP_TRY(hipEventRecord(c->pending.back().e1, c->stream));
+    } else {
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    }
+    return SSDR_OK;
+}
+static int resolve_pending(ssdr_ctx *c)
+{
+    for (auto &p : c->pending) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventSynchronize(p.e1));
+        HIP_TRY(hipEventElapsedTime(&ms, p.e0, p.e1));
+        if (p.which >= 0) { c->k_ms[p.which] += ms; c->k_n[p.which] += 1; c->last_ms = ms; }
+        c->free_events.push_back(p.e0);
+        c->free_events.push_back(p.e1);
+    }
+    c->pending.clear();
+    return SSDR_OK;
+}
+
+extern "C" {
+
+const char *ssdr_version(void) { return "supersdr_amd 0.1 (gfx950)"; }
+const char *ssdr_last_hip_error(void) { return g_hip_err; }
+
+const char *ssdr_strerror(int code)
+{
+    switch (code) {
+    case SSDR_OK: return "ok";
+    case SSDR_EINVAL: return "invalid argument";
+    case SSDR_ENOMEM: return "out of memory";
+    case SSDR_EHIP: return "HIP runtime error";
+    case SSDR_ENODEV: return "no such GPU device";
+    case SSDR_ESTATE: return "call out of order";
+    default: return "unknown error";
+    }
+}
+
+void ssdr_destroy(ssdr_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+    void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_wf_acc,
+                    c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_scratch};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto &p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    for (auto e : c->free_events) (void)hipEventDestroy(e);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int ssdr_default_params(int mode, ssdr_chan_params *p)
+{
+    if (!p || mode < SSDR_MODE_AM || mode > SSDR_MODE_NBFM) return SSDR_EINVAL;
+    memset(p, 0, sizeof *p);
+    p->mode = mode;
+    p->agc_on = 1;                    // utils_supersdr.py:937
+    p->agc_hang = 0;                  // :938
+    p->agc_thresh = -80.0;            // :939
+    p->agc_slope = 0.0;               // :940
+    p->agc_decay = (mode == SSDR_MODE_CW) ? 1000.0 : 4000.0;   // :941-942
+    p->agc_man_gain = 50.0;           // :943
+    p->wf_cal_db = 0.0;
+    p->smeter_cal_db = -13.0;         // :790
+    switch (mode) {                   // passbands: utils_supersdr.py:46-50, kiwi/client.py:217-249
+    case SSDR_MODE_AM: p->low_cut = -6000.0; p->high_cut = 6000.0; break;
+    case SSDR_MODE_LSB: p->low_cut = -3000.0; p->high_cut = -30.0; break;
+    case SSDR_MODE_USB: p->low_cut = 30.0; p->high_cut = 3000.0; break;
+    case SSDR_MODE_CW: p->low_cut = 400.0; p->high_cut = 800.0; break;
+    default: p->low_cut = -6000.0; p->high_cut = 6000.0; break;
+    }
+    return SSDR_OK;
+}
+
+int ssdr_compile_params(const ssdr_chan_params *p, ssdr_chan_consts *consts, float *taps)
+{
+    return ssdr_compile_params_host(p, consts, taps);
+}
+
+int ssdr_table(int which, float *out, uint32_t n)
+{
+    if (!out) return SSDR_EINVAL;
+    float wr[512], wi[512];
+    switch (which) {
+    case SSDR_T_WINDOW:
+        if (n != SSDR_NFFT) return SSDR_EINVAL;
+        ssdr_make_window(out);
+        return SSDR_OK;
+    case SSDR_T_TWIDDLE_RE:
+    case SSDR_T_TWIDDLE_IM:
+        if (n != 512) return SSDR_EINVAL;
+        ssdr_make_twiddles(wr, wi);
+        memcpy(out, which == SSDR_T_TWIDDLE_RE ? wr : wi, sizeof wr);
+        return SSDR_OK;
+    case SSDR_T_DB_THRESH:
+        if (n != 256) return SSDR_EINVAL;
+        ssdr_make_thresholds(out);
+        return SSDR_OK;
+    default: return SSDR_EINVAL;
+    }
+}
+
+int ssdr_reset_state(ssdr_ctx *c, uint32_t first, uint32_t count)
+{
+    if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
+    if (!count) return SSDR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<ssdr_chan_consts> k(count);
+    HIP_TRY(hipMemcpyAsync(k.data(), c->d_consts + first, count * sizeof(ssdr_chan_consts), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<ssdr_chan_state> st(count);
+    for (uint32_t i = 0; i < count; i++) {
+        memset(&st[i], 0, sizeof st[i]);
+        st[i].agc_d = k[i].agc_knee;          // envelope starts at the knee: full gain, no pop
+        for (int j = 0; j < 8; j++) st[i].agc_m[j] = -1000.0f;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_state + first, st.data(), count * sizeof(ssdr_chan_state), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_hist + (size_t)first * SSDR_HIST, 0, (size_t)count * SSDR_HIST * 4, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_wf_acc + (size_t)first * SSDR_NFFT, 0, (size_t)count * SSDR_NFFT * 2, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (first == 0 && count == c->n_ch) { c->wf_phase = 0; c->synth_sample0 = 0; }
+    return SSDR_OK;
+}
+
+int ssdr_set_params(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan_params *p)
+{
+    if (!c || !p || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
+    if (!count) return SSDR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<ssdr_chan_consts> k(count);
+    std::vector<float> taps((size_t)count * SSDR_NTAP_MAX);
+    for (uint32_t i = 0; i < count; i++) {
+        const int rc = ssdr_compile_params_host(p + i, &k[i], taps.data() + (size_t)i * SSDR_NTAP_MAX);
+        if (rc != SSDR_OK) return rc;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_consts + first, k.data(), count * sizeof(ssdr_chan_consts), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_taps + (size_t)first * SSDR_NTAP_MAX, taps.data(), taps.size() * sizeof(float),
+                           hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t frame, ssdr_ctx **out)
+{
+    if (!out) return SSDR_EINVAL;
+    *out = nullptr;
+    if (nfft != SSDR_NFFT || frame != SSDR_FRAME || n_channels == 0) return SSDR_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) {
+        snprintf(g_hip_err, sizeof g_hip_err, "hipGetDeviceCount: %d device(s), asked for %d", ndev, device_id);
+        return SSDR_ENODEV;
+    }
+    ssdr_ctx *c = new (std::nothrow) ssdr_ctx;
+    if (!c) return SSDR_ENOMEM;
+    c->device = device_id;
+    c->n_ch = n_channels;
+    int rc = [&]() -> int {
+        HIP_TRY(hipSetDevice(device_id));
+        HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+        c->stream = c->own_stream;
+        HIP_TRY(hipEventCreate(&c->ev0));
+        HIP_TRY(hipEventCreate(&c->ev1));
+        HIP_TRY(hipMalloc(&c->d_win, SSDR_NFFT * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->d_thr, 256 * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->d_tw, SSDR_TW_STAGE_N * sizeof(float2)));
+        HIP_TRY(hipMalloc(&c->d_consts, (size_t)n_channels * sizeof(ssdr_chan_consts)));
+        HIP_TRY(hipMalloc(&c->d_taps, (size_t)n_channels * SSDR_NTAP_MAX * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->d_state, (size_t)n_channels * sizeof(ssdr_chan_state)));
+        HIP_TRY(hipMalloc(&c->d_hist, (size_t)n_channels * SSDR_HIST * 4));
+        HIP_TRY(hipMalloc(&c->d_wf_acc, (size_t)n_channels * SSDR_NFFT * 2));
+        HIP_TRY(hipMalloc(&c->d_scratch, 64));
+        std::vector<float> win(SSDR_NFFT), thr(256);
+        std::vector<float2> tw(SSDR_TW_STAGE_N);
+        ssdr_make_window(win.data());
+        ssdr_make_thresholds(thr.data());
+        ssdr_make_tw_stage(tw.data());
+        HIP_TRY(hipMemcpy(c->d_win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_thr, thr.data(), thr.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+        c->wf_grid = (uint32_t)prop.multiProcessorCount * 3u;     // 3 x 256-thread workgroups per CU (LDS-bound)
+        return SSDR_OK;
+    }();
+    if (rc == SSDR_OK) {
+        // every channel starts as the reference's default receiver: AM, AGC on (utils:936-944)
+        ssdr_chan_params dp;
+        ssdr_default_params(SSDR_MODE_AM, &dp);
+        std::vector<ssdr_chan_params> all(n_channels, dp);
+        rc = ssdr_set_params(c, 0, n_channels, all.data());
+    }
+    if (rc == SSDR_OK) rc = ssdr_reset_state(c, 0, n_channels);
+    if (rc != SSDR_OK) { ssdr_destroy(c); return rc; }
+    *out = c;
+    return SSDR_OK;
+}
+
+int ssdr_set_averaging(ssdr_ctx *c, uint32_t n)
+{
+    if (!c || n < 1 || n > 100) return SSDR_EINVAL;      // supersdr.py:376-385: averaging_n in 1..100
+    if (n != c->n_avg) {
+        // like the reference (a new deque per output line, utils:882), a change restarts the group
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipMemsetAsync(c->d_wf_acc, 0, (size_t)c->n_ch * SSDR_NFFT * 2, c->stream));
+        c->wf_phase = 0;
+        c->n_avg = n;
+    }
+    return SSDR_OK;
+}
+
+int ssdr_set_stream(ssdr_ctx *c, void *hip_stream)
+{
+    if (!c) return SSDR_EINVAL;
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return SSDR_OK;
+}
+
+int ssdr_set_profiling(ssdr_ctx *c, int on)
+{
+    if (!c) return SSDR_EINVAL;
+    c->profiling = on != 0;
+    return SSDR_OK;
+}
+
+int ssdr_kernel_stats(ssdr_ctx *c, int which, float *total_ms, uint32_t *launches, int reset)
+{
+    if (!c || which < 0 || which >= SSDR_K_COUNT) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = resolve_pending(c);
+    if (rc != SSDR_OK) return rc;
+    if (total_ms) *total_ms = c->k_ms[which];
+    if (launches) *launches = c->k_n[which];
+    if (reset) { c->k_ms[which] = 0.0f; c->k_n[which] = 0; }
+    return SSDR_OK;
+}
+
+int ssdr_elapsed_ms(ssdr_ctx *c, float *ms)
+{
+    if (!c || !ms) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->profiling) {
+        int rc = resolve_pending(c);
+        if (rc != SSDR_OK) return rc;
+        *ms = c->last_ms;
+        return SSDR_OK;
+    }
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return SSDR_OK;
+}
+
+int ssdr_sync(ssdr_ctx *c)
+{
+    if (!c) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+static int ensure_input(ssdr_ctx *c, uint32_t n_frames)
+{
+    if (c->iq_own_frames < n_frames) {
+        if (c->d_iq_own) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_iq_own)); c->d_iq_own = nullptr; c->iq_own_frames = 0; }
+        HIP_TRY(hipMalloc(&c->d_iq_own, (size_t)c->n_ch * n_frames * SSDR_FRAME * 4));
+        c->iq_own_frames = n_frames;
+    }
+    return SSDR_OK;
+}
+
+int ssdr_push_iq(ssdr_ctx *c, const int16_t *iq, uint32_t n_frames, int is_device)
+{
+    if (!c || !iq || n_frames == 0) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    if (is_device) {
+        c->d_iq = reinterpret_cast<const uint32_t *>(iq);
+    } else {
+        int rc = ensure_input(c, n_frames);
+        if (rc != SSDR_OK) return rc;
+        HIP_TRY(hipMemcpyAsync(c->d_iq_own, iq, (size_t)c->n_ch * n_frames * SSDR_FRAME * 4, hipMemcpyHostToDevice, c->stream));
+        c->d_iq = c->d_iq_own;
+    }
+    c->in_frames = n_frames;
+    c->have_input = true;
+    return SSDR_OK;
+}
+
+int ssdr_synth_iq(ssdr_ctx *c, uint32_t n_frames, uint32_t seed, uint32_t first_channel_id)
+{
+    if (!c || n_frames == 0) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_input(c, n_frames);
+    if (rc != SSDR_OK) return rc;
+    SsdrSynthArgs a;
+    a.iq = c->d_iq_own;
+    a.ch_stride = (uint64_t)n_frames * SSDR_FRAME;
+    a.n_ch = c->n_ch;
+    a.n_samples = n_frames * SSDR_FRAME;
+    a.seed = seed;
+    a.first_channel_id = first_channel_id;
+    a.sample0 = c->synth_sample0;
+    if ((rc = timed_begin(c)) != SSDR_OK) return rc;
+    HIP_TRY(ssdr_launch_synth(a, c->stream));
+    if ((rc = timed_end(c, SSDR_K_SYNTH)) != SSDR_OK) return rc;
+    c->synth_sample0 += a.n_samples;
+    c->d_iq = c->d_iq_own;
+    c->in_frames = n_frames;
+    c->have_input = true;
+    return SSDR_OK;
+}
+
+int ssdr_read_input(ssdr_ctx *c, uint32_t first, uint32_t count, int16_t *iq_out)
+{
+    if (!c || !iq_out || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
+    if (!c->have_input) return SSDR_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t per_ch = (size_t)c->in_frames * SSDR_FRAME;
+    HIP_TRY(hipMemcpyAsync(iq_out, c->d_iq + (size_t)first * per_ch, (size_t)count * per_ch * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out_is_device)
+{
+    if (!c) return SSDR_EINVAL;
+    if (!c->have_input) return SSDR_ESTATE;
+    if (c->in_frames & 1u) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t n_lines = c->in_frames / 2;
+    const uint32_t total = c->wf_phase + n_lines;
+    const uint32_t n_out = total / c->n_avg;
+    const uint32_t n_groups = (total + c->n_avg - 1) / c->n_avg;
+    if (c->wf_out_lines < n_out) {
+        if (c->d_wf_out) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_wf_out)); c->d_wf_out = nullptr; c->wf_out_lines = 0; }
+        HIP_TRY(hipMalloc(&c->d_wf_out, (size_t)n_out * c->n_ch * SSDR_NFFT * 2));
+        c->wf_out_lines = n_out;
+    }
+    SsdrWfArgs a;
+    a.iq = c->d_iq;
+    a.ch_stride = (uint64_t)c->in_frames * SSDR_FRAME;
+    a.n_ch = c->n_ch;
+    a.n_lines = n_lines;
+    a.n_avg = c->n_avg;
+    a.phase = c->wf_phase;
+    a.n_groups = n_groups;
+    a.out = c->d_wf_out;
+    a.acc = c->d_wf_acc;
+    a.consts = c->d_consts;
+    a.win = c->d_win;
+    a.tw_stage = c->d_tw;
+    a.thr = c->d_thr;
+    const uint64_t items = (uint64_t)((c->n_ch + 1) / 2) * n_groups;
+    const uint64_t need = (items + SSDR_WF_BLOCK / 64 - 1) / (SSDR_WF_BLOCK / 64);
+    const uint32_t grid = (uint32_t)(need < c->wf_grid ? need : c->wf_grid);
+    int rc;
+    if ((rc = timed_begin(c)) != SSDR_OK) return rc;
+    HIP_TRY(ssdr_launch_wf(a, grid ? grid : 1, c->stream));
+    if ((rc = timed_end(c, SSDR_K_WF)) != SSDR_OK) return rc;
+    c->wf_phase = total % c->n_avg;
+    c->wf_lines_ready = n_out;
+    if (lines_ready) *lines_ready = n_out;
+    if (wf_sum_out && n_out) {
+        const size_t bytes = (size_t)n_out * c->n_ch * SSDR_NFFT * 2;
+        HIP_TRY(hipMemcpyAsync(wf_sum_out, c->d_wf_out, bytes, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+        if (!out_is_device) HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SSDR_OK;
+}
+
+int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_device)
+{
+    if (!c) return SSDR_EINVAL;
+    if (!c->have_input) return SSDR_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->audio_frames < c->in_frames) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_pcm) { HIP_TRY(hipFree(c->d_pcm)); c->d_pcm = nullptr; }
+        if (c->d_rssi) { HIP_TRY(hipFree(c->d_rssi)); c->d_rssi = nullptr; }
+        c->audio_frames = 0;
+        HIP_TRY(hipMalloc(&c->d_pcm, (size_t)c->n_ch * c->in_frames * SSDR_FRAME * 2));
+        HIP_TRY(hipMalloc(&c->d_rssi, (size_t)c->n_ch * c->in_frames * sizeof(float)));
+        c->audio_frames = c->in_frames;
+    }
+    SsdrAudioArgs a;
+    a.iq = c->d_iq;
+    a.ch_stride = (uint64_t)c->in_frames * SSDR_FRAME;
+    a.n_ch = c->n_ch;
+    a.n_frames = c->in_frames;
+    a.consts = c->d_consts;
+    a.taps = c->d_taps;
+    a.state = c->d_state;
+    a.hist = c->d_hist;
+    a.pcm = c->d_pcm;
+    a.rssi = c->d_rssi;
+    int rc;
+    if ((rc = timed_begin(c)) != SSDR_OK) return rc;
+    HIP_TRY(ssdr_launch_audio(a, c->stream));
+    if ((rc = timed_end(c, SSDR_K_AUDIO)) != SSDR_OK) return rc;
+    const hipMemcpyKind kind = out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (pcm_out) HIP_TRY(hipMemcpyAsync(pcm_out, c->d_pcm, (size_t)c->n_ch * c->in_frames * SSDR_FRAME * 2, kind, c->stream));
+    if (rssi_out) HIP_TRY(hipMemcpyAsync(rssi_out, c->d_rssi, (size_t)c->n_ch * c->in_frames * sizeof(float), kind, c->stream));
+    if ((pcm_out || rssi_out) && !out_is_device) HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_wf_device(ssdr_ctx *c, int16_t **ptr, uint32_t *lines)
+{
+    if (!c || !ptr) return SSDR_EINVAL;
+    *ptr = c->d_wf_out;
+    if (lines) *lines = c->wf_lines_ready;
+    return SSDR_OK;
+}
+
+int ssdr_audio_device(ssdr_ctx *c, int16_t **pcm, float **rssi)
+{
+    if (!c) return SSDR_EINVAL;
+    if (pcm) *pcm = c->d_pcm;
+    if (rssi) *rssi = c->d_rssi;
+    return SSDR_OK;
+}
+
+int ssdr_get_consts(ssdr_ctx *c, uint32_t first, uint32_t count, ssdr_chan_consts *consts, float *taps)
+{
+    if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    if (consts) HIP_TRY(hipMemcpyAsync(consts, c->d_consts + first, count * sizeof(ssdr_chan_consts), hipMemcpyDeviceToHost, c->stream));
+    if (taps) HIP_TRY(hipMemcpyAsync(taps, c->d_taps + (size_t)first * SSDR_NTAP_MAX, (size_t)count * SSDR_NTAP_MAX * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_get_state(ssdr_ctx *c, uint32_t first, uint32_t count, ssdr_chan_state *state, int16_t *hist)
+{
+    if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    if (state) HIP_TRY(hipMemcpyAsync(state, c->d_state + first, count * sizeof(ssdr_chan_state), hipMemcpyDeviceToHost, c->stream));
+    if (hist) HIP_TRY(hipMemcpyAsync(hist, c->d_hist + (size_t)first * SSDR_HIST, (size_t)count * SSDR_HIST * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_set_state(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan_state *state, const int16_t *hist)
+{
+    if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    if (state) HIP_TRY(hipMemcpyAsync(c->d_state + first, state, count * sizeof(ssdr_chan_state), hipMemcpyHostToDevice, c->stream));
+    if (hist) HIP_TRY(hipMemcpyAsync(c->d_hist + (size_t)first * SSDR_HIST, hist, (size_t)count * SSDR_HIST * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_selftest_quantiser(ssdr_ctx *c, uint64_t *mismatches)
+{
+    if (!c || !mismatches) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->d_scratch, 0, 8, c->stream));
+    HIP_TRY(ssdr_launch_quant_selftest(c->d_thr, c->d_scratch, c->stream));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, c->d_scratch, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *mismatches = v;
+    return SSDR_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,105 @@
+// ssdr_math.h -- deterministic fp32 device math for the SuperSDR hot path (gfx950).
+//
+// No libm transcendentals and no implicit contraction (-ffp-contract=off): every
+// rounding step is explicit, so results are reproducible op-for-op on any IEEE-754
+// machine.  v_fma_f32 / v_rndne_f32 / IEEE divide and sqrt are the only primitives.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "ssdr_consts.h"
+
+#define SSDR_DEV __device__ __forceinline__
+
+// sin/cos of 2*pi*(phase>>12)/2^20: 20-bit phase truncation (DDS practice), exact
+// integer quadrant reduction, minimax polynomials on [-pi/4, pi/4].
+SSDR_DEV void ssdr_sincos20(uint32_t phase, float &c_out, float &s_out)
+{
+    const float S1 = -1.6666654611e-1f, S2 = 8.3321608736e-3f, S3 = -1.9515295891e-4f;
+    const float C1 = 4.166664568298827e-2f, C2 = -1.388731625493765e-3f, C3 = 2.443315711809948e-5f;
+    uint32_t p20 = phase >> 12;
+    uint32_t k = (p20 + (1u << 17)) >> 18;
+    int32_t ri = (int32_t)p20 - (int32_t)(k << 18);
+    float th = (float)ri * SSDR_C_2PI_20;
+    float t2 = th * th;
+    float u = fmaf(t2, S3, S2);
+    u = fmaf(t2, u, S1);
+    float s = fmaf(th * t2, u, th);
+    float v = fmaf(t2, C3, C2);
+    v = fmaf(t2, v, C1);
+    float c = fmaf(t2 * t2, v, fmaf(-0.5f, t2, 1.0f));
+    // rotate by k quadrants: branch-free selects
+    float cc = (k & 1u) ? s : c;
+    float ss = (k & 1u) ? c : s;
+    c_out = ((k + 1u) & 2u) ? -cc : cc;       // k=1,2 -> negative cos side
+    s_out = (k & 2u) ? -ss : ss;              // k=2,3 -> negative sin side
+}
+
+// log2(x) for normal x > 0: exponent split + atanh series in s = (m-1)/(m+1).
+SSDR_DEV float ssdr_log2p(float x)
+{
+    const float L1 = 0.33333333333f, L2 = 0.2f, L3 = 0.14285714286f, L4 = 0.11111111111f;
+    uint32_t I = __float_as_uint(x);
+    int32_t e = (int32_t)(I >> 23) - 127;
+    float m = __uint_as_float((I & 0x007FFFFFu) | 0x3F800000u);
+    if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float z = s * s;
+    float t = fmaf(z, L4, L3);
+    t = fmaf(z, t, L2);
+    t = fmaf(z, t, L1);
+    t = z * t;
+    float sk = s * SSDR_K2_LN2;
+    return (float)e + fmaf(sk, t, sk);
+}
+
+// 2^y, |y| <= 126
+SSDR_DEV float ssdr_exp2p(float y)
+{
+    const float E1 = 0.69314718056f, E2 = 0.24022650696f, E3 = 0.055504108665f,
+                E4 = 0.0096181291076f, E5 = 0.0013333558146f, E6 = 0.00015403530393f,
+                E7 = 0.000015252733805f;
+    y = fminf(fmaxf(y, -126.0f), 126.0f);
+    float n = rintf(y);
+    float f = y - n;
+    float r = fmaf(E7, f, E6);
+    r = fmaf(r, f, E5);
+    r = fmaf(r, f, E4);
+    r = fmaf(r, f, E3);
+    r = fmaf(r, f, E2);
+    r = fmaf(r, f, E1);
+    r = fmaf(r, f, 1.0f);
+    return __uint_as_float(__float_as_uint(r) + ((uint32_t)(int32_t)n << 23));
+}
+
+// atan2(y, x): cephes atanf reduction, IEEE divides
+SSDR_DEV float ssdr_atan2p(float y, float x)
+{
+    const float A0 = -3.33329491539e-1f, A1 = 1.99777106478e-1f,
+                A2 = -1.38776856032e-1f, A3 = 8.05374449538e-2f;
+    const float PI_4 = 0.78539816339744831f, PI_2 = 1.5707963267948966f, PI_1 = 3.14159265358979323f;
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float t = mn / mx;
+    float u = t, off = 0.0f;
+    if (t > 0.41421356237f) { u = (t - 1.0f) / (t + 1.0f); off = PI_4; }
+    float z = u * u;
+    float q = fmaf(A3, z, A2);
+    q = fmaf(q, z, A1);
+    q = fmaf(q, z, A0);
+    float r = off + fmaf(u * z, q, u);
+    if (ay > ax) r = PI_2 - r;
+    if (x < 0.0f) r = PI_1 - r;
+    if (y < 0.0f) r = -r;
+    return (mx == 0.0f) ? 0.0f : r;
+}
+
+// dB quantiser: byte = #{k in 1..255 : T[k] <= p}.  The float's own bit pattern is a
+// piecewise-linear log2: y = bits*QA + QB never exceeds the true position and is at
+// most 0.26+margin below it, so floor(y) is the answer or one less; one compare
+// against the threshold table (LDS) settles it.  No log, exact by construction.
+SSDR_DEV int ssdr_quantise(float p, const float *thr)
+{
+    float y = fmaf((float)(int32_t)__float_as_uint(p), SSDR_QA, SSDR_QB);
+    int k = (int)floorf(y);
+    k = min(max(k, 0), 254);
+    return k + ((p >= thr[k + 1]) ? 1 : 0);
+}

@@ -1,0 +1,126 @@
+// ssdr_tables.cpp -- host-side tables and per-channel parameter compilation.
+//
+// Every table is a float64 formula rounded once to float32.  The FIR design is the
+// reference's only filter design, filtering.__init__ (utils_supersdr.py:334-344):
+//   b = fl/fs; N = ceil(4/b) forced odd; h = sinc(2 fl/fs (n-(N-1)/2)) * blackman(N); h /= sum(h)
+#include "ssdr_kernels.h"
+#include <cmath>
+#include <cstring>
+#include <algorithm>
+
+static const double kPi = 3.14159265358979323846;
+
+void ssdr_make_window(float *win)
+{
+    for (int n = 0; n < SSDR_NFFT; n++) win[n] = (float)(0.5 - 0.5 * std::cos(2.0 * kPi * n / SSDR_NFFT));
+}
+
+void ssdr_make_twiddles(float *wr, float *wi)
+{
+    for (int m = 0; m < 512; m++) {
+        wr[m] = (float)std::cos(2.0 * kPi * m / SSDR_NFFT);
+        wi[m] = (float)(-std::sin(2.0 * kPi * m / SSDR_NFFT));
+    }
+    wr[0] = 1.0f; wi[0] = 0.0f;
+    wr[256] = 0.0f; wi[256] = -1.0f;
+}
+
+// stage t (FFT stage 6+t), sub-block jl, lane l -> W_1024[(l + 32 jl) << (4 - t)]
+void ssdr_make_tw_stage(float2 *tw)
+{
+    float wr[512], wi[512];
+    ssdr_make_twiddles(wr, wi);
+    for (int t = 0; t < 5; t++) {
+        const int half = 1 << t, off = 32 * (half - 1);
+        for (int jl = 0; jl < half; jl++)
+            for (int l = 0; l < 32; l++) {
+                const int m = (l + 32 * jl) << (4 - t);
+                tw[off + jl * 32 + l] = make_float2(wr[m], wi[m]);
+            }
+    }
+}
+
+void ssdr_make_thresholds(float *thr)
+{
+    for (int k = 0; k < 256; k++) thr[k] = (float)(std::pow(10.0, (k - 255) / 10.0) * 281474976710656.0 /* 2^48 */);
+}
+
+static double sinc_pi(double x)
+{
+    if (x == 0.0) return 1.0;
+    const double y = kPi * x;
+    return std::sin(y) / y;
+}
+
+// utils_supersdr.py:334-344, with the tap count capped at n_max (odd)
+static int design_lowpass(double fl, double fs, int n_max, double *h)
+{
+    const double b = fl / fs;
+    int N = (int)std::ceil(4.0 / b);
+    if (N % 2 == 0) N += 1;
+    if (N > n_max) N = (n_max % 2) ? n_max : n_max - 1;
+    double sum = 0.0;
+    for (int n = 0; n < N; n++) {
+        const double w = (N == 1) ? 1.0
+                                  : 0.42 - 0.5 * std::cos(2.0 * kPi * n / (N - 1)) + 0.08 * std::cos(4.0 * kPi * n / (N - 1));
+        h[n] = sinc_pi(2.0 * fl / fs * (n - (N - 1) / 2.0)) * w;
+        sum += h[n];
+    }
+    for (int n = 0; n < N; n++) h[n] /= sum;
+    return N;
+}
+
+static uint32_t dphi_of(double f_hz)
+{
+    const double x = std::nearbyint(f_hz / SSDR_RATE * 4294967296.0);
+    long long v = (long long)x % 4294967296ll;
+    if (v < 0) v += 4294967296ll;
+    return (uint32_t)v;
+}
+
+int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps)
+{
+    if (!p || !c || !taps) return SSDR_EINVAL;
+    if (p->mode < SSDR_MODE_AM || p->mode > SSDR_MODE_NBFM) return SSDR_EINVAL;
+    std::memset(c, 0, sizeof *c);
+    double f_bc, fl;
+    if (p->mode >= SSDR_MODE_LSB && p->mode <= SSDR_MODE_CW) {
+        f_bc = 0.5 * (p->low_cut + p->high_cut);
+        fl = 0.5 * std::fabs(p->high_cut - p->low_cut);
+    } else {
+        f_bc = 0.0;
+        fl = std::max(std::fabs(p->low_cut), std::fabs(p->high_cut));
+    }
+    fl = std::min(std::max(fl, 50.0), SSDR_RATE / 2.0);
+    double h[SSDR_NTAP_MAX];
+    const int ntap = design_lowpass(fl, (double)SSDR_RATE, SSDR_NTAP_MAX - 1, h);
+    for (int i = 0; i < SSDR_NTAP_MAX; i++) taps[i] = (i < ntap) ? (float)h[i] : 0.0f;
+    c->mode = (uint32_t)p->mode;
+    c->ntap = (uint32_t)ntap;
+    c->ntap8 = (uint32_t)((ntap + 7) & ~7);
+    c->dphi1 = dphi_of(p->f_shift_hz + f_bc);
+    c->dphi2 = dphi_of(f_bc);
+    c->wf_cal_lin = (float)std::pow(10.0, p->wf_cal_db / 10.0);
+    c->smeter_cal_db = (float)p->smeter_cal_db;
+    const double log2_10 = std::log2(10.0);
+    double c0, c1;
+    if (p->mode == SSDR_MODE_NBFM) {
+        c0 = 0.0; c1 = 0.0;
+    } else if (p->agc_on) {
+        const double gs = std::min(std::max(p->agc_slope, 0.0), 10.0) / 100.0;
+        c1 = (gs - 1.0) / 2.0;
+        c0 = -1.0 - 30.0 * c1;
+    } else {
+        c1 = 0.0;
+        c0 = (p->agc_man_gain - 50.0) * log2_10 / 20.0;
+    }
+    const double knee = (p->agc_thresh - p->smeter_cal_db) * (log2_10 / 10.0) + 30.0;
+    const double tau = std::max(p->agc_decay, 1.0) / 1000.0;
+    const double delta8 = 2.0 * std::log2(std::exp(1.0)) * 8.0 / (tau * SSDR_RATE);
+    c->agc_c0 = (float)c0;
+    c->agc_c1 = (float)c1;
+    c->agc_knee = (float)knee;
+    c->agc_delta8 = (float)delta8;
+    c->hang_frames = p->agc_hang ? (uint32_t)std::min(std::max(std::nearbyint(p->agc_decay / 500.0), 1.0), 8.0) : 0u;
+    return SSDR_OK;
+}

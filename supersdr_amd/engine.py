@@ -1,0 +1,175 @@
+"""SsdrEngine -- thin NumPy-facing wrapper over the libssdr C-ABI (one ctx == one GPU).
+
+Host code stays Python, as in the reference; every number is produced by the HIP
+kernels behind include/ssdr.h.  NumPy is used for host buffers only.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import ChanParams, ChanConsts, ChanState, check, lib
+
+CONSTS_DTYPE = np.dtype([("mode", "<u4"), ("ntap8", "<u4"), ("dphi1", "<u4"), ("dphi2", "<u4"),
+                         ("wf_cal_lin", "<f4"), ("smeter_cal_db", "<f4"), ("agc_c0", "<f4"), ("agc_c1", "<f4"),
+                         ("agc_knee", "<f4"), ("agc_delta8", "<f4"), ("hang_frames", "<u4"), ("ntap", "<u4"),
+                         ("pad", "<u4", (4,))])
+STATE_DTYPE = np.dtype([("phi1", "<u4"), ("phi2", "<u4"), ("dc", "<f4"), ("agc_d", "<f4"), ("agc_m", "<f4", (8,)),
+                        ("prev_re", "<f4"), ("prev_im", "<f4"), ("pad", "<u4", (2,))])
+assert CONSTS_DTYPE.itemsize == 64 and STATE_DTYPE.itemsize == 64
+
+
+def default_params(mode="am", **over):
+    """Reference defaults for a receiver in `mode` (utils_supersdr.py:42-50, 936-944)."""
+    p = ChanParams()
+    m = L.MODE_BY_NAME[mode.lower()] if isinstance(mode, str) else int(mode)
+    check(lib.ssdr_default_params(m, C.byref(p)), "ssdr_default_params")
+    for k, v in over.items():
+        if not hasattr(p, k):
+            raise AttributeError("ssdr_chan_params has no field %r" % k)
+        setattr(p, k, v)
+    return p
+
+
+def compile_params(p):
+    """ChanParams -> (consts record, float32[128] taps), computed by the library's host code."""
+    k = ChanConsts()
+    taps = np.zeros(L.NTAP_MAX, np.float32)
+    check(lib.ssdr_compile_params(C.byref(p), C.byref(k), taps.ctypes.data), "ssdr_compile_params")
+    rec = np.frombuffer(bytes(k), dtype=CONSTS_DTYPE)[0]
+    return rec, taps
+
+
+def table(which):
+    n = {L.T_WINDOW: 1024, L.T_TWIDDLE_RE: 512, L.T_TWIDDLE_IM: 512, L.T_DB_THRESH: 256}[which]
+    out = np.empty(n, np.float32)
+    check(lib.ssdr_table(which, out.ctypes.data, n), "ssdr_table")
+    return out
+
+
+class SsdrEngine:
+    def __init__(self, n_channels, device=0):
+        self.n_ch = int(n_channels)
+        self._ctx = L._P()
+        check(lib.ssdr_create(int(device), self.n_ch, L.NFFT, L.FRAME, C.byref(self._ctx)), "ssdr_create")
+        self.in_frames = 0
+
+    def close(self):
+        if self._ctx:
+            lib.ssdr_destroy(self._ctx)
+            self._ctx = L._P()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- control plane
+    def set_params(self, first, params):
+        params = list(params)
+        arr = (ChanParams * len(params))(*params)
+        check(lib.ssdr_set_params(self._ctx, int(first), len(params), arr), "ssdr_set_params")
+
+    def reset_state(self, first=0, count=None):
+        check(lib.ssdr_reset_state(self._ctx, int(first), self.n_ch - first if count is None else int(count)),
+              "ssdr_reset_state")
+
+    def set_averaging(self, n):
+        check(lib.ssdr_set_averaging(self._ctx, int(n)), "ssdr_set_averaging")
+
+    # ---- data plane
+    def push_iq(self, iq):
+        """iq: int16 [n_ch, n_frames*512, 2] host array (copied to the GPU)."""
+        iq = np.ascontiguousarray(iq, dtype=np.int16)
+        if iq.ndim != 3 or iq.shape[0] != self.n_ch or iq.shape[2] != 2 or iq.shape[1] % L.FRAME:
+            raise ValueError("iq must be int16[n_ch=%d, k*512, 2], got %r" % (self.n_ch, iq.shape))
+        self.in_frames = iq.shape[1] // L.FRAME
+        check(lib.ssdr_push_iq(self._ctx, iq.ctypes.data, self.in_frames, 0), "ssdr_push_iq")
+        self.sync()             # the host buffer may be released by the caller after this returns
+
+    def push_iq_device(self, dev_ptr, n_frames):
+        self.in_frames = int(n_frames)
+        check(lib.ssdr_push_iq(self._ctx, int(dev_ptr), self.in_frames, 1), "ssdr_push_iq")
+
+    def synth_iq(self, n_frames, seed=0x5D5D, first_channel_id=0):
+        self.in_frames = int(n_frames)
+        check(lib.ssdr_synth_iq(self._ctx, self.in_frames, int(seed), int(first_channel_id)), "ssdr_synth_iq")
+
+    def read_input(self, first=0, count=None):
+        count = self.n_ch - first if count is None else int(count)
+        out = np.empty((count, self.in_frames * L.FRAME, 2), np.int16)
+        check(lib.ssdr_read_input(self._ctx, int(first), count, out.ctypes.data), "ssdr_read_input")
+        return out
+
+    def run_wf(self, fetch=True):
+        """-> int16 [lines_ready, n_ch, 1024] sums of `averaging` byte lines (or the line count if not fetch)."""
+        n = C.c_uint32(0)
+        if not fetch:
+            check(lib.ssdr_run_wf(self._ctx, None, C.byref(n), 0), "ssdr_run_wf")
+            return n.value
+        total_lines = self.in_frames // 2 + 1          # upper bound incl. a carried partial group
+        out = np.empty((total_lines, self.n_ch, L.NFFT), np.int16)
+        check(lib.ssdr_run_wf(self._ctx, out.ctypes.data, C.byref(n), 0), "ssdr_run_wf")
+        return out[: n.value]
+
+    def run_audio(self, fetch=True):
+        """-> (int16 [n_ch, n_frames*512] pcm, float32 [n_ch, n_frames] rssi dBm)."""
+        if not fetch:
+            check(lib.ssdr_run_audio(self._ctx, None, None, 0), "ssdr_run_audio")
+            return None
+        pcm = np.empty((self.n_ch, self.in_frames * L.FRAME), np.int16)
+        rssi = np.empty((self.n_ch, self.in_frames), np.float32)
+        check(lib.ssdr_run_audio(self._ctx, pcm.ctypes.data, rssi.ctypes.data, 0), "ssdr_run_audio")
+        return pcm, rssi
+
+    def sync(self):
+        check(lib.ssdr_sync(self._ctx), "ssdr_sync")
+
+    # ---- measurement
+    def set_profiling(self, on):
+        check(lib.ssdr_set_profiling(self._ctx, int(bool(on))), "ssdr_set_profiling")
+
+    def kernel_stats(self, which, reset=False):
+        ms, n = C.c_float(0), C.c_uint32(0)
+        check(lib.ssdr_kernel_stats(self._ctx, int(which), C.byref(ms), C.byref(n), int(reset)), "ssdr_kernel_stats")
+        return ms.value, n.value
+
+    def elapsed_ms(self):
+        ms = C.c_float(0)
+        check(lib.ssdr_elapsed_ms(self._ctx, C.byref(ms)), "ssdr_elapsed_ms")
+        return ms.value
+
+    def set_stream(self, hip_stream):
+        check(lib.ssdr_set_stream(self._ctx, hip_stream), "ssdr_set_stream")
+
+    # ---- introspection (tests, checkpointing)
+    def get_consts(self, first=0, count=None):
+        count = self.n_ch - first if count is None else int(count)
+        k = np.empty(count, CONSTS_DTYPE)
+        taps = np.empty((count, L.NTAP_MAX), np.float32)
+        check(lib.ssdr_get_consts(self._ctx, int(first), count, k.ctypes.data, taps.ctypes.data), "ssdr_get_consts")
+        return k, taps
+
+    def get_state(self, first=0, count=None):
+        count = self.n_ch - first if count is None else int(count)
+        st = np.empty(count, STATE_DTYPE)
+        hist = np.empty((count, L.HIST, 2), np.int16)
+        check(lib.ssdr_get_state(self._ctx, int(first), count, st.ctypes.data, hist.ctypes.data), "ssdr_get_state")
+        return st, hist
+
+    def set_state(self, first, state, hist):
+        state = np.ascontiguousarray(state, STATE_DTYPE)
+        hist = np.ascontiguousarray(hist, np.int16)
+        check(lib.ssdr_set_state(self._ctx, int(first), len(state), state.ctypes.data, hist.ctypes.data), "ssdr_set_state")
+
+    def selftest_quantiser(self):
+        n = C.c_uint64(0)
+        check(lib.ssdr_selftest_quantiser(self._ctx, C.byref(n)), "ssdr_selftest_quantiser")
+        return n.value

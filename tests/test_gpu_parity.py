@@ -1,0 +1,253 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the oracle.
+
+  * bit-exact vs the fp32 twin (oracle/ssdr_twin.c) on every int16 bin and PCM sample
+  * vs the normative NumPy float64 oracle: waterfall bins identical outside the
+    threshold guard band (|p/T - 1| < 2e-5) and <= 1 step inside it; PCM within
+    1e-5 RMS of full scale (north_star tolerance)
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ssdr_oracle as O  # noqa: E402
+import twinlib  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+PCM_RMS_TOL = 1e-5          # of full scale, north_star
+MODES = ["am", "usb", "lsb", "nbfm"]
+
+
+@pytest.fixture(scope="module")
+def S():
+    import supersdr_amd
+    return supersdr_amd
+
+
+def oracle_wf(iq, n_avg, cal_db=0.0):
+    n_ch = iq.shape[0]
+    out = np.stack([O.wf_sum_lines(iq[c].reshape(-1, 1024, 2), n_avg, cal_db) for c in range(n_ch)], axis=1)
+    return out
+
+
+def oracle_guard(iq, n_avg):
+    n_ch = iq.shape[0]
+    g = np.stack([O.wf_guard_band(iq[c].reshape(-1, 1024, 2)) for c in range(n_ch)], axis=1)   # [lines, ch, 1024]
+    L = g.shape[0] // n_avg
+    return g[: L * n_avg].reshape(L, n_avg, n_ch, 1024).sum(axis=1)                              # count per summed bin
+
+
+def mixed_params(S, n_ch, **over):
+    ps, ops = [], []
+    for c in range(n_ch):
+        m = MODES[c % 4]
+        fc = ((c * 37) % 97 - 48) * 100.0
+        p = S.default_params(m, f_shift_hz=fc, **over)
+        ps.append(p)
+        ops.append(O.ChanParams(mode=m, f_shift_hz=fc, low_cut=p.low_cut, high_cut=p.high_cut, agc_on=p.agc_on,
+                                hang=p.agc_hang, thresh=p.agc_thresh, slope=p.agc_slope, decay=p.agc_decay,
+                                man_gain=p.agc_man_gain, wf_cal_db=p.wf_cal_db, smeter_cal_db=p.smeter_cal_db))
+    return ps, ops
+
+
+def test_quantiser_exhaustive(S):
+    """every positive finite float32 power: bit-pattern estimate + one compare == binary search"""
+    with S.SsdrEngine(1) as eng:
+        assert eng.selftest_quantiser() == 0
+
+
+def test_tables_match_oracle(S, twin):
+    assert np.array_equal(S.table(0), O.hann_window())
+    wr, wi = O.twiddles()
+    assert np.array_equal(S.table(1), wr) and np.array_equal(S.table(2), wi)
+    assert np.array_equal(S.table(3), O.db_thresholds())
+    assert np.array_equal(S.table(0), twin.win) and np.array_equal(S.table(3), twin.thr)
+
+
+@pytest.mark.parametrize("n_ch,n_lines,n_avg", [(1, 1, 1), (2, 3, 1), (7, 4, 2), (64, 6, 3), (33, 10, 10)])
+def test_wf_bit_exact_vs_twin_and_oracle(S, twin, n_ch, n_lines, n_avg):
+    iq = O.synth_iq(n_ch, n_lines * 1024, seed=11 + n_ch)
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_averaging(n_avg)
+        eng.push_iq(iq)
+        wf = eng.run_wf()
+    ref_t = twin.wf(iq, n_avg)
+    assert wf.shape == ref_t.shape == (n_lines // n_avg, n_ch, 1024)
+    assert np.array_equal(wf, ref_t)
+    ref_o = oracle_wf(iq, n_avg)
+    guard = oracle_guard(iq, n_avg)
+    diff = np.abs(wf.astype(np.int32) - ref_o)
+    assert not (diff > guard).any()            # identical outside the guard band, <= 1 step per guarded line inside
+
+
+def test_wf_known_answer_full_scale_tone(S):
+    """full-scale complex tone at FFT bin 100 -> byte 255 at shifted bin 612; bins away from it far below"""
+    n = np.arange(1024)
+    z = 32767.0 * np.exp(2j * np.pi * 100 * n / 1024)
+    iq = np.stack([np.rint(z.real), np.rint(z.imag)], axis=-1).astype(np.int16)[None]
+    with S.SsdrEngine(1) as eng:
+        eng.push_iq(iq)
+        wf = eng.run_wf()[0, 0]
+    assert wf[612] in (254, 255) and int(np.argmax(wf)) == 612
+    assert wf[611] == wf[613] and 248 <= wf[611] <= 249          # Hann side bins: -6.02 dB
+    assert wf[100] < 180
+
+
+def test_wf_carry_across_calls(S, twin):
+    """averaging groups that straddle pushes: 3 pushes of 2,3,5 lines with N=4 == one push of 10 lines"""
+    n_ch = 5
+    iq = O.synth_iq(n_ch, 10 * 1024, seed=5)
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_averaging(4)
+        outs = []
+        for a, b in ((0, 2), (2, 5), (5, 10)):
+            eng.push_iq(iq[:, a * 1024: b * 1024])
+            outs.append(eng.run_wf())
+    got = np.concatenate(outs, axis=0)
+    assert [o.shape[0] for o in outs] == [0, 1, 1]
+    assert np.array_equal(got, twin.wf(iq, 4))
+
+
+def test_wf_calibration_and_edges(S, twin):
+    """wf_cal_db shifts bytes; zero input -> byte 0; int16 extremes do not overflow"""
+    n_ch = 4
+    iq = O.synth_iq(n_ch, 1024, seed=3)
+    iq[1] = 0
+    iq[2, :, 0] = 32767
+    iq[2, :, 1] = -32768
+    ps = [S.default_params("am", wf_cal_db=db) for db in (0.0, 0.0, 0.0, 7.0)]
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.push_iq(iq)
+        wf = eng.run_wf()
+        consts, _ = eng.get_consts()
+    assert np.array_equal(wf, twin.wf(iq, 1, consts["wf_cal_lin"]))
+    assert (wf[0, 1] == 0).all()
+    assert wf[0, 2].max() == 255                               # DC bin of a constant full-scale input, clamped
+    o3 = O.wf_sum_lines(iq[3].reshape(-1, 1024, 2), 1, 7.0)
+    g3 = O.wf_guard_band(iq[3].reshape(-1, 1024, 2), 7.0)
+    assert not ((wf[:, 3] != o3) & ~g3).any()
+
+
+@pytest.mark.parametrize("n_ch,n_frames", [(1, 1), (4, 2), (16, 5), (67, 3)])
+def test_audio_bit_exact_vs_twin_and_oracle(S, twin, n_ch, n_frames):
+    iq = O.synth_iq(n_ch, n_frames * 512, seed=21 + n_ch)
+    ps, ops = mixed_params(S, n_ch)
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.push_iq(iq)
+        pcm, rssi = eng.run_audio()
+        consts, taps = eng.get_consts()
+        st_g, hist_g = eng.get_state()
+    st, hist = twinlib.fresh_state(consts)
+    pcm_t, rssi_t = twin.audio(iq, consts, taps, st, hist)
+    assert np.array_equal(pcm, pcm_t)
+    assert np.array_equal(rssi, rssi_t)
+    assert st_g.tobytes() == st.tobytes() and np.array_equal(hist_g, hist)
+    pcm_o, rssi_o = O.audio_chain(iq, ops)
+    rms = np.sqrt(((pcm.astype(np.float64) - pcm_o) ** 2).mean(axis=1)) / 32768.0
+    assert rms.max() < PCM_RMS_TOL
+    assert np.abs(rssi - rssi_o).max() < 1e-3
+
+
+def test_audio_state_carry_across_calls(S, twin):
+    """frame-by-frame pushes == one multi-frame push (FIR history, NCO phase, DC, AGC all carried)"""
+    n_ch, n_frames = 8, 6
+    iq = O.synth_iq(n_ch, n_frames * 512, seed=77)
+    ps, _ = mixed_params(S, n_ch)
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.push_iq(iq)
+        pcm_all, rssi_all = eng.run_audio()
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        parts, rparts = [], []
+        for a, b in ((0, 1), (1, 3), (3, 6)):
+            eng.push_iq(iq[:, a * 512: b * 512])
+            p, r = eng.run_audio()
+            parts.append(p)
+            rparts.append(r)
+    assert np.array_equal(np.concatenate(parts, axis=1), pcm_all)
+    assert np.array_equal(np.concatenate(rparts, axis=1), rssi_all)
+
+
+@pytest.mark.parametrize("over", [dict(agc_hang=1), dict(agc_on=0, agc_man_gain=56.0), dict(agc_slope=6.0),
+                                  dict(agc_thresh=-30.0), dict(agc_decay=400.0)])
+def test_audio_agc_variants(S, twin, over):
+    n_ch, n_frames = 8, 12
+    iq = O.synth_iq(n_ch, n_frames * 512, seed=5)
+    iq[:, 3 * 512: 6 * 512] //= 16            # level step down and back up: exercises decay / hang / knee
+    ps, ops = mixed_params(S, n_ch, **over)
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.push_iq(iq)
+        pcm, rssi = eng.run_audio()
+        consts, taps = eng.get_consts()
+    st, hist = twinlib.fresh_state(consts)
+    pcm_t, rssi_t = twin.audio(iq, consts, taps, st, hist)
+    assert np.array_equal(pcm, pcm_t) and np.array_equal(rssi, rssi_t)
+    pcm_o, _ = O.audio_chain(iq, ops)
+    rms = np.sqrt(((pcm.astype(np.float64) - pcm_o) ** 2).mean(axis=1)) / 32768.0
+    assert rms.max() < PCM_RMS_TOL
+
+
+def test_audio_cw_long_filter_and_passband_change(S, twin):
+    """CW: 127-tap filter (max history); then a passband change mid-stream keeps state"""
+    n_ch, n_frames = 3, 4
+    iq = O.synth_iq(n_ch, n_frames * 512, seed=9, modes=[1, 1, 1])
+    ps = [S.default_params("cw", f_shift_hz=((c * 37) % 97 - 48) * 100.0 + 400.0) for c in range(n_ch)]
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.push_iq(iq[:, : 2 * 512])
+        p1, _ = eng.run_audio()
+        c1, t1 = eng.get_consts()
+        ps2 = [S.default_params("usb", f_shift_hz=p.f_shift_hz) for p in ps]
+        eng.set_params(0, ps2)
+        eng.push_iq(iq[:, 2 * 512:])
+        p2, _ = eng.run_audio()
+        c2, t2 = eng.get_consts()
+    assert (c1["ntap"] == 127).all()
+    st, hist = twinlib.fresh_state(c1)
+    q1, _ = twin.audio(iq[:, : 2 * 512], c1, t1, st, hist)
+    q2, _ = twin.audio(iq[:, 2 * 512:], c2, t2, st, hist)
+    assert np.array_equal(p1, q1) and np.array_equal(p2, q2)
+
+
+def test_synth_input_roundtrip_and_parity(S, twin):
+    """device-generated bench input: read it back, run both stages, compare with the twin on the same bytes"""
+    n_ch, n_frames = 32, 4
+    with S.SsdrEngine(n_ch) as eng:
+        ps, _ = mixed_params(S, n_ch)
+        eng.set_params(0, ps)
+        eng.set_averaging(2)
+        eng.synth_iq(n_frames, seed=1234)
+        iq = eng.read_input()
+        wf = eng.run_wf()
+        pcm, rssi = eng.run_audio()
+        consts, taps = eng.get_consts()
+    assert iq.std() > 1000 and np.abs(iq).max() < 12000
+    assert np.array_equal(wf, twin.wf(iq, 2, consts["wf_cal_lin"]))
+    st, hist = twinlib.fresh_state(consts)
+    pcm_t, rssi_t = twin.audio(iq, consts, taps, st, hist)
+    assert np.array_equal(pcm, pcm_t) and np.array_equal(rssi, rssi_t)
+
+
+def test_error_codes(S):
+    from supersdr_amd import _lib as L
+    import ctypes as C
+    ctx = L._P()
+    assert L.lib.ssdr_create(0, 0, 1024, 512, C.byref(ctx)) == L.EINVAL
+    assert L.lib.ssdr_create(0, 4, 512, 512, C.byref(ctx)) == L.EINVAL
+    assert L.lib.ssdr_create(99, 4, 1024, 512, C.byref(ctx)) == L.ENODEV
+    with S.SsdrEngine(2) as eng:
+        with pytest.raises(S.SsdrError):
+            eng.run_wf()                       # nothing pushed: SSDR_ESTATE
+        with pytest.raises(S.SsdrError):
+            eng.set_averaging(0)
+        eng.push_iq(np.zeros((2, 512, 2), np.int16))
+        with pytest.raises(S.SsdrError):
+            eng.run_wf()                       # odd frame count: no whole 1024-sample line
