@@ -209,6 +209,18 @@ void twin_wf_line(const int16_t *iq, const float *win, const float *wr, const fl
     }
 }
 
+/* diagnostic: the fp32 scaled powers of one line in FFT order (guard-band calibration in tests) */
+void twin_wf_power(const int16_t *iq, const float *win, const float *wr, const float *wi, float cal_lin, float *p_out)
+{
+    float re[NFFT], im[NFFT];
+    for (int n = 0; n < NFFT; n++) {
+        re[n] = (float)iq[2 * n] * win[n];
+        im[n] = (float)iq[2 * n + 1] * win[n];
+    }
+    fft1024(re, im, wr, wi);
+    for (int k = 0; k < NFFT; k++) p_out[k] = fmaf(re[k], re[k], im[k] * im[k]) * cal_lin;
+}
+
 /* batch: iq[n_ch][n_lines*1024][2] -> out[n_lines/n_avg][n_ch][1024] int16 sums */
 void twin_wf(const int16_t *iq, uint32_t n_ch, uint32_t n_lines, uint32_t n_avg,
              const float *cal_lin /*[n_ch]*/, const float *win, const float *wr, const float *wi,

@@ -32,7 +32,8 @@ struct ssdr_ctx {
     float *d_taps = nullptr;
     ssdr_chan_state *d_state = nullptr;
     uint32_t *d_hist = nullptr;
-    int16_t *d_wf_acc = nullptr;
+    int16_t *d_wf_acc[2] = {nullptr, nullptr};          // ping-pong: carry-in / carry-out of partial groups
+    int wf_acc_cur = 0;
     // input batch
     uint32_t *d_iq_own = nullptr;
     size_t iq_own_frames = 0;
@@ -128,7 +129,7 @@ void ssdr_destroy(ssdr_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_wf_acc,
+    void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -207,7 +208,8 @@ int ssdr_reset_state(ssdr_ctx *c, uint32_t first, uint32_t count)
     }
     HIP_TRY(hipMemcpyAsync(c->d_state + first, st.data(), count * sizeof(ssdr_chan_state), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_hist + (size_t)first * SSDR_HIST, 0, (size_t)count * SSDR_HIST * 4, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_wf_acc + (size_t)first * SSDR_NFFT, 0, (size_t)count * SSDR_NFFT * 2, c->stream));
+    for (int i = 0; i < 2; i++)
+        HIP_TRY(hipMemsetAsync(c->d_wf_acc[i] + (size_t)first * SSDR_NFFT, 0, (size_t)count * SSDR_NFFT * 2, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (first == 0 && count == c->n_ch) { c->wf_phase = 0; c->synth_sample0 = 0; }
     return SSDR_OK;
@@ -258,7 +260,8 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         HIP_TRY(hipMalloc(&c->d_taps, (size_t)n_channels * SSDR_NTAP_MAX * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_state, (size_t)n_channels * sizeof(ssdr_chan_state)));
         HIP_TRY(hipMalloc(&c->d_hist, (size_t)n_channels * SSDR_HIST * 4));
-        HIP_TRY(hipMalloc(&c->d_wf_acc, (size_t)n_channels * SSDR_NFFT * 2));
+        HIP_TRY(hipMalloc(&c->d_wf_acc[0], (size_t)n_channels * SSDR_NFFT * 2));
+        HIP_TRY(hipMalloc(&c->d_wf_acc[1], (size_t)n_channels * SSDR_NFFT * 2));
         HIP_TRY(hipMalloc(&c->d_scratch, 64));
         std::vector<float> win(SSDR_NFFT), thr(256);
         std::vector<float2> tw(SSDR_TW_STAGE_N);
@@ -292,7 +295,7 @@ int ssdr_set_averaging(ssdr_ctx *c, uint32_t n)
     if (n != c->n_avg) {
         // like the reference (a new deque per output line, utils:882), a change restarts the group
         HIP_TRY(hipSetDevice(c->device));
-        HIP_TRY(hipMemsetAsync(c->d_wf_acc, 0, (size_t)c->n_ch * SSDR_NFFT * 2, c->stream));
+        // (partial sums are only read when wf_phase != 0, so no clearing is needed)
         c->wf_phase = 0;
         c->n_avg = n;
     }
@@ -434,7 +437,8 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
     a.phase = c->wf_phase;
     a.n_groups = n_groups;
     a.out = c->d_wf_out;
-    a.acc = c->d_wf_acc;
+    a.acc_in = c->d_wf_acc[c->wf_acc_cur];
+    a.acc_out = c->d_wf_acc[c->wf_acc_cur ^ 1];
     a.consts = c->d_consts;
     a.win = c->d_win;
     a.tw_stage = c->d_tw;
@@ -447,6 +451,7 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
     HIP_TRY(ssdr_launch_wf(a, grid ? grid : 1, c->stream));
     if ((rc = timed_end(c, SSDR_K_WF)) != SSDR_OK) return rc;
     c->wf_phase = total % c->n_avg;
+    if (c->wf_phase) c->wf_acc_cur ^= 1;             // a partial group was written to acc_out
     c->wf_lines_ready = n_out;
     if (lines_ready) *lines_ready = n_out;
     if (wf_sum_out && n_out) {

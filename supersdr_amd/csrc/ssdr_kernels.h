@@ -15,7 +15,9 @@ struct SsdrWfArgs {
     uint32_t n_avg, phase;                   // averaging N; lines already summed in `acc`
     uint32_t n_groups;                       // averaging groups touched by this batch
     int16_t *out;                            // [n_complete_groups][n_ch][1024]
-    int16_t *acc;                            // [n_ch][1024] partial sums carried between calls
+    const int16_t *acc_in;                   // [n_ch][1024] partial sums carried in from the previous call
+    int16_t *acc_out;                        // [n_ch][1024] partial sums carried out (a different buffer: other
+                                             // workgroups may still be reading acc_in)
     const ssdr_chan_consts *consts;          // [n_ch] (wf_cal_lin)
     const float *win;                        // [1024]
     const float2 *tw_stage;                  // [992]

@@ -198,8 +198,8 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK) void ssdr_wf_kernel(SsdrWfArgs a)
         for (int j = 0; j < 32; j++) x16[(32 * ((j + 16) & 31) + l)] = (int16_t)acc[j];
         wave_lds_sync();
         int16_t *dst = complete ? a.out + ((uint64_t)grp * a.n_ch + ch) * SSDR_NFFT
-                                : a.acc + (uint64_t)ch * SSDR_NFFT;
-        const int16_t *cin = a.acc + (uint64_t)ch * SSDR_NFFT;
+                                : a.acc_out + (uint64_t)ch * SSDR_NFFT;
+        const int16_t *cin = a.acc_in + (uint64_t)ch * SSDR_NFFT;
         const uint4 *x128 = reinterpret_cast<const uint4 *>(xch);
 #pragma unroll
         for (int q = 0; q < 4; q++) {

@@ -2,8 +2,9 @@
 
   * bit-exact vs the fp32 twin (oracle/ssdr_twin.c) on every int16 bin and PCM sample
   * vs the normative NumPy float64 oracle: waterfall bins identical outside the
-    threshold guard band (|p/T - 1| < 2e-5) and <= 1 step inside it; PCM within
-    1e-5 RMS of full scale (north_star tolerance)
+    threshold guard band (bins whose |X| is within the fp32 FFT error bound of a 1-dB
+    threshold, ssdr_oracle.wf_allowed_diff) and bounded inside it; PCM within 1e-5 RMS
+    of full scale (north_star tolerance)
 """
 import os
 import sys
@@ -36,9 +37,9 @@ def oracle_wf(iq, n_avg, cal_db=0.0):
 
 def oracle_guard(iq, n_avg):
     n_ch = iq.shape[0]
-    g = np.stack([O.wf_guard_band(iq[c].reshape(-1, 1024, 2)) for c in range(n_ch)], axis=1)   # [lines, ch, 1024]
+    g = np.stack([O.wf_allowed_diff(iq[c].reshape(-1, 1024, 2)) for c in range(n_ch)], axis=1)  # [lines, ch, 1024]
     L = g.shape[0] // n_avg
-    return g[: L * n_avg].reshape(L, n_avg, n_ch, 1024).sum(axis=1)                              # count per summed bin
+    return g[: L * n_avg].reshape(L, n_avg, n_ch, 1024).sum(axis=1)                              # steps allowed per summed bin
 
 
 def mixed_params(S, n_ch, **over):
@@ -81,7 +82,8 @@ def test_wf_bit_exact_vs_twin_and_oracle(S, twin, n_ch, n_lines, n_avg):
     ref_o = oracle_wf(iq, n_avg)
     guard = oracle_guard(iq, n_avg)
     diff = np.abs(wf.astype(np.int32) - ref_o)
-    assert not (diff > guard).any()            # identical outside the guard band, <= 1 step per guarded line inside
+    assert not (diff > guard).any()            # identical outside the guard band, bounded inside it
+    assert (diff > 0).mean() < 1e-3            # and actual flips are a sliver (expected ~3e-4 of bins)
 
 
 def test_wf_known_answer_full_scale_tone(S):
@@ -229,7 +231,7 @@ def test_synth_input_roundtrip_and_parity(S, twin):
         wf = eng.run_wf()
         pcm, rssi = eng.run_audio()
         consts, taps = eng.get_consts()
-    assert iq.std() > 1000 and np.abs(iq).max() < 12000
+    assert iq.std() > 1000 and np.abs(iq).max() < 14000
     assert np.array_equal(wf, twin.wf(iq, 2, consts["wf_cal_lin"]))
     st, hist = twinlib.fresh_state(consts)
     pcm_t, rssi_t = twin.audio(iq, consts, taps, st, hist)
