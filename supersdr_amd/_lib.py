@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssdr.so")
+LIB_PATH = os.environ.get("SSDR_LIB_PATH") or os.path.join(_HERE, "libssdr.so")   # override: A/B builds only
 
 NFFT, FRAME, RATE, NTAP_MAX, HIST = 1024, 512, 12000, 128, 128
 OK, EINVAL, ENOMEM, EHIP, ENODEV, ESTATE = 0, -1, -2, -3, -4, -5

@@ -273,7 +273,11 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         HIP_TRY(hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device_id));
-        c->wf_grid = (uint32_t)prop.multiProcessorCount * 3u;     // 3 x 256-thread workgroups per CU (LDS-bound)
+        int per_cu = 0;
+        HIP_TRY(ssdr_wf_blocks_per_cu(&per_cu));
+        if (per_cu < 1) per_cu = 1;
+        // persistent grid == exactly the resident workgroups (a larger grid would run a ragged second round)
+        c->wf_grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
         return SSDR_OK;
     }();
     if (rc == SSDR_OK) {

@@ -4,7 +4,18 @@
 #include <stdint.h>
 #include "../../include/ssdr.h"
 
+#ifndef SSDR_WF_BLOCK
 #define SSDR_WF_BLOCK 256                    // threads per workgroup of the waterfall kernel
+#endif
+#ifndef SSDR_WF_ABLATE
+#define SSDR_WF_ABLATE 0                     // profiling ablations only (1 memory-only, 2 no loads, 3 no stores)
+#endif
+#ifndef SSDR_WF_PREFETCH
+#define SSDR_WF_PREFETCH 0                   // 1: register software pipeline (costs 32 VGPRs)
+#endif
+#ifndef SSDR_WF_WAVES_PER_EU
+#define SSDR_WF_WAVES_PER_EU 3                // register budget: 3 waves/SIMD -> <= 168 VGPRs
+#endif
 #define SSDR_TW_STAGE_N 992                  // per-stage twiddle table entries: 32*(1+2+4+8+16)
 #define SSDR_AUDIO_BLOCK 64                  // one wave == one receiver channel
 
@@ -45,6 +56,7 @@ struct SsdrSynthArgs {
 };
 
 hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream);
+hipError_t ssdr_wf_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_synth(const SsdrSynthArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_quant_selftest(const float *thr, unsigned long long *mismatch, hipStream_t stream);

@@ -27,67 +27,118 @@ namespace {
 constexpr int XPAD = 33;                       // row stride (floats) of the transpose buffer
 constexpr int XCH_FLOATS = 32 * XPAD;          // per FFT: 4224 B
 constexpr int WAVES = SSDR_WF_BLOCK / 64;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// The register budget only holds if the phases of a line stay phases: without these fences
+// the machine scheduler hoists later phases' LDS table reads across the whole FFT and spills.
+// (Scheduling fence only; emits no instruction.)
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 __device__ constexpr int brev5(int v)
 {
     return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
 }
 
-SSDR_DEV void bfly(float &ur, float &ui, float &vr, float &vi, float wr, float wi)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Complex data lives in 64-bit register pairs (re, im) so that every butterfly is packed
+// fp32 math: a complex add is ONE v_pk_add_f32, a complex multiply TWO packed ops.  A wave
+// can issue one VALU instruction per 4 cycles, and that -- not HBM -- is what bounds this
+// kernel (profiles/), so the instruction count is the figure of merit.
+//
+// t = w * v with exactly the scalar definition's roundings:
+//   m  = (wi*vi, wi*vr)                       v_pk_mul_f32, operand halves picked by op_sel
+//   t  = (fma(wr, vr, -m.x), fma(wr, vi, m.y)) v_pk_fma_f32, neg_lo on the addend
+// hipcc does not form the half-negated addend itself (it emits an extra negate + move),
+// hence the two asm statements in the stage functions below.
+SSDR_DEV void bfly_1(f32x2 &u, f32x2 &v)                          // w = 1
 {
-    float tr = fmaf(wr, vr, -(wi * vi));
-    float ti = fmaf(wr, vi, wi * vr);
-    float xr = ur, xi = ui;
-    ur = xr + tr; ui = xi + ti;
-    vr = xr - tr; vi = xi - ti;
+    const f32x2 t = v, x = u;
+    u = x + t; v = x - t;
 }
-SSDR_DEV void bfly_1(float &ur, float &ui, float &vr, float &vi)      // w = 1
+SSDR_DEV void bfly_mj(f32x2 &u, f32x2 &v)                         // w = -j: t = (vi, -vr)
 {
-    float tr = vr, ti = vi, xr = ur, xi = ui;
-    ur = xr + tr; ui = xi + ti;
-    vr = xr - tr; vi = xi - ti;
+    const f32x2 t = {v.y, -v.x}, x = u;
+    u = x + t; v = x - t;
 }
-SSDR_DEV void bfly_mj(float &ur, float &ui, float &vr, float &vi)     // w = -j
-{
-    float tr = vi, ti = -vr, xr = ur, xi = ui;
-    ur = xr + tr; ui = xi + ti;
-    vr = xr - tr; vi = xi - ti;
-}
+
+// Butterflies are issued in batches, phase by phase (all multiplies, all fmas, all adds):
+// a packed-fp32 result cannot be consumed by the very next instruction without a wait
+// state, and independent work between producer and consumer is free.
 
 // stages 1..5 on a[0..31] (a-index order), twiddle W_1024[k * (1024 >> s)] = W32[k * (32 >> s)]
 template <int S>
-SSDR_DEV void stage_const(float (&re)[32], float (&im)[32])
+SSDR_DEV void stage_const(f32x2 (&z)[32])
 {
     constexpr float W32R[16] = SSDR_W32R_INIT;
     constexpr float W32I[16] = SSDR_W32I_INIT;
     constexpr int half = 1 << (S - 1);
+    constexpr int nblk = 32 / (2 * half);
 #pragma unroll
-    for (int blk = 0; blk < 32; blk += 2 * half) {
+    for (int k = 0; k < half; k++) {
+        const int mi = k * (32 >> S);                 // index into W32 (0..15)
+        if (mi == 0) {
 #pragma unroll
-        for (int k = 0; k < half; k++) {
-            const int m = k * (32 >> S);              // index into W32 (0..15)
-            const int i = blk + k, j = i + half;
-            if (m == 0) bfly_1(re[i], im[i], re[j], im[j]);
-            else if (m == 8) bfly_mj(re[i], im[i], re[j], im[j]);
-            else bfly(re[i], im[i], re[j], im[j], W32R[m], W32I[m]);
+            for (int blk = 0; blk < 32; blk += 2 * half) bfly_1(z[blk + k], z[blk + k + half]);
+        } else if (mi == 8) {
+#pragma unroll
+            for (int blk = 0; blk < 32; blk += 2 * half) bfly_mj(z[blk + k], z[blk + k + half]);
+        } else {
+            // the same wave-uniform constant for every block: twiddle from an SGPR pair
+            const f32x2 w = {W32R[mi], W32I[mi]};
+            f32x2 m[nblk], t[nblk];
+#pragma unroll
+            for (int b = 0; b < nblk; b++)
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(m[b]) : "s"(w), "v"(z[b * 2 * half + k + half]));
+#pragma unroll
+            for (int b = 0; b < nblk; b++)
+                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+                    : "=v"(t[b]) : "s"(w), "v"(z[b * 2 * half + k + half]), "v"(m[b]));
+#pragma unroll
+            for (int b = 0; b < nblk; b++) {
+                const int i = b * 2 * half + k, j = i + half;
+                const f32x2 x = z[i];
+                z[i] = x + t[b]; z[j] = x - t[b];
+            }
         }
     }
 }
 
 // stages 6..10 (T = s - 6) on x[j] = a[32 j + lane]; twiddle W_1024[(lane + 32 (j mod 2^T)) << (4 - T)]
 template <int T>
-SSDR_DEV void stage_lane(float (&re)[32], float (&im)[32], const float2 *tw_lane)
+SSDR_DEV void stage_lane(f32x2 (&z)[32], const f32x2 *tw_lane)
 {
     constexpr int half = 1 << T;
     constexpr int off = 32 * (half - 1);
+    constexpr int nblk = 16 / half;                   // butterflies sharing one twiddle
+    constexpr int JB = (nblk >= 4) ? 1 : 4 / nblk;    // twiddles per batch so that a batch has >= 4 butterflies
 #pragma unroll
-    for (int jl = 0; jl < half; jl++) {
-        const float2 w = tw_lane[off + jl * 32];
+    for (int jl0 = 0; jl0 < half; jl0 += JB) {
+        f32x2 w[JB];
 #pragma unroll
-        for (int blk = 0; blk < 32; blk += 2 * half) {
-            const int i = blk + jl, j = i + half;
-            bfly(re[i], im[i], re[j], im[j], w.x, w.y);
-        }
+        for (int q = 0; q < JB; q++) w[q] = tw_lane[off + (jl0 + q) * 32];
+        f32x2 m[JB * nblk], t[JB * nblk];
+#pragma unroll
+        for (int q = 0; q < JB; q++)
+#pragma unroll
+            for (int b = 0; b < nblk; b++)
+                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]"
+                    : "=v"(m[q * nblk + b]) : "v"(w[q]), "v"(z[b * 2 * half + jl0 + q + half]));
+#pragma unroll
+        for (int q = 0; q < JB; q++)
+#pragma unroll
+            for (int b = 0; b < nblk; b++)
+                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
+                    : "=v"(t[q * nblk + b]) : "v"(w[q]), "v"(z[b * 2 * half + jl0 + q + half]), "v"(m[q * nblk + b]));
+#pragma unroll
+        for (int q = 0; q < JB; q++)
+#pragma unroll
+            for (int b = 0; b < nblk; b++) {
+                const int i = b * 2 * half + jl0 + q, j = i + half;
+                const f32x2 x = z[i];
+                z[i] = x + t[q * nblk + b]; z[j] = x - t[q * nblk + b];
+            }
+        if (((jl0 / JB) & 1) == 1) SCHED_FENCE();
     }
 }
 
@@ -101,119 +152,205 @@ SSDR_DEV void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// one windowed FFT + power + quantise for the 32-lane half this lane belongs to
-SSDR_DEV void fft_line_bytes(const uint32_t *__restrict__ src /* + lane */, const float *s_win_lane,
-                             const float2 *s_tw_lane, const float *s_thr, float *xch, int l, float cal,
-                             int (&acc)[32])
+// raw int16 IQ dwords of one line -> windowed complex samples in a-index (bit-reversed) order
+SSDR_DEV void load_line(const uint32_t *__restrict__ src /* + lane */, uint32_t (&raw)[32])
 {
-    float re[32], im[32];
-    uint32_t raw[32];
 #pragma unroll
-    for (int r = 0; r < 32; r++) raw[r] = src[32 * r];
+    for (int r = 0; r < 32; r++) raw[r] = __builtin_nontemporal_load(src + 32 * r);
+}
+
+SSDR_DEV void window_line(const uint32_t (&raw)[32], const float *s_win_lane, f32x2 (&z)[32])
+{
 #pragma unroll
     for (int r = 0; r < 32; r++) {
         const float w = s_win_lane[32 * r];
-        const float xr = (float)(int16_t)(raw[r] & 0xFFFFu);
-        const float xi = (float)((int32_t)raw[r] >> 16);
-        re[brev5(r)] = xr * w;
-        im[brev5(r)] = xi * w;
-    }
-    stage_const<1>(re, im);
-    stage_const<2>(re, im);
-    stage_const<3>(re, im);
-    stage_const<4>(re, im);
-    stage_const<5>(re, im);
-
-    // transpose: element (g = brev5(l), r) -> lane r, register g
-    const int g = __builtin_bitreverse32((uint32_t)l) >> 27;
-#pragma unroll
-    for (int r = 0; r < 32; r++) xch[r * XPAD + g] = re[r];
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < 32; j++) re[j] = xch[l * XPAD + j];
-    wave_lds_sync();
-#pragma unroll
-    for (int r = 0; r < 32; r++) xch[r * XPAD + g] = im[r];
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < 32; j++) im[j] = xch[l * XPAD + j];
-    wave_lds_sync();
-
-    stage_lane<0>(re, im, s_tw_lane);
-    stage_lane<1>(re, im, s_tw_lane);
-    stage_lane<2>(re, im, s_tw_lane);
-    stage_lane<3>(re, im, s_tw_lane);
-    stage_lane<4>(re, im, s_tw_lane);
-
-#pragma unroll
-    for (int j = 0; j < 32; j++) {
-        const float p = fmaf(re[j], re[j], im[j] * im[j]) * cal;
-        acc[j] += ssdr_quantise(p, s_thr);
+        const f32x2 x = {(float)(int16_t)(raw[r] & 0xFFFFu), (float)((int32_t)raw[r] >> 16)};
+        z[brev5(r)] = x * w;
+        if ((r & 7) == 7) SCHED_FENCE();
     }
 }
 
-__global__ __launch_bounds__(SSDR_WF_BLOCK) void ssdr_wf_kernel(SsdrWfArgs a)
+// 1024-pt FFT of the windowed line held by this 32-lane half; on return z[j] = X[32 j + l]
+SSDR_DEV void fft_line(f32x2 (&z)[32], const f32x2 *s_tw_lane, float *xch, int l)
+{
+    stage_const<1>(z);
+    stage_const<2>(z);
+    stage_const<3>(z);
+    stage_const<4>(z);
+    stage_const<5>(z);
+    SCHED_FENCE();
+
+    // transpose: element (g = brev5(l), r) -> lane r, register g; re then im through the same buffer.
+    // Rows are written with stride 33 across lanes and read along rows: conflict-free both ways, and the
+    // reads of one lane are 132 B apart so they stay single ds_read_b32 landing in the right pair half.
+    const int g = __builtin_bitreverse32((uint32_t)l) >> 27;
+#pragma unroll
+    for (int r = 0; r < 32; r++) xch[g * XPAD + r] = z[r].x;
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 32; j++) z[j].x = xch[j * XPAD + l];
+    wave_lds_sync();
+#pragma unroll
+    for (int r = 0; r < 32; r++) xch[g * XPAD + r] = z[r].y;
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 32; j++) z[j].y = xch[j * XPAD + l];
+    wave_lds_sync();
+
+    SCHED_FENCE();
+    stage_lane<0>(z, s_tw_lane);
+    stage_lane<1>(z, s_tw_lane);
+    stage_lane<2>(z, s_tw_lane);
+    SCHED_FENCE();
+    stage_lane<3>(z, s_tw_lane);
+    SCHED_FENCE();
+    stage_lane<4>(z, s_tw_lane);
+    SCHED_FENCE();
+}
+
+struct WfItem {                 // one (channel pair, averaging group) work item, wave-uniform except ch/ch_ok
+    uint32_t ch, l0, l1, grp;
+    bool ch_ok, carry_in, complete;
+};
+
+SSDR_DEV WfItem wf_item(const SsdrWfArgs &a, uint64_t item, uint32_t n_pairs, int h)
+{
+    WfItem it;
+    it.grp = (uint32_t)(item / n_pairs);
+    const uint32_t pair = (uint32_t)(item - (uint64_t)it.grp * n_pairs);
+    const uint32_t ch_raw = 2 * pair + h;
+    it.ch_ok = ch_raw < a.n_ch;
+    it.ch = it.ch_ok ? ch_raw : a.n_ch - 1;
+    // lines [l0, l1) of this batch belong to averaging group `grp`
+    const int64_t g0 = (int64_t)it.grp * a.n_avg - a.phase;
+    it.l0 = g0 < 0 ? 0u : (uint32_t)g0;
+    it.l1 = min((uint32_t)(g0 + a.n_avg), a.n_lines);
+    it.carry_in = (it.grp == 0) && (a.phase != 0);
+    it.complete = (g0 + (int64_t)a.n_avg) <= (int64_t)a.n_lines;
+    return it;
+}
+
+// AVG == false: averaging N == 1, every line is an output line (no accumulators at all).
+// Lines stream through a software pipeline: the next line's 32 loads per lane are issued as
+// soon as the current line has been converted to float, and fly under the whole FFT.
+template <bool AVG>
+__global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_kernel(SsdrWfArgs a)
 {
     __shared__ float s_win[SSDR_NFFT];
-    __shared__ float2 s_tw[SSDR_TW_STAGE_N];
+    __shared__ f32x2 s_tw[SSDR_TW_STAGE_N];
     __shared__ float s_thr[256];
     __shared__ __attribute__((aligned(16))) float s_xch[WAVES][2][XCH_FLOATS];
 
     for (int i = threadIdx.x; i < SSDR_NFFT; i += SSDR_WF_BLOCK) s_win[i] = a.win[i];
-    for (int i = threadIdx.x; i < SSDR_TW_STAGE_N; i += SSDR_WF_BLOCK) s_tw[i] = a.tw_stage[i];
+    for (int i = threadIdx.x; i < SSDR_TW_STAGE_N; i += SSDR_WF_BLOCK) s_tw[i] = f32x2{a.tw_stage[i].x, a.tw_stage[i].y};
     for (int i = threadIdx.x; i < 256; i += SSDR_WF_BLOCK) s_thr[i] = a.thr[i];
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, l = lane & 31;
     float *xch = &s_xch[wave][h][0];
+    int16_t *x16 = reinterpret_cast<int16_t *>(xch);
+    const u32x4 *x128 = reinterpret_cast<const u32x4 *>(xch);
     const uint32_t n_pairs = (a.n_ch + 1) >> 1;
     const uint64_t n_items = (uint64_t)n_pairs * a.n_groups;
     const uint64_t wave_stride = (uint64_t)gridDim.x * WAVES;
 
-    for (uint64_t item = (uint64_t)blockIdx.x * WAVES + wave; item < n_items; item += wave_stride) {
-        const uint32_t grp = (uint32_t)(item / n_pairs);
-        const uint32_t pair = (uint32_t)(item - (uint64_t)grp * n_pairs);
-        const uint32_t ch_raw = 2 * pair + h;
-        const bool ch_ok = ch_raw < a.n_ch;
-        const uint32_t ch = ch_ok ? ch_raw : a.n_ch - 1;
-        // lines [l0, l1) of this batch belong to averaging group `grp`
-        const int64_t g0 = (int64_t)grp * a.n_avg - a.phase;
-        const uint32_t l0 = g0 < 0 ? 0u : (uint32_t)g0;
-        const uint32_t l1 = min((uint32_t)(g0 + a.n_avg), a.n_lines);
-        const bool carry_in = (grp == 0) && (a.phase != 0);
-        const bool complete = (g0 + (int64_t)a.n_avg) <= (int64_t)a.n_lines;
-        const float cal = a.consts[ch].wf_cal_lin;
+    uint64_t item = (uint64_t)blockIdx.x * WAVES + wave;
+    if (item >= n_items) return;
+    WfItem it = wf_item(a, item, n_pairs, h);
+    uint32_t line = it.l0;
+    float cal = a.consts[it.ch].wf_cal_lin;
 
-        int acc[32];
+    uint32_t raw[32];
+#if SSDR_WF_PREFETCH
+    load_line(a.iq + (uint64_t)it.ch * a.ch_stride + (uint64_t)line * SSDR_NFFT + l, raw);
+#endif
+    uint32_t acc[AVG ? 16 : 1];
 #pragma unroll
-        for (int j = 0; j < 32; j++) acc[j] = 0;
-        const uint32_t *src = a.iq + (uint64_t)ch * a.ch_stride + (uint64_t)l0 * SSDR_NFFT + l;
-        for (uint32_t line = l0; line < l1; line++, src += SSDR_NFFT)
-            fft_line_bytes(src, s_win + l, s_tw + l, s_thr, xch, l, cal, acc);
+    for (int j = 0; j < (AVG ? 16 : 1); j++) acc[j] = 0;
 
-        // stage the int16 line through LDS with the fftshift folded into the address
-        int16_t *x16 = reinterpret_cast<int16_t *>(xch);
+    for (;;) {
+        f32x2 z[32];
+#if !SSDR_WF_PREFETCH
+#if SSDR_WF_ABLATE == 2      // ablation: no global loads
 #pragma unroll
-        for (int j = 0; j < 32; j++) x16[(32 * ((j + 16) & 31) + l)] = (int16_t)acc[j];
-        wave_lds_sync();
-        int16_t *dst = complete ? a.out + ((uint64_t)grp * a.n_ch + ch) * SSDR_NFFT
-                                : a.acc_out + (uint64_t)ch * SSDR_NFFT;
-        const int16_t *cin = a.acc_in + (uint64_t)ch * SSDR_NFFT;
-        const uint4 *x128 = reinterpret_cast<const uint4 *>(xch);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            uint4 v = x128[q * 32 + l];
-            if (carry_in) {                     // wave-uniform; sums stay < 2^15 so a 32-bit add is a packed 2x16 add
-                const uint4 c = reinterpret_cast<const uint4 *>(cin)[q * 32 + l];
-                v.x += c.x;
-                v.y += c.y;
-                v.z += c.z;
-                v.w += c.w;
-            }
-            if (ch_ok) reinterpret_cast<uint4 *>(dst)[q * 32 + l] = v;
+        for (int r = 0; r < 32; r++) raw[r] = (uint32_t)(line * 2654435761u + r * 40503u + lane * 97u) & 0x1FFF1FFFu;
+#else
+        load_line(a.iq + (uint64_t)it.ch * a.ch_stride + (uint64_t)line * SSDR_NFFT + l, raw);
+#endif
+#endif
+#if SSDR_WF_ABLATE != 1
+        window_line(raw, s_win + l, z);
+        SCHED_FENCE();
+#endif
+
+        // what comes next: the following line of this group, or the first line of the next item
+        const bool group_end = (line + 1 == it.l1);
+        uint64_t nitem = item;
+        WfItem nit = it;
+        uint32_t nline = line + 1;
+        if (group_end) {
+            nitem = item + wave_stride;
+            if (nitem < n_items) { nit = wf_item(a, nitem, n_pairs, h); nline = nit.l0; }
         }
-        wave_lds_sync();
+        const bool has_next = !group_end || nitem < n_items;
+#if SSDR_WF_PREFETCH
+        if (has_next)
+            load_line(a.iq + (uint64_t)nit.ch * a.ch_stride + (uint64_t)nline * SSDR_NFFT + l, raw);
+        SCHED_FENCE();
+#endif
+
+#if SSDR_WF_ABLATE == 1      // ablation: memory traffic only
+#pragma unroll
+        for (int j = 0; j < 32; j++) x16[32 * ((j + 16) & 31) + l] = (int16_t)(raw[j] & 0xFF);
+#else
+        fft_line(z, s_tw + l, xch, l);
+
+        // |X|^2 -> 1-dB byte; bin k = 32 j + l lands at fftshifted position 32 ((j+16)&31) + l
+        if (AVG) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const float p0 = fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal;
+                const float p1 = fmaf(z[j + 16].x, z[j + 16].x, z[j + 16].y * z[j + 16].y) * cal;
+                acc[j] += (uint32_t)ssdr_quantise(p0, s_thr) | ((uint32_t)ssdr_quantise(p1, s_thr) << 16);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; j++) {
+                const float p = fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal;
+                x16[32 * ((j + 16) & 31) + l] = (int16_t)ssdr_quantise(p, s_thr);
+                if ((j & 7) == 7) SCHED_FENCE();
+            }
+        }
+
+#endif   // SSDR_WF_ABLATE == 1
+        if (group_end) {
+            if (AVG) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    x16[32 * (j + 16) + l] = (int16_t)(acc[j] & 0xFFFFu);
+                    x16[32 * j + l] = (int16_t)(acc[j] >> 16);
+                    acc[j] = 0;
+                }
+            }
+            wave_lds_sync();
+            int16_t *dst = it.complete ? a.out + ((uint64_t)it.grp * a.n_ch + it.ch) * SSDR_NFFT
+                                       : a.acc_out + (uint64_t)it.ch * SSDR_NFFT;
+            const int16_t *cin = a.acc_in + (uint64_t)it.ch * SSDR_NFFT;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u32x4 v = x128[q * 32 + l];
+                if (AVG && it.carry_in)         // wave-uniform; sums stay < 2^15 so a 32-bit add is a packed 2x16 add
+                    v += reinterpret_cast<const u32x4 *>(cin)[q * 32 + l];
+                if (it.ch_ok && (SSDR_WF_ABLATE != 3 || v.x == 0x12345u)) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst) + q * 32 + l);
+            }
+            wave_lds_sync();
+            if (!has_next) break;
+            cal = a.consts[nit.ch].wf_cal_lin;
+        }
+        item = nitem;
+        it = nit;
+        line = nline;
     }
 }
 
@@ -241,8 +378,21 @@ __global__ void ssdr_quant_selftest_kernel(const float *thr_g, unsigned long lon
 
 hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL(ssdr_wf_kernel, dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
+    if (a.n_avg > 1) hipLaunchKernelGGL(ssdr_wf_kernel<true>, dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL(ssdr_wf_kernel<false>, dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
     return hipGetLastError();
+}
+
+// workgroups of the waterfall kernel that are resident per CU (min over both instances)
+hipError_t ssdr_wf_blocks_per_cu(int *blocks)
+{
+    int b0 = 0, b1 = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, ssdr_wf_kernel<false>, SSDR_WF_BLOCK, 0);
+    if (e != hipSuccess) return e;
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, ssdr_wf_kernel<true>, SSDR_WF_BLOCK, 0);
+    if (e != hipSuccess) return e;
+    *blocks = b0 < b1 ? b0 : b1;
+    return hipSuccess;
 }
 
 hipError_t ssdr_launch_quant_selftest(const float *thr, unsigned long long *mismatch, hipStream_t stream)
