@@ -103,16 +103,12 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from supersdr_amd.dist import Rendezvous, env_rank
+    rank, local_rank, world = env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    rdv = Rendezvous("nccl", torch.device("cuda", local_rank))     # barrier + max-over-ranks only
 
     import supersdr_amd as S
     from supersdr_amd import _lib as L
@@ -138,9 +134,7 @@ def main():
         if do_audio:
             eng.run_audio(fetch=False)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
+    barrier = rdv.barrier
 
     for _ in range(args.warmup):
         step()
@@ -156,11 +150,7 @@ def main():
     eng.sync()
     torch.cuda.synchronize()
     barrier()
-    wall = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
+    wall = rdv.max_over_ranks(time.perf_counter() - t0)
 
     wf_ms, wf_n = eng.kernel_stats(L.K_WF)
     au_ms, au_n = eng.kernel_stats(L.K_AUDIO)
@@ -206,8 +196,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    rdv.close()
 
 
 if __name__ == "__main__":

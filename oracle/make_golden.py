@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""make_golden.py -- generate tests/golden/*.npz by running the REAL reference.
+
+Run in the build container only (needs /root/reference; never on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+The reference is pure Python and cannot travel, so its behaviour on the hot path is
+captured here as data: inputs and the outputs the reference's own functions produce.
+GUI/audio modules the image lacks (pygame, sounddevice, tkinter, xmltodict) are replaced
+by inert stubs -- none of them is touched by the functions exercised below.  Instances are
+built with cls.__new__ (the constructors open sockets) and given only the attributes the
+exercised method reads.
+
+Fixtures (all small):
+  filtering.npz    filtering(fl, fs).h for the cut-offs the path uses        utils_supersdr.py:333-344
+  binning.npz      np.mean time binning of N byte-valued lines               utils_supersdr.py:881-888
+  db2col.npz       spectrum_db2col in/out at zoom 0/8/14, autoscale on/off   utils_supersdr.py:787-813
+  playbuffer.npz   play_buffer over 4 consecutive frames, volume/pan cases   utils_supersdr.py:1106-1148
+  frames.npz       W/F, SND and IQ frame bytes and their decoded arrays      utils_supersdr.py:780-785,
+                   ADPCM known answer                                        1065-1074; kiwi/client.py:33-87,384-482
+  wavreader.npz    decode of a synthetic Kiwi IQ wav                         kiwi/wavreader.py:74-102
+"""
+import io
+import os
+import queue
+import struct
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    for name in ("pygame", "pygame.font", "pygame.event", "pygame.draw", "pygame.freetype", "sounddevice",
+                 "xmltodict", "requests"):
+        sys.modules.setdefault(name, mock.MagicMock())
+    loc = types.ModuleType("pygame.locals")
+    for k in (["K_%d" % i for i in range(10)] + ["K_KP%d" % i for i in range(10)] +
+              ["K_BACKSPACE", "K_RETURN", "K_ESCAPE", "K_KP_ENTER"]):
+        setattr(loc, k, hash(k) & 0xFFFF)
+    sys.modules["pygame.locals"] = loc
+    tk = types.ModuleType("tkinter")
+    tk.__all__ = []
+    sys.modules["tkinter"] = tk
+    sys.modules["tkinter.ttk"] = mock.MagicMock()
+    sys.modules["tkinter.messagebox"] = mock.MagicMock()
+    sys.path.insert(0, REF)
+    cwd = os.getcwd()
+    os.chdir(REF)              # the reference opens its .ttf fonts relative to CWD at import time
+    try:
+        import utils_supersdr as U
+        from kiwi import client as KC
+        from kiwi import wavreader as WR
+    finally:
+        os.chdir(cwd)
+    return U, KC, WR
+
+
+def gold_filtering(U):
+    out = {}
+    for fl, fs in ((6000, 48000), (3000, 12000), (6000, 12000), (1485, 12000), (200, 12000), (2700, 12000),
+                   (500, 12000), (6000, 12000.5), (10125, 48000)):
+        f = U.filtering(fl, fs)
+        out["h_%g_%g" % (fl, fs)] = f.h
+        out["n_%g_%g" % (fl, fs)] = np.int64(f.n_tap)
+    x = np.random.default_rng(1).standard_normal(300)
+    f = U.filtering(6000, 48000)
+    out["lowpass_in"] = x
+    out["lowpass_out"] = f.lowpass(x)
+    return out
+
+
+def gold_binning(U):
+    from collections import deque
+    rng = np.random.default_rng(2)
+    out = {}
+    for n in (1, 2, 3, 7, 10, 33, 100):
+        lines = rng.integers(0, 256, (n, 1024)).astype(np.uint8)
+        d = deque([], n)
+        for i in range(n):
+            d.append(lines[i].astype(np.float32))       # what receive_spectrum leaves in self.spectrum
+        out["lines_%d" % n] = lines
+        out["mean_%d" % n] = np.mean(d, axis=0)         # utils_supersdr.py:886
+    return out
+
+
+def gold_db2col(U):
+    rng = np.random.default_rng(3)
+    out = {}
+    i = 0
+    for zoom in (0, 8, 14):
+        for auto in (True, False):
+            for dlo, dhi in ((0, 0), (-10, 20)):
+                wf = U.kiwi_waterfall.__new__(U.kiwi_waterfall)
+                wf.zoom = zoom
+                wf.wf_auto_scaling = auto
+                wf.delta_low_db, wf.delta_high_db = dlo, dhi
+                wf.dynamic_range = wf.MIN_DYN_RANGE
+                base = rng.integers(120, 150, 1024).astype(np.float32)
+                base[rng.integers(0, 1024, 20)] += rng.integers(20, 90, 20)
+                if i % 3 == 2:
+                    base = (rng.integers(0, 2551, 1024) / 10.0).astype(np.float32)      # averaged (k/10) values
+                wf.spectrum = base.copy()
+                wf.spectrum_db2col()
+                out["in_%d" % i] = base
+                out["cfg_%d" % i] = np.array([zoom, int(auto), dlo, dhi], np.float64)
+                out["color_%d" % i] = np.asarray(wf.wf_color)
+                out["scal_%d" % i] = np.array([wf.low_clip_db, wf.high_clip_db, wf.dynamic_range,
+                                               wf.wf_min_db, wf.wf_max_db], np.float64)
+                i += 1
+    out["count"] = np.int64(i)
+    return out
+
+
+def gold_playbuffer(U):
+    rng = np.random.default_rng(4)
+    out = {}
+    case = 0
+    for volume, balance in ((100, 0.0), (150, 0.0), (70, -0.5), (100, 1.0), (100, -1.0)):
+        snd = U.kiwi_sound.__new__(U.kiwi_sound)
+        snd.audio_buffer = queue.Queue()
+        snd.volume = volume
+        snd.late_flag = False
+        snd.SAMPLE_RATIO = 4
+        snd.kiwi_filter = U.filtering(12000 / 2, 48000)
+        snd.n_tap = snd.kiwi_filter.n_tap
+        snd.lowpass = snd.kiwi_filter.lowpass
+        snd.old_buffer = np.zeros((snd.n_tap - 1))
+        snd.audio_balance = balance
+        snd.rssi = -80
+        snd.mute_counter = 0
+        snd.max_rssi_before_mute = -20
+        snd.muting_delay = 15
+        snd.audio_rec = types.SimpleNamespace(recording_flag=False)
+        frames = (rng.standard_normal((4, 512)) * 9000).clip(-32768, 32767).astype(np.int16)
+        frames[1, 100:110] = 32767                        # drives the truncating cast into wrap at volume 150
+        outs = []
+        for f in range(4):
+            snd.audio_buffer.put(frames[f])
+            o = np.zeros((2048, 2), np.int16)
+            with np.errstate(invalid="ignore"):
+                snd.play_buffer(o, 2048, None, None)
+            outs.append(o.copy())
+        out["in_%d" % case] = frames
+        out["cfg_%d" % case] = np.array([volume, balance], np.float64)
+        out["out_%d" % case] = np.stack(outs)
+        case += 1
+    out["count"] = np.int64(case)
+    out["n_tap"] = np.int64(U.filtering(6000, 48000).n_tap)
+    return out
+
+
+def gold_frames(U, KC):
+    rng = np.random.default_rng(5)
+    out = {}
+    # --- W/F frame: utils_supersdr.kiwi_waterfall.receive_spectrum
+    bins = rng.integers(0, 256, 1024).astype(np.uint8)
+    msg = bytearray(b"W/F" + b"\x00" + struct.pack("<III", 1234, 7, 42) + bins.tobytes())
+    wf = U.kiwi_waterfall.__new__(U.kiwi_waterfall)
+    wf.wf_stream = types.SimpleNamespace(receive_message=lambda: msg)
+    wf.keepalive = lambda: None
+    wf.receive_spectrum()
+    out["wf_msg"] = np.frombuffer(bytes(msg), np.uint8)
+    out["wf_spectrum"] = wf.spectrum
+    # --- SND frame: utils_supersdr.kiwi_sound.process_audio_stream
+    pcm = rng.integers(-32768, 32768, 512).astype(np.int16)
+    smsg = bytearray(b"SND" + struct.pack("<BI", 2, 77) + struct.pack(">H", 1270 - 733) + pcm.astype(">i2").tobytes())
+    snd = U.kiwi_sound.__new__(U.kiwi_sound)
+    snd.stream = types.SimpleNamespace(receive_message=lambda: smsg)
+    snd.run_index, snd.delta_t = 0, 0.0
+    snd.KIWI_SAMPLES_PER_FRAME, snd.KIWI_RATE = 512, 12000
+    samples = snd.process_audio_stream()
+    out["snd_msg"] = np.frombuffer(bytes(smsg), np.uint8)
+    out["snd_samples"] = samples
+    out["snd_rssi"] = np.float64(snd.rssi)
+    out["snd_adc_ovf"] = np.int64(snd.adc_overflow_flag)
+    # --- IQ frame: kiwi.client.KiwiSDRStream._process_aud (IQ branch) -> _process_iq_samples
+    iq = rng.integers(-32768, 32768, (512, 2)).astype(np.int16)
+    body = bytearray(struct.pack("<BI", 0, 99) + struct.pack(">H", 870) + struct.pack("<BBII", 5, 0, 1234567, 891011) +
+                     iq.astype(">i2").tobytes())
+    got = {}
+
+    class Rec(KC.KiwiSDRStream):
+        def __init__(self):
+            self._options = types.SimpleNamespace(ADC_OV=False, S_meter=-1, sdt=0, sound=True, raw=False, tstamp=False,
+                                                  stats=False)
+            self._s_meter_valid = False
+            self._modulation = "iq"
+            self._compression = False
+
+        def _process_iq_samples(self, seq, samples, rssi, gps):
+            got.update(seq=seq, samples=samples.copy(), rssi=rssi, gps=gps)
+
+    Rec()._process_aud(body)
+    out["iq_body"] = np.frombuffer(bytes(body), np.uint8)
+    out["iq_int16"] = iq
+    out["iq_complex64"] = got["samples"]
+    out["iq_rssi"] = np.float64(got["rssi"])
+    out["iq_seq"] = np.int64(got["seq"])
+    out["iq_gps"] = np.array([got["gps"]["last_gps_solution"], got["gps"]["dummy"], got["gps"]["gpssec"],
+                              got["gps"]["gpsnsec"]], np.int64)
+    # --- IMA ADPCM decoder known answer (kiwi/client.py:58-87): state persists across two calls
+    dec = KC.ImaAdpcmDecoder()
+    data = rng.integers(0, 256, 600).astype(np.uint8)
+    a = np.array(dec.decode(bytearray(data[:256].tobytes())), np.int16)
+    b = np.array(dec.decode(bytearray(data[256:].tobytes())), np.int16)
+    out["adpcm_in"] = data
+    out["adpcm_out"] = np.concatenate([a, b])
+    # --- W/F frame, compressed (kiwi/client.py:470-482): decoder reset per line, 10-sample tail dropped
+    got_wf = {}
+
+    class RecWf(KC.KiwiSDRStream):
+        def __init__(self):
+            self._options = types.SimpleNamespace(raw=False)
+            self._compression = True
+            self._decoder = KC.ImaAdpcmDecoder()
+
+        def _process_waterfall_samples(self, seq, samples):
+            got_wf.update(seq=seq, samples=np.array(samples, np.int16))
+
+    cbody = bytearray(struct.pack("<III", 1, 2, 3) + data[:517].tobytes())
+    RecWf()._process_wf(cbody)
+    out["wfc_body"] = np.frombuffer(bytes(cbody), np.uint8)
+    out["wfc_samples"] = got_wf["samples"]
+    return out
+
+
+def gold_wavreader(WR):
+    """A synthetic Kiwi IQ wav: RIFF/WAVE, fmt (PCM, 2 ch), then [kiwi chunk][data chunk] x 5
+    (512 samples per block, GNSS stamps 42.667 ms apart; the reader drops the first two blocks)."""
+    rng = np.random.default_rng(6)
+    blocks = [rng.integers(-32768, 32768, (512, 2)).astype("<i2") for _ in range(5)]
+    body = b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 2, 12000, 48000, 4, 16)
+    for i, blk in enumerate(blocks):
+        body += b"kiwi" + struct.pack("<IBBII", 10, 3, 0, 1000, 42666667 * i)
+        body += b"data" + struct.pack("<I", blk.nbytes) + blk.tobytes()
+    wav = b"RIFF" + struct.pack("<I", len(body)) + body
+    path = "/tmp/ssdr_golden_kiwi.wav"
+    with open(path, "wb") as f:
+        f.write(wav)
+    out = {"wav_bytes": np.frombuffer(wav, np.uint8), "blocks": np.stack(blocks).astype(np.int16)}
+    try:
+        t, z = WR.read_kiwi_iq_wav(path)
+        out["t"] = np.asarray(t, np.float64)
+        out["z"] = np.asarray(z, np.complex64)
+        out["ok"] = np.int64(1)
+    except Exception as e:          # keep the failure visible in the fixture rather than hiding it
+        out["ok"] = np.int64(0)
+        out["error"] = np.frombuffer(repr(e).encode(), np.uint8)
+    os.remove(path)
+    return out
+
+
+def main():
+    U, KC, WR = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, "filtering.npz"), **gold_filtering(U))
+    np.savez_compressed(os.path.join(OUT, "binning.npz"), **gold_binning(U))
+    np.savez_compressed(os.path.join(OUT, "db2col.npz"), **gold_db2col(U))
+    np.savez_compressed(os.path.join(OUT, "playbuffer.npz"), **gold_playbuffer(U))
+    np.savez_compressed(os.path.join(OUT, "frames.npz"), **gold_frames(U, KC))
+    np.savez_compressed(os.path.join(OUT, "wavreader.npz"), **gold_wavreader(WR))
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()

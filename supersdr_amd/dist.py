@@ -1,0 +1,67 @@
+"""Multi-GPU harness: channel-block sharding and the timing rendezvous.
+
+The path has no exchange step (channels are independent), so there is NO
+data-path collective: torch.distributed (backend "nccl" == RCCL on the GPU box, "gloo" in the
+CPU tests) is used only for the barrier around the timed region and the max-over-ranks of the
+wall time.  One process per GPU, launched by torch.distributed.run.
+"""
+import os
+
+
+def env_rank():
+    """(rank, local_rank, world) from the torchrun environment (single process if absent)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def channel_block(rank, world, total_channels):
+    """Contiguous block [first, first+count) of `total_channels` owned by `rank`; blocks differ
+    by at most one channel and cover every channel exactly once."""
+    base, extra = divmod(int(total_channels), int(world))
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+class Rendezvous:
+    """barrier() and max_over_ranks() for the bench; a no-op world of one needs no process group."""
+
+    def __init__(self, backend="nccl", device=None):
+        self.rank, self.local_rank, self.world = env_rank()
+        self.backend = backend
+        self.device = device
+        self._dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = {}
+            if backend == "nccl" and device is not None:
+                kw["device_id"] = device
+            dist.init_process_group(backend=backend, **kw)
+            self._dist = dist
+
+    def barrier(self):
+        if self._dist is not None:
+            self._dist.barrier()
+
+    def max_over_ranks(self, value):
+        if self._dist is None:
+            return float(value)
+        import torch
+        dev = self.device if (self.backend == "nccl" and self.device is not None) else "cpu"
+        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, value):
+        if self._dist is None:
+            return float(value)
+        import torch
+        dev = self.device if (self.backend == "nccl" and self.device is not None) else "cpu"
+        t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self._dist is not None:
+            self._dist.destroy_process_group()
+            self._dist = None

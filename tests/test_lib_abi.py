@@ -1,0 +1,118 @@
+"""The C-ABI library on a machine WITHOUT a GPU: it loads, exports every symbol that
+include/ssdr.h declares, its host-only entry points work, and device entry points fail
+with an error code (never a crash, never a CPU fallback)."""
+import ctypes as C
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ssdr_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def S():
+    import supersdr_amd
+    return supersdr_amd
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "ssdr.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ssdr_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_library_agree(S):
+    from supersdr_amd import _lib as L
+    names = declared_functions()
+    assert len(names) >= 27
+    raw = C.CDLL(L.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "libssdr.so does not export %s" % n
+    assert sorted(L.EXPORTS) == names          # the ctypes binding covers exactly the header
+
+
+def test_struct_layouts(S):
+    from supersdr_amd import _lib as L
+    assert C.sizeof(L.ChanParams) == 88 and C.sizeof(L.ChanConsts) == 64 and C.sizeof(L.ChanState) == 64
+    assert L.ChanParams.f_shift_hz.offset == 16 and L.ChanParams.smeter_cal_db.offset == 80
+
+
+def test_host_only_entry_points(S):
+    from supersdr_amd import _lib as L
+    assert b"gfx950" in L.lib.ssdr_version()
+    assert L.lib.ssdr_strerror(L.ENODEV) == b"no such GPU device"
+    assert L.lib.ssdr_strerror(-99) == b"unknown error"
+    p = S.default_params("cw")
+    assert (p.low_cut, p.high_cut, p.agc_decay, p.agc_thresh, p.agc_man_gain) == (400.0, 800.0, 1000.0, -80.0, 50.0)
+    p = S.default_params("lsb")
+    assert (p.low_cut, p.high_cut, p.agc_decay, p.smeter_cal_db) == (-3000.0, -30.0, 4000.0, -13.0)
+    bad = L.ChanParams()
+    assert L.lib.ssdr_default_params(9, C.byref(bad)) == L.EINVAL
+
+
+def test_tables_equal_oracle(S):
+    assert np.array_equal(S.table(0), O.hann_window())
+    wr, wi = O.twiddles()
+    assert np.array_equal(S.table(1), wr) and np.array_equal(S.table(2), wi)
+    assert np.array_equal(S.table(3), O.db_thresholds())
+    assert S.table(1)[0] == 1.0 and S.table(2)[256] == -1.0 and S.table(1)[256] == 0.0
+
+
+@pytest.mark.parametrize("mode,over", [("am", {}), ("usb", {}), ("lsb", dict(f_shift_hz=-1234.5)), ("cw", {}),
+                                       ("nbfm", {}), ("usb", dict(agc_on=0, agc_man_gain=61.0)),
+                                       ("am", dict(agc_hang=1, agc_decay=2600.0, agc_slope=7.0, agc_thresh=-95.0)),
+                                       ("usb", dict(low_cut=300.0, high_cut=2700.0, wf_cal_db=-3.5, f_shift_hz=5999.9))])
+def test_param_compile_equals_oracle(S, mode, over):
+    """ssdr_compile_params (library host code) == ssdr_oracle.compile_params, field by field;
+    FIR taps use the reference's design formula (utils_supersdr.py:334-344)"""
+    p = S.default_params(mode, **over)
+    k, taps = S.compile_params(p)
+    op = O.ChanParams(mode=mode, f_shift_hz=p.f_shift_hz, low_cut=p.low_cut, high_cut=p.high_cut, agc_on=p.agc_on,
+                      hang=p.agc_hang, thresh=p.agc_thresh, slope=p.agc_slope, decay=p.agc_decay,
+                      man_gain=p.agc_man_gain, wf_cal_db=p.wf_cal_db, smeter_cal_db=p.smeter_cal_db)
+    ok = O.compile_params(op)
+    for f in ("mode", "ntap", "dphi1", "dphi2", "hang_frames"):
+        assert int(k[f]) == int(ok[f]), f
+    assert int(k["ntap8"]) == (int(ok["ntap"]) + 7) // 8 * 8
+    for f in ("wf_cal_lin", "smeter_cal_db", "agc_c0", "agc_c1", "agc_knee", "agc_delta8"):
+        assert np.float32(k[f]) == np.float32(ok[f]), f
+    assert np.array_equal(taps, ok["taps"])
+
+
+def test_device_entry_points_fail_cleanly_without_gpu(S):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; covered by the -m gpu tests")
+    from supersdr_amd import _lib as L
+    ctx = L._P()
+    assert L.lib.ssdr_create(0, 4, 1024, 512, C.byref(ctx)) == L.ENODEV
+    assert not ctx
+    assert L.lib.ssdr_create(0, 4, 512, 512, C.byref(ctx)) == L.EINVAL
+    with pytest.raises(S.SsdrError):
+        S.SsdrEngine(4)                                   # the product refuses to run: no CPU path
+    assert L.lib.ssdr_sync(None) == L.EINVAL and L.lib.ssdr_run_wf(None, None, None, 0) == L.EINVAL
+    L.lib.ssdr_destroy(None)
+
+
+def test_missing_library_is_a_loud_import_error(tmp_path):
+    import subprocess
+    code = ("import os,sys; os.environ['SSDR_LIB_PATH']=%r; sys.path.insert(0,%r)\n"
+            "try:\n import supersdr_amd\nexcept ImportError as e:\n print('IMPORTERROR', 'no CPU fallback' in str(e).lower() or 'missing' in str(e))\n"
+            % (str(tmp_path / "nope.so"), ROOT))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert "IMPORTERROR True" in out.stdout
+
+
+def test_product_never_touches_the_oracle():
+    """supersdr_amd/ must not import, load or link anything under oracle/ (or any CPU twin)"""
+    bad = re.compile(r"oracle|ssdr_twin|twinlib|ssdr_oracle")
+    for dp, _, files in os.walk(os.path.join(ROOT, "supersdr_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                txt = open(os.path.join(dp, f)).read()
+                assert not bad.search(txt), os.path.join(dp, f)

@@ -1,0 +1,246 @@
+"""Known-answer tests for the stages the reference does NOT contain (FFT/log-mag, NCO, FIR,
+demodulators, AGC -- parity unpinned), and the fp32 C twin against the NumPy
+float64 oracle.  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import ssdr_oracle as O  # noqa: E402
+import twinlib  # noqa: E402
+
+FS = 12000.0
+
+
+def tone(f_hz, amp, n, phase=0.0):
+    t = np.arange(n)
+    z = amp * np.exp(1j * (2 * np.pi * f_hz * t / FS + phase))
+    return np.stack([np.rint(z.real), np.rint(z.imag)], axis=-1).astype(np.int16)
+
+
+def consts_for(params):
+    n = len(params)
+    consts = np.zeros(n, twinlib.CONSTS_DTYPE)
+    taps = np.zeros((n, 128), np.float32)
+    for c, p in enumerate(params):
+        k = O.compile_params(p)
+        for f in ("mode", "ntap", "dphi1", "dphi2", "wf_cal_lin", "smeter_cal_db", "agc_c0", "agc_c1", "agc_knee",
+                  "agc_delta8", "hang_frames"):
+            consts[f][c] = k[f]
+        consts["ntap8"][c] = (k["ntap"] + 7) // 8 * 8
+        taps[c] = k["taps"]
+    return consts, taps
+
+
+# ------------------------------------------------------------------ waterfall
+def test_wf_full_scale_tone_is_byte_255():
+    k0 = 100
+    iq = tone(k0 * FS / 1024, 32767.0, 1024)
+    b = O.wf_line(iq)
+    assert int(np.argmax(b)) == (k0 + 512) % 1024
+    assert b[(k0 + 512) % 1024] in (254, 255)          # 32767/32768 -> -0.0003 dB
+    assert b[(k0 + 511) % 1024] == b[(k0 + 513) % 1024] == 248        # Hann neighbours: -6.02 dB
+    assert b[(k0 + 540) % 1024] < 150                  # far skirt
+
+
+def test_wf_level_steps_one_byte_per_db():
+    levels = []
+    for amp_db in (-10.5, -11.5, -12.5, -40.5):
+        iq = tone(37 * FS / 1024, 32768.0 * 10 ** (amp_db / 20), 1024)
+        levels.append(int(O.wf_line(iq).max()))
+    assert levels == [244, 243, 242, 214]              # floor(255 + dB)
+
+
+def test_wf_negative_frequency_and_calibration():
+    iq = tone(-3000.0, 8000.0, 1024)
+    b = O.wf_line(iq)
+    assert int(np.argmax(b)) == 512 - 256              # -3 kHz -> bin 256 (ascending frequency from -6 kHz)
+    b7 = O.wf_line(iq, wf_cal_db=7.0)
+    assert int(b7.max()) - int(b.max()) == 7
+
+
+def test_wf_sum_and_mean():
+    iq = O.synth_iq(1, 4 * 1024, seed=1)[0].reshape(4, 1024, 2)
+    s = O.wf_sum_lines(iq, 4)
+    lines = O.wf_line(iq).astype(np.float32)
+    assert np.array_equal(O.wf_mean_from_sum(s[0], 4), np.mean(list(lines), axis=0))
+
+
+# ------------------------------------------------------------------ audio
+def run_oracle(p, iq):
+    ch = O.AudioChannel(p)
+    return ch.process(iq)
+
+
+def spectrum_peak(x, lo=50.0):
+    """(frequency of the strongest component, its amplitude by projection at that frequency)"""
+    w = np.hanning(len(x))
+    X = np.abs(np.fft.rfft(x * w, 8 * len(x)))
+    f = np.fft.rfftfreq(8 * len(x), 1 / FS)
+    X[f < lo] = 0
+    fp = f[np.argmax(X)]
+    amp = 2 * np.abs(np.sum(x * w * np.exp(-2j * np.pi * fp * np.arange(len(x)) / FS))) / w.sum()
+    return fp, amp
+
+
+def test_am_recovers_modulation_tone():
+    n = 16 * 512
+    t = np.arange(n)
+    z = 8000 * (1 + 0.5 * np.sin(2 * np.pi * 1000 * t / FS)) * np.exp(2j * np.pi * 1500 * t / FS)
+    iq = np.stack([np.rint(z.real), np.rint(z.imag)], -1).astype(np.int16)
+    pcm, rssi = run_oracle(O.ChanParams("am", f_shift_hz=1500.0), iq)
+    f, a = spectrum_peak(pcm[4096:].astype(float))
+    assert abs(f - 1000) < 5
+    # AGC pins the envelope peak (1.5 A) to 16384 -> the 0.5 A modulation comes out at 16384/3
+    assert abs(a - 16384 / 3) / (16384 / 3) < 0.02
+    # carrier power: 10 log10((8000^2 (1 + 0.5^2/2)) / 32768^2) - 13 dBm
+    assert abs(rssi[-1] - (10 * np.log10(8000 ** 2 * 1.125 / 32768 ** 2) - 13)) < 0.05
+
+
+def test_ssb_sideband_selection():
+    n = 16 * 512
+    up = tone(1000.0, 8000.0, n)        # +1 kHz: passes USB (30..3000), rejected by LSB
+    usb, _ = run_oracle(O.ChanParams("usb", low_cut=30, high_cut=3000), up)
+    lsb, _ = run_oracle(O.ChanParams("lsb", low_cut=-3000, high_cut=-30, agc_on=0, man_gain=50), up)
+    usb_m, _ = run_oracle(O.ChanParams("usb", low_cut=30, high_cut=3000, agc_on=0, man_gain=50), up)
+    f, a = spectrum_peak(usb[4096:].astype(float))
+    assert abs(f - 1000) < 5 and abs(a - 16384) / 16384 < 0.02       # AGC target 0.5 FS
+    f, a = spectrum_peak(usb_m[4096:].astype(float))
+    assert abs(a - 8000) / 8000 < 0.01                               # manGain 50 dB = unity
+    assert np.abs(lsb[4096:]).max() < 8000 * 10 ** (-60 / 20)        # > 60 dB opposite-sideband rejection
+
+
+def test_cw_pitch():
+    n = 24 * 512
+    iq = tone(0.0, 4000.0, n)           # carrier at the tuned frequency + 0 -> with cw passband 400..800 centred 600
+    pcm, _ = run_oracle(O.ChanParams("cw", f_shift_hz=-600.0, low_cut=400, high_cut=800, decay=1000), iq)
+    f, _ = spectrum_peak(pcm[8192:].astype(float))
+    assert abs(f - 600) < 5
+
+
+def test_nbfm_deviation_scale():
+    n = 8 * 512
+    t = np.arange(n)
+    dev = 2500.0
+    ph = 2 * np.pi * np.cumsum(dev * np.sin(2 * np.pi * 400 * t / FS)) / FS
+    z = 8000 * np.exp(1j * ph)
+    iq = np.stack([np.rint(z.real), np.rint(z.imag)], -1).astype(np.int16)
+    pcm, _ = run_oracle(O.ChanParams("nbfm"), iq)
+    f, a = spectrum_peak(pcm[2048:].astype(float))
+    assert abs(f - 400) < 5
+    assert abs(a - 16384 * dev / 5000) / (16384 * dev / 5000) < 0.02  # 5 kHz deviation <-> 0.5 FS
+
+
+def test_agc_decay_time_constant_and_hang():
+    """after a 20 dB drop the gain recovers at 8.686 dB per `decay` ms; with hang it first holds"""
+    n1, n2 = 8 * 512, 24 * 512
+    iq = np.concatenate([tone(1000.0, 8000.0, n1), tone(1000.0, 800.0, n2)])
+    for hang in (0, 1):
+        p = O.ChanParams("usb", low_cut=30, high_cut=3000, decay=1000, hang=hang)
+        ch = O.AudioChannel(p)
+        ys = []
+        for f in range((n1 + n2) // 512):
+            _, _, y = ch.process_frame(iq[f * 512:(f + 1) * 512])
+            ys.append(np.abs(y).max())
+        ys = np.array(ys)
+        assert abs(ys[7] - 16384) / 16384 < 0.02
+        drop = 20 * np.log10(ys[9] / ys[7])              # right after the step: gain still low
+        rec = 20 * np.log10(ys[9 + 12] / ys[9])          # 12 frames = 512 ms later
+        if hang == 0:
+            assert -20.5 < drop < -19.0
+            assert abs(rec - 8.686 * 0.512) < 0.3
+        else:
+            assert -20.5 < drop < -19.5
+            assert 20 * np.log10(ys[9 + 1] / ys[9]) < 0.05   # held (hang = 2 frames at decay 1000 ms)
+            assert rec > 2.5
+
+
+def test_agc_threshold_knee_and_slope():
+    weak = tone(1000.0, 20.0, 12 * 512)                  # -64 dBFS = -77 dBm: below a -60 dBm knee
+    p = O.ChanParams("usb", low_cut=30, high_cut=3000, thresh=-60)
+    pcm, _ = run_oracle(p, weak)
+    knee_amp = 32768 * 10 ** ((-60 + 13) / 20)
+    want = 20.0 * 16384 / knee_amp                       # fixed max gain below the knee
+    _, a = spectrum_peak(pcm[3072:].astype(float))
+    assert abs(a - want) / want < 0.03
+    strong = tone(1000.0, 8000.0, 12 * 512)
+    p10 = O.ChanParams("usb", low_cut=30, high_cut=3000, slope=10)
+    pcm10, _ = run_oracle(p10, strong)
+    _, a10 = spectrum_peak(pcm10[3072:].astype(float))
+    want10 = 16384 * (8000 / 32768) ** 0.1               # output rises slope/100 dB per dB
+    assert abs(a10 - want10) / want10 < 0.02
+
+
+def test_state_carry_is_sample_exact():
+    iq = O.synth_iq(1, 6 * 512, seed=3, modes=[1])[0]
+    p = O.ChanParams("usb", f_shift_hz=-1100.0, low_cut=30, high_cut=3000)
+    a, ra = O.AudioChannel(p).process(iq)
+    ch = O.AudioChannel(p)
+    parts = [ch.process(iq[s:e])[0] for s, e in ((0, 512), (512, 2048), (2048, 3072))]
+    assert np.array_equal(np.concatenate(parts), a)
+
+
+# ------------------------------------------------------------------ twin vs oracle
+def test_twin_tables_equal_oracle_tables(twin):
+    assert np.array_equal(twin.win, O.hann_window())
+    wr, wi = O.twiddles()
+    assert np.array_equal(twin.wr, wr) and np.array_equal(twin.wi, wi)
+    assert np.array_equal(twin.thr, O.db_thresholds())
+
+
+def test_twin_helpers_accuracy(twin):
+    rng = np.random.default_rng(0)
+    ph = rng.integers(0, 2 ** 32, 20000, dtype=np.uint64)
+    cs = np.array([twin.sincos20(int(p)) for p in ph[:4000]])
+    ref = O.nco_phasor(ph[:4000])
+    assert np.abs(cs[:, 0] - ref.real).max() < 2e-7 and np.abs(cs[:, 1] - ref.imag).max() < 2e-7
+    x = np.exp(rng.uniform(-20, 45, 4000)).astype(np.float32)
+    l2 = np.array([twin.lib.twin_log2p(float(v)) for v in x])
+    assert np.abs(l2 - np.log2(x.astype(np.float64))).max() < 8e-6      # fp32 resolution at |log2| ~ 64
+    y = rng.uniform(-40, 30, 4000).astype(np.float32)
+    e2 = np.array([twin.lib.twin_exp2p(float(v)) for v in y])
+    assert np.abs(e2 / 2.0 ** y.astype(np.float64) - 1).max() < 3e-7
+    a = rng.standard_normal((4000, 2)).astype(np.float32)
+    at = np.array([twin.lib.twin_atan2p(float(u), float(v)) for u, v in a])
+    assert np.abs(at - np.arctan2(a[:, 0].astype(np.float64), a[:, 1])).max() < 4e-7
+    assert twin.lib.twin_atan2p(0.0, 0.0) == 0.0
+
+
+def test_twin_quantiser_is_the_threshold_count(twin):
+    T = O.db_thresholds()
+    rng = np.random.default_rng(1)
+    p = np.concatenate([np.exp(rng.uniform(-40, 40, 5000)), T.astype(np.float64), np.nextafter(T, 0).astype(np.float64),
+                        [0.0, 1e30]]).astype(np.float32)
+    got = np.array([twin.lib.twin_quantise(float(v), T.ctypes.data) for v in p])
+    assert np.array_equal(got, O.wf_quantise(p.astype(np.float64)))
+
+
+@pytest.mark.parametrize("seed,n_ch,n_lines,n_avg", [(1, 3, 2, 1), (2, 8, 6, 3)])
+def test_twin_wf_vs_oracle(twin, seed, n_ch, n_lines, n_avg):
+    iq = O.synth_iq(n_ch, n_lines * 1024, seed=seed)
+    t = twin.wf(iq, n_avg)
+    o = np.stack([O.wf_sum_lines(iq[c].reshape(-1, 1024, 2), n_avg) for c in range(n_ch)], axis=1)
+    allowed = np.stack([O.wf_allowed_diff(iq[c].reshape(-1, 1024, 2)) for c in range(n_ch)], axis=1)
+    L = allowed.shape[0] // n_avg
+    allowed = allowed[: L * n_avg].reshape(L, n_avg, n_ch, 1024).sum(axis=1)
+    d = np.abs(t.astype(np.int32) - o)
+    assert not (d > allowed).any() and (d > 0).mean() < 1e-3
+
+
+def test_twin_audio_vs_oracle_all_modes(twin):
+    modes = ["am", "usb", "lsb", "nbfm", "cw"]
+    pb = {"am": (-6000, 6000), "usb": (30, 3000), "lsb": (-3000, -30), "nbfm": (-6000, 6000), "cw": (400, 800)}
+    iq = O.synth_iq(5, 6 * 512, seed=4, modes=[0, 1, 2, 3, 1])
+    ps = [O.ChanParams(m, f_shift_hz=((c * 37) % 97 - 48) * 100.0, low_cut=pb[m][0], high_cut=pb[m][1],
+                       hang=int(c == 1), decay=1000 if m == "cw" else 4000) for c, m in enumerate(modes)]
+    pcm_o, rssi_o = O.audio_chain(iq, ps)
+    consts, taps = consts_for(ps)
+    st, hist = twinlib.fresh_state(consts)
+    pcm_t, rssi_t = twin.audio(iq, consts, taps, st, hist)
+    rms = np.sqrt(((pcm_t.astype(np.float64) - pcm_o) ** 2).mean(axis=1)) / 32768
+    assert rms.max() < 1e-5                                          # north_star audio tolerance
+    assert np.abs(pcm_t.astype(np.int32) - pcm_o).max() <= 1
+    assert np.abs(rssi_t - rssi_o).max() < 1e-4
