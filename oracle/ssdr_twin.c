@@ -162,7 +162,13 @@ static uint32_t bitrev10(uint32_t v)
     return r;
 }
 
-/* textbook iterative radix-2 DIT, fused-multiply-add butterflies */
+/* textbook iterative radix-2 DIT.  Butterfly (u, v, w) -> (u + w v, u - w v) in its 6-FMA form
+ * (Linzer-Feig / Goedecker):
+ *     s = (fma(-wi, vi, ur), fma(wi, vr, ui))
+ *     a = (fma( wr, vr, sr), fma(wr, vi, si))        = u + w v
+ *     b = (fma(  2, ur, -ar), fma(2, ui, -ai))       = 2u - a
+ * Stages 1..5 use the exact forms a = u + v, b = u - v for w = 1 and a = u + (vi, -vr), b = u - (vi, -vr)
+ * for w = -j; stages 6..10 always use the general form (table values (1,0) and (0,-1) are exact). */
 static void fft1024(float *re, float *im, const float *wr, const float *wi)
 {
     for (uint32_t i = 0; i < NFFT; i++) {
@@ -177,17 +183,20 @@ static void fft1024(float *re, float *im, const float *wr, const float *wi)
         for (int blk = 0; blk < NFFT; blk += 2 * half) {
             for (int k = 0; k < half; k++) {
                 int m = k * step, i = blk + k, j = i + half;
-                float tr, ti;
-                if (m == 0) { tr = re[j]; ti = im[j]; }
-                else if (m == 256) { tr = im[j]; ti = -re[j]; }
-                else {
+                float ur = re[i], ui = im[i], vr = re[j], vi = im[j];
+                if (s <= 5 && m == 0) {
+                    re[i] = ur + vr; im[i] = ui + vi;
+                    re[j] = ur - vr; im[j] = ui - vi;
+                } else if (s <= 5 && m == 256) {
+                    re[i] = ur + vi; im[i] = ui - vr;
+                    re[j] = ur - vi; im[j] = ui + vr;
+                } else {
                     float a = wr[m], b = wi[m];
-                    tr = fmaf(a, re[j], -(b * im[j]));
-                    ti = fmaf(a, im[j], b * re[j]);
+                    float sr = fmaf(-b, vi, ur), si = fmaf(b, vr, ui);
+                    float ar = fmaf(a, vr, sr), ai = fmaf(a, vi, si);
+                    re[i] = ar; im[i] = ai;
+                    re[j] = fmaf(2.0f, ur, -ar); im[j] = fmaf(2.0f, ui, -ai);
                 }
-                float ur = re[i], ui = im[i];
-                re[i] = ur + tr; im[i] = ui + ti;
-                re[j] = ur - tr; im[j] = ui - ti;
             }
         }
     }

@@ -41,30 +41,32 @@ __device__ constexpr int brev5(int v)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Complex data lives in 64-bit register pairs (re, im) so that every butterfly is packed
-// fp32 math: a complex add is ONE v_pk_add_f32, a complex multiply TWO packed ops.  A wave
-// can issue one VALU instruction per 4 cycles, and that -- not HBM -- is what bounds this
-// kernel (profiles/), so the instruction count is the figure of merit.
-//
-// t = w * v with exactly the scalar definition's roundings:
-//   m  = (wi*vi, wi*vr)                       v_pk_mul_f32, operand halves picked by op_sel
-//   t  = (fma(wr, vr, -m.x), fma(wr, vi, m.y)) v_pk_fma_f32, neg_lo on the addend
-// hipcc does not form the half-negated addend itself (it emits an extra negate + move),
-// hence the two asm statements in the stage functions below.
-SSDR_DEV void bfly_1(f32x2 &u, f32x2 &v)                          // w = 1
+// Radix-2 DIT butterfly in its 6-FMA form (Linzer-Feig / Goedecker):
+//     s = u - j*wi*(j v)...   precisely, with w = (wr, wi), v = (vr, vi), u = (ur, ui):
+//     sr = fma(-wi, vi, ur)     si = fma(wi, vr, ui)          s = u + j*wi*v  (imaginary part of w)
+//     ar = fma( wr, vr, sr)     ai = fma(wr, vi, si)          a = u + w*v
+//     br = fma( 2, ur, -ar)     bi = fma(2, ui, -ai)          b = 2u - a = u - w*v
+// 6 full-rate fp32 ops instead of 8 (mul, mul, fma, fma, 4 adds); on gfx950 only fma/add/mul/mov
+// issue at 2 cycles per wave, so op count IS the cost (profiles/r01_valu_issue_rate_ubench.txt).
+// The twin (oracle/ssdr_twin.c) states the same six roundings.
+SSDR_DEV void bfly(f32x2 &u, f32x2 &v, float wr, float wi)
+{
+    const float sr = fmaf(-wi, v.y, u.x), si = fmaf(wi, v.x, u.y);
+    const float ar = fmaf(wr, v.x, sr), ai = fmaf(wr, v.y, si);
+    const float br = fmaf(2.0f, u.x, -ar), bi = fmaf(2.0f, u.y, -ai);
+    u = f32x2{ar, ai};
+    v = f32x2{br, bi};
+}
+SSDR_DEV void bfly_1(f32x2 &u, f32x2 &v)                          // w = 1 (stages 1..5 only)
 {
     const f32x2 t = v, x = u;
     u = x + t; v = x - t;
 }
-SSDR_DEV void bfly_mj(f32x2 &u, f32x2 &v)                         // w = -j: t = (vi, -vr)
+SSDR_DEV void bfly_mj(f32x2 &u, f32x2 &v)                         // w = -j: t = (vi, -vr) (stages 1..5 only)
 {
     const f32x2 t = {v.y, -v.x}, x = u;
     u = x + t; v = x - t;
 }
-
-// Butterflies are issued in batches, phase by phase (all multiplies, all fmas, all adds):
-// a packed-fp32 result cannot be consumed by the very next instruction without a wait
-// state, and independent work between producer and consumer is free.
 
 // stages 1..5 on a[0..31] (a-index order), twiddle W_1024[k * (1024 >> s)] = W32[k * (32 >> s)]
 template <int S>
@@ -73,72 +75,35 @@ SSDR_DEV void stage_const(f32x2 (&z)[32])
     constexpr float W32R[16] = SSDR_W32R_INIT;
     constexpr float W32I[16] = SSDR_W32I_INIT;
     constexpr int half = 1 << (S - 1);
-    constexpr int nblk = 32 / (2 * half);
 #pragma unroll
     for (int k = 0; k < half; k++) {
         const int mi = k * (32 >> S);                 // index into W32 (0..15)
-        if (mi == 0) {
 #pragma unroll
-            for (int blk = 0; blk < 32; blk += 2 * half) bfly_1(z[blk + k], z[blk + k + half]);
-        } else if (mi == 8) {
-#pragma unroll
-            for (int blk = 0; blk < 32; blk += 2 * half) bfly_mj(z[blk + k], z[blk + k + half]);
-        } else {
-            // the same wave-uniform constant for every block: twiddle from an SGPR pair
-            const f32x2 w = {W32R[mi], W32I[mi]};
-            f32x2 m[nblk], t[nblk];
-#pragma unroll
-            for (int b = 0; b < nblk; b++)
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(m[b]) : "s"(w), "v"(z[b * 2 * half + k + half]));
-#pragma unroll
-            for (int b = 0; b < nblk; b++)
-                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
-                    : "=v"(t[b]) : "s"(w), "v"(z[b * 2 * half + k + half]), "v"(m[b]));
-#pragma unroll
-            for (int b = 0; b < nblk; b++) {
-                const int i = b * 2 * half + k, j = i + half;
-                const f32x2 x = z[i];
-                z[i] = x + t[b]; z[j] = x - t[b];
-            }
+        for (int blk = 0; blk < 32; blk += 2 * half) {
+            const int i = blk + k, j = i + half;
+            if (mi == 0) bfly_1(z[i], z[j]);
+            else if (mi == 8) bfly_mj(z[i], z[j]);
+            else bfly(z[i], z[j], W32R[mi], W32I[mi]);
         }
     }
 }
 
-// stages 6..10 (T = s - 6) on x[j] = a[32 j + lane]; twiddle W_1024[(lane + 32 (j mod 2^T)) << (4 - T)]
+// stages 6..10 (T = s - 6) on x[j] = a[32 j + lane]; twiddle W_1024[(lane + 32 (j mod 2^T)) << (4 - T)].
+// Every butterfly takes the general form here, also where a lane's twiddle happens to be 1 or -j.
 template <int T>
 SSDR_DEV void stage_lane(f32x2 (&z)[32], const f32x2 *tw_lane)
 {
     constexpr int half = 1 << T;
     constexpr int off = 32 * (half - 1);
-    constexpr int nblk = 16 / half;                   // butterflies sharing one twiddle
-    constexpr int JB = (nblk >= 4) ? 1 : 4 / nblk;    // twiddles per batch so that a batch has >= 4 butterflies
 #pragma unroll
-    for (int jl0 = 0; jl0 < half; jl0 += JB) {
-        f32x2 w[JB];
+    for (int jl = 0; jl < half; jl++) {
+        const f32x2 w = tw_lane[off + jl * 32];
 #pragma unroll
-        for (int q = 0; q < JB; q++) w[q] = tw_lane[off + (jl0 + q) * 32];
-        f32x2 m[JB * nblk], t[JB * nblk];
-#pragma unroll
-        for (int q = 0; q < JB; q++)
-#pragma unroll
-            for (int b = 0; b < nblk; b++)
-                asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]"
-                    : "=v"(m[q * nblk + b]) : "v"(w[q]), "v"(z[b * 2 * half + jl0 + q + half]));
-#pragma unroll
-        for (int q = 0; q < JB; q++)
-#pragma unroll
-            for (int b = 0; b < nblk; b++)
-                asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_lo:[0,0,1]"
-                    : "=v"(t[q * nblk + b]) : "v"(w[q]), "v"(z[b * 2 * half + jl0 + q + half]), "v"(m[q * nblk + b]));
-#pragma unroll
-        for (int q = 0; q < JB; q++)
-#pragma unroll
-            for (int b = 0; b < nblk; b++) {
-                const int i = b * 2 * half + jl0 + q, j = i + half;
-                const f32x2 x = z[i];
-                z[i] = x + t[q * nblk + b]; z[j] = x - t[q * nblk + b];
-            }
-        if (((jl0 / JB) & 1) == 1) SCHED_FENCE();
+        for (int blk = 0; blk < 32; blk += 2 * half) {
+            const int i = blk + jl, j = i + half;
+            bfly(z[i], z[j], w.x, w.y);
+        }
+        if ((jl & 3) == 3) SCHED_FENCE();
     }
 }
 
