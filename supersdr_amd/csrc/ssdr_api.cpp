@@ -27,6 +27,7 @@ struct ssdr_ctx {
     // tables
     float *d_win = nullptr, *d_thr = nullptr;
     float2 *d_tw = nullptr;
+    uint2 *d_lut = nullptr;
     // per-channel
     ssdr_chan_consts *d_consts = nullptr;
     float *d_taps = nullptr;
@@ -129,7 +130,7 @@ void ssdr_destroy(ssdr_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_wf_acc[0], c->d_wf_acc[1],
+    void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_scratch};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -256,6 +257,7 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         HIP_TRY(hipMalloc(&c->d_win, SSDR_NFFT * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_thr, 256 * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_tw, SSDR_TW_STAGE_N * sizeof(float2)));
+        HIP_TRY(hipMalloc(&c->d_lut, SSDR_LUT_N * sizeof(uint2)));
         HIP_TRY(hipMalloc(&c->d_consts, (size_t)n_channels * sizeof(ssdr_chan_consts)));
         HIP_TRY(hipMalloc(&c->d_taps, (size_t)n_channels * SSDR_NTAP_MAX * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_state, (size_t)n_channels * sizeof(ssdr_chan_state)));
@@ -271,6 +273,9 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         HIP_TRY(hipMemcpy(c->d_win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_thr, thr.data(), thr.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+        std::vector<uint2> lut(SSDR_LUT_N);
+        if (ssdr_make_quant_lut(lut.data()) != 0) return SSDR_EINVAL;
+        HIP_TRY(hipMemcpy(c->d_lut, lut.data(), lut.size() * sizeof(uint2), hipMemcpyHostToDevice));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device_id));
         int per_cu = 0;
@@ -446,7 +451,7 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
     a.consts = c->d_consts;
     a.win = c->d_win;
     a.tw_stage = c->d_tw;
-    a.thr = c->d_thr;
+    a.lut = c->d_lut;
     const uint64_t items = (uint64_t)((c->n_ch + 1) / 2) * n_groups;
     const uint64_t need = (items + SSDR_WF_BLOCK / 64 - 1) / (SSDR_WF_BLOCK / 64);
     const uint32_t grid = (uint32_t)(need < c->wf_grid ? need : c->wf_grid);
@@ -553,7 +558,7 @@ int ssdr_selftest_quantiser(ssdr_ctx *c, uint64_t *mismatches)
     if (!c || !mismatches) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemsetAsync(c->d_scratch, 0, 8, c->stream));
-    HIP_TRY(ssdr_launch_quant_selftest(c->d_thr, c->d_scratch, c->stream));
+    HIP_TRY(ssdr_launch_quant_selftest(c->d_thr, c->d_lut, c->d_scratch, c->stream));
     unsigned long long v = 0;
     HIP_TRY(hipMemcpyAsync(&v, c->d_scratch, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

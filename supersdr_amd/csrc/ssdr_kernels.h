@@ -5,18 +5,26 @@
 #include "../../include/ssdr.h"
 
 #ifndef SSDR_WF_BLOCK
-#define SSDR_WF_BLOCK 256                    // threads per workgroup of the waterfall kernel
+#define SSDR_WF_BLOCK 512                    // two workgroups per CU: 16 waves = 4 per SIMD, <= 128 VGPRs
+#endif
+#ifndef SSDR_WF_LUT_GLOBAL
+#define SSDR_WF_LUT_GLOBAL 0
 #endif
 #ifndef SSDR_WF_ABLATE
 #define SSDR_WF_ABLATE 0                     // profiling ablations only (1 memory-only, 2 no loads, 3 no stores)
 #endif
-#ifndef SSDR_WF_PREFETCH
-#define SSDR_WF_PREFETCH 0                   // 1: register software pipeline (costs 32 VGPRs)
-#endif
-#ifndef SSDR_WF_WAVES_PER_EU
-#define SSDR_WF_WAVES_PER_EU 3                // register budget: 3 waves/SIMD -> <= 168 VGPRs
-#endif
 #define SSDR_TW_STAGE_N 992                  // per-stage twiddle table entries: 32*(1+2+4+8+16)
+// dB quantiser table: one entry per 2^-SSDR_LUT_BITS octave segment of [2^-37, 2^50], indexed by
+// bits(p) >> (23 - SSDR_LUT_BITS).  4 bits: 0.19 dB segments, index from one SDWA op, 11 KB;
+// 2 bits: 0.75 dB segments (still < 1 dB: at most one threshold inside), shift + and, 2.8 KB.
+#ifndef SSDR_LUT_BITS
+#define SSDR_LUT_BITS 2
+#endif
+#define SSDR_LUT_PLO 0x1p-37f
+#define SSDR_LUT_PHI 0x1p50f
+#define SSDR_LUT_SHIFT (23 - SSDR_LUT_BITS)
+#define SSDR_LUT_IDX0 (90 << SSDR_LUT_BITS)                      // bits(2^-37) >> SHIFT
+#define SSDR_LUT_N (((177 - 90) << SSDR_LUT_BITS) + 1)           // (bits(2^50) >> SHIFT) - IDX0 + 1
 #define SSDR_AUDIO_BLOCK 64                  // one wave == one receiver channel
 
 struct SsdrWfArgs {
@@ -30,9 +38,9 @@ struct SsdrWfArgs {
     int16_t *acc_out;                        // [n_ch][1024] partial sums carried out (a different buffer: other
                                              // workgroups may still be reading acc_in)
     const ssdr_chan_consts *consts;          // [n_ch] (wf_cal_lin)
-    const float *win;                        // [1024]
+    const float *win;                        // [513]  first half of the symmetric window + midpoint
     const float2 *tw_stage;                  // [992]
-    const float *thr;                        // [256]
+    const uint2 *lut;                        // [SSDR_LUT_N] quantiser segments: {count at lower edge, threshold inside or +inf}
 };
 
 struct SsdrAudioArgs {
@@ -59,11 +67,12 @@ hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream
 hipError_t ssdr_wf_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_synth(const SsdrSynthArgs &a, hipStream_t stream);
-hipError_t ssdr_launch_quant_selftest(const float *thr, unsigned long long *mismatch, hipStream_t stream);
+hipError_t ssdr_launch_quant_selftest(const float *thr, const uint2 *lut, unsigned long long *mismatch, hipStream_t stream);
 
 // host-side tables and parameter compilation (ssdr_tables.cpp)
 void ssdr_make_window(float *win);                    // [1024]
 void ssdr_make_twiddles(float *wr, float *wi);        // [512] each
 void ssdr_make_tw_stage(float2 *tw);                  // [992]
 void ssdr_make_thresholds(float *thr);                // [256]
+int ssdr_make_quant_lut(uint2 *lut);                  // [SSDR_LUT_N]; returns 0, or -1 if a segment held two thresholds
 int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps);

@@ -45,6 +45,29 @@ void ssdr_make_thresholds(float *thr)
     for (int k = 0; k < 256; k++) thr[k] = (float)(std::pow(10.0, (k - 255) / 10.0) * 281474976710656.0 /* 2^48 */);
 }
 
+// Quantiser segments (see ssdr_wf.hip:quantise): segment i holds the floats p with
+// (bits(p) >> SSDR_LUT_SHIFT) == SSDR_LUT_IDX0 + i; entry = {#{k>=1 : T[k] <= lower edge}, the threshold inside the
+// segment or +inf}.  A segment is narrower than 1 dB, so it never holds two thresholds (checked).
+int ssdr_make_quant_lut(uint2 *lut)
+{
+    float thr[256];
+    ssdr_make_thresholds(thr);
+    for (int i = 0; i < SSDR_LUT_N; i++) {
+        const uint32_t lo_bits = (uint32_t)(SSDR_LUT_IDX0 + i) << SSDR_LUT_SHIFT;
+        const uint32_t hi_bits = lo_bits + (1u << SSDR_LUT_SHIFT);
+        float lo, hi;
+        std::memcpy(&lo, &lo_bits, 4);
+        std::memcpy(&hi, &hi_bits, 4);
+        uint32_t base = 0;
+        for (int k = 1; k < 256; k++) base += (thr[k] <= lo) ? 1u : 0u;
+        uint32_t next_bits = 0x7F800000u;                       // +inf: no threshold inside
+        if (base < 255 && thr[base + 1] < hi) std::memcpy(&next_bits, &thr[base + 1], 4);
+        if (base < 254 && thr[base + 2] < hi) return -1;
+        lut[i] = make_uint2(base, next_bits);
+    }
+    return 0;
+}
+
 static double sinc_pi(double x)
 {
     if (x == 0.0) return 1.0;

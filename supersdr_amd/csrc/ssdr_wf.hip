@@ -13,12 +13,18 @@
 //     owns (compile-time W_32 twiddles), ONE transpose through LDS (stride-33 padded,
 //     conflict-free both ways, re then im through the same 4.1 KB), stages 6..10 in
 //     registers again with per-lane twiddles from a per-stage LDS table.
-//   * power, quantiser (bit-pattern estimate + one LDS threshold compare), N-line
+//   * power, quantiser (one LDS table look-up + one compare, see quantise()), N-line
 //     accumulation in registers, then the line is staged through the (now free)
 //     exchange buffer so every lane stores 16 contiguous bytes (512 B per half-wave
 //     instruction) with the fftshift folded into the LDS address.
 //   The butterflies are exactly those of a textbook radix-2 DIT FFT (same operand
-//   pairs, same fma pattern), only regrouped -- results are bit-identical to it.
+//   pairs, same six fused multiply-adds), only regrouped -- results are bit-identical.
+//
+// What bounds it (profiles/): VALU issue, not HBM.  On gfx950 only v_fma/add/mul/mov_f32
+// and simple integer add/and issue at ~2.5 cycles per wave; shifts, conversions, med3,
+// compares and all packed-fp32 ops take ~4.5.  Hence: scalar (unpacked) 6-FMA butterflies,
+// a quantiser with a single slow op chain, and one 1024-thread workgroup per CU (16 waves,
+// 4 per SIMD, <= 128 VGPRs) that owns the whole 160 KB of LDS.
 #include "ssdr_math.h"
 #include "ssdr_kernels.h"
 
@@ -28,6 +34,28 @@ constexpr int XPAD = 33;                       // row stride (floats) of the tra
 constexpr int XCH_FLOATS = 32 * XPAD;          // per FFT: 4224 B
 constexpr int WAVES = SSDR_WF_BLOCK / 64;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// LDS map of the waterfall kernel (one allocation starting at LDS address 0, so that the quantiser's
+// table index IS the LDS address: entry i of the table lives at byte 8*i, i = bits(p) >> SSDR_LUT_SHIFT):
+//   window (513 floats: first half + midpoint, w[n] = w[1024-n]), per-stage twiddles for FFT stages
+//   6..10 (992 float2), quantiser table, then the per-wave transpose / staging buffers (2 x 4224 B).
+constexpr int LDS_LUT0 = SSDR_LUT_IDX0 * 8;                     // address of the first stored entry
+constexpr int LDS_LUT_END = LDS_LUT0 + SSDR_LUT_N * 8;
+#if SSDR_LUT_BITS == 4
+constexpr int LDS_WIN = 0;                                      // [0, 2064)
+constexpr int LDS_TW = 2064;                                    // [2064, 10000)   table at [11520, 22664)
+constexpr int LDS_XCH = (LDS_LUT_END + 15) & ~15;
+static_assert(LDS_TW + SSDR_TW_STAGE_N * 8 <= LDS_LUT0, "tables overlap");
+#else
+constexpr int LDS_WIN = 0;                                      // [0, 2064)       table at [2880, 5672)
+constexpr int LDS_TW = (LDS_LUT_END + 15) & ~15;                // [5680, 13616)
+constexpr int LDS_XCH = LDS_TW + SSDR_TW_STAGE_N * 8;
+static_assert(LDS_WIN + 2064 <= LDS_LUT0, "tables overlap");
+#endif
+constexpr int LDS_TOTAL = LDS_XCH + WAVES * 2 * XCH_FLOATS * 4;
+static_assert(LDS_XCH % 16 == 0 && LDS_TW % 8 == 0, "alignment");
+static_assert(LDS_TOTAL * (1024 / SSDR_WF_BLOCK) <= 163840, "LDS budget: 16 waves per CU");
 
 // The register budget only holds if the phases of a line stay phases: without these fences
 // the machine scheduler hoists later phases' LDS table reads across the whole FFT and spills.
@@ -39,16 +67,11 @@ __device__ constexpr int brev5(int v)
     return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
 }
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// Radix-2 DIT butterfly in its 6-FMA form (Linzer-Feig / Goedecker):
-//     s = u - j*wi*(j v)...   precisely, with w = (wr, wi), v = (vr, vi), u = (ur, ui):
-//     sr = fma(-wi, vi, ur)     si = fma(wi, vr, ui)          s = u + j*wi*v  (imaginary part of w)
+// Radix-2 DIT butterfly in its 6-FMA form (Linzer-Feig / Goedecker), w = (wr, wi):
+//     sr = fma(-wi, vi, ur)     si = fma(wi, vr, ui)
 //     ar = fma( wr, vr, sr)     ai = fma(wr, vi, si)          a = u + w*v
-//     br = fma( 2, ur, -ar)     bi = fma(2, ui, -ai)          b = 2u - a = u - w*v
-// 6 full-rate fp32 ops instead of 8 (mul, mul, fma, fma, 4 adds); on gfx950 only fma/add/mul/mov
-// issue at 2 cycles per wave, so op count IS the cost (profiles/r01_valu_issue_rate_ubench.txt).
-// The twin (oracle/ssdr_twin.c) states the same six roundings.
+//     br = fma(  2, ur, -ar)    bi = fma( 2, ui, -ai)         b = 2u - a = u - w*v
+// 6 full-rate fp32 ops instead of 8.  The twin (oracle/ssdr_twin.c) states the same six roundings.
 SSDR_DEV void bfly(f32x2 &u, f32x2 &v, float wr, float wi)
 {
     const float sr = fmaf(-wi, v.y, u.x), si = fmaf(wi, v.x, u.y);
@@ -107,6 +130,15 @@ SSDR_DEV void stage_lane(f32x2 (&z)[32], const f32x2 *tw_lane)
     }
 }
 
+// Per-lane LDS base addresses are all cheap functions of the lane id.  Left alone, the compiler keeps
+// a dozen of them live across the whole line (and spills them at the 128-VGPR budget); laundering
+// the lane id through an empty asm makes each phase recompute its own base in one or two fast ops.
+SSDR_DEV int opaque(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 SSDR_DEV void wave_lds_sync()
 {
     // One wave owns its LDS region and DS instructions of a wave execute in order, so
@@ -117,18 +149,45 @@ SSDR_DEV void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// raw int16 IQ dwords of one line -> windowed complex samples in a-index (bit-reversed) order
+// dB quantiser: byte = #{k in 1..255 : T[k] <= p}, exactly, without a logarithm.
+// A float's top bits (sign, exponent, SSDR_LUT_BITS mantissa bits) name a segment narrower than 1 dB;
+// a segment contains at most one 1-dB threshold, so the host tabulates per segment the count at
+// its lower edge and the one threshold that may lie inside it (+inf if none):
+//     byte = lut[seg].base + (p >= lut[seg].next)
+// p is clamped to [2^-37, 2^50] (below T[1] / above T[255]).  The table sits in LDS such that the
+// segment index scaled by the entry size is the LDS address.
+SSDR_DEV uint32_t quantise(float p, const unsigned char *lut0, uint32_t mask)
+{
+    const float pc = __builtin_amdgcn_fmed3f(p, SSDR_LUT_PLO, SSDR_LUT_PHI);
+    uint32_t off;
+#if SSDR_LUT_BITS == 4
+    // one full-rate op: SDWA picks the upper half-word, the mask (0xFFF8) drops the low mantissa bits
+    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+        : "=v"(off) : "v"(__float_as_uint(pc)), "v"(mask));
+#else
+    off = (__float_as_uint(pc) >> (SSDR_LUT_SHIFT - 3)) & mask;          // mask = ~7
+#endif
+    const uint2 e = *reinterpret_cast<const uint2 *>(lut0 + off);
+    return e.x + ((pc >= __uint_as_float(e.y)) ? 1u : 0u);
+}
+
 SSDR_DEV void load_line(const uint32_t *__restrict__ src /* + lane */, uint32_t (&raw)[32])
 {
 #pragma unroll
     for (int r = 0; r < 32; r++) raw[r] = __builtin_nontemporal_load(src + 32 * r);
 }
 
-SSDR_DEV void window_line(const uint32_t (&raw)[32], const float *s_win_lane, f32x2 (&z)[32])
+// raw int16 IQ dwords of one line -> windowed complex samples in a-index (bit-reversed) order.
+// The window is symmetric, w[n] = w[1024-n]: samples of the second half read the same 513-entry table
+// backwards from a second per-lane base.
+SSDR_DEV void window_line(const uint32_t (&raw)[32], const unsigned char *smem, int l, f32x2 (&z)[32])
 {
+    const int ll = opaque(l);
+    const float *win_up = reinterpret_cast<const float *>(smem + LDS_WIN) + ll;
+    const float *win_dn = reinterpret_cast<const float *>(smem + LDS_WIN) - ll;
 #pragma unroll
     for (int r = 0; r < 32; r++) {
-        const float w = s_win_lane[32 * r];
+        const float w = (r < 16) ? win_up[32 * r] : win_dn[32 * (32 - r)];
         const f32x2 x = {(float)(int16_t)(raw[r] & 0xFFFFu), (float)((int32_t)raw[r] >> 16)};
         z[brev5(r)] = x * w;
         if ((r & 7) == 7) SCHED_FENCE();
@@ -136,7 +195,7 @@ SSDR_DEV void window_line(const uint32_t (&raw)[32], const float *s_win_lane, f3
 }
 
 // 1024-pt FFT of the windowed line held by this 32-lane half; on return z[j] = X[32 j + l]
-SSDR_DEV void fft_line(f32x2 (&z)[32], const f32x2 *s_tw_lane, float *xch, int l)
+SSDR_DEV void fft_line(f32x2 (&z)[32], const unsigned char *smem, float *xch_wave, int h, int l)
 {
     stage_const<1>(z);
     stage_const<2>(z);
@@ -146,23 +205,25 @@ SSDR_DEV void fft_line(f32x2 (&z)[32], const f32x2 *s_tw_lane, float *xch, int l
     SCHED_FENCE();
 
     // transpose: element (g = brev5(l), r) -> lane r, register g; re then im through the same buffer.
-    // Rows are written with stride 33 across lanes and read along rows: conflict-free both ways, and the
-    // reads of one lane are 132 B apart so they stay single ds_read_b32 landing in the right pair half.
-    const int g = __builtin_bitreverse32((uint32_t)l) >> 27;
+    // Rows are written with stride 33 across lanes and read along rows: conflict-free both ways.
+    const int lx = opaque(l);
+    float *xch = xch_wave + opaque(h) * XCH_FLOATS;
+    const int g = __builtin_bitreverse32((uint32_t)lx) >> 27;
 #pragma unroll
     for (int r = 0; r < 32; r++) xch[g * XPAD + r] = z[r].x;
     wave_lds_sync();
 #pragma unroll
-    for (int j = 0; j < 32; j++) z[j].x = xch[j * XPAD + l];
+    for (int j = 0; j < 32; j++) z[j].x = xch[j * XPAD + lx];
     wave_lds_sync();
 #pragma unroll
     for (int r = 0; r < 32; r++) xch[g * XPAD + r] = z[r].y;
     wave_lds_sync();
 #pragma unroll
-    for (int j = 0; j < 32; j++) z[j].y = xch[j * XPAD + l];
+    for (int j = 0; j < 32; j++) z[j].y = xch[j * XPAD + lx];
     wave_lds_sync();
 
     SCHED_FENCE();
+    const f32x2 *s_tw_lane = reinterpret_cast<const f32x2 *>(smem + LDS_TW) + opaque(l);
     stage_lane<0>(z, s_tw_lane);
     stage_lane<1>(z, s_tw_lane);
     stage_lane<2>(z, s_tw_lane);
@@ -178,11 +239,11 @@ struct WfItem {                 // one (channel pair, averaging group) work item
     bool ch_ok, carry_in, complete;
 };
 
-SSDR_DEV WfItem wf_item(const SsdrWfArgs &a, uint64_t item, uint32_t n_pairs, int h)
+SSDR_DEV WfItem wf_item(const SsdrWfArgs &a, uint32_t item, uint32_t n_pairs, int h)
 {
     WfItem it;
-    it.grp = (uint32_t)(item / n_pairs);
-    const uint32_t pair = (uint32_t)(item - (uint64_t)it.grp * n_pairs);
+    it.grp = item / n_pairs;
+    const uint32_t pair = item - it.grp * n_pairs;
     const uint32_t ch_raw = 2 * pair + h;
     it.ch_ok = ch_raw < a.n_ch;
     it.ch = it.ch_ok ? ch_raw : a.n_ch - 1;
@@ -195,137 +256,121 @@ SSDR_DEV WfItem wf_item(const SsdrWfArgs &a, uint64_t item, uint32_t n_pairs, in
     return it;
 }
 
-// AVG == false: averaging N == 1, every line is an output line (no accumulators at all).
-// Lines stream through a software pipeline: the next line's 32 loads per lane are issued as
-// soon as the current line has been converted to float, and fly under the whole FFT.
-template <bool AVG>
-__global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_kernel(SsdrWfArgs a)
+SSDR_DEV void load_tables(unsigned char *smem, const float *win, const float2 *tw, const uint2 *lut)
 {
-    __shared__ float s_win[SSDR_NFFT];
-    __shared__ f32x2 s_tw[SSDR_TW_STAGE_N];
-    __shared__ float s_thr[256];
-    __shared__ __attribute__((aligned(16))) float s_xch[WAVES][2][XCH_FLOATS];
-
-    for (int i = threadIdx.x; i < SSDR_NFFT; i += SSDR_WF_BLOCK) s_win[i] = a.win[i];
-    for (int i = threadIdx.x; i < SSDR_TW_STAGE_N; i += SSDR_WF_BLOCK) s_tw[i] = f32x2{a.tw_stage[i].x, a.tw_stage[i].y};
-    for (int i = threadIdx.x; i < 256; i += SSDR_WF_BLOCK) s_thr[i] = a.thr[i];
+    float *s_win = reinterpret_cast<float *>(smem + LDS_WIN);
+    f32x2 *s_tw = reinterpret_cast<f32x2 *>(smem + LDS_TW);
+    uint2 *s_lut = reinterpret_cast<uint2 *>(smem + LDS_LUT0);
+    for (int i = threadIdx.x; i < 513; i += blockDim.x) s_win[i] = win[i];
+    for (int i = threadIdx.x; i < SSDR_TW_STAGE_N; i += blockDim.x) s_tw[i] = f32x2{tw[i].x, tw[i].y};
+    for (int i = threadIdx.x; i < SSDR_LUT_N; i += blockDim.x) s_lut[i] = lut[i];
     __syncthreads();
+}
+
+// AVG == false: averaging N == 1, every line is an output line (no accumulators at all).
+template <bool AVG>
+__global__ __launch_bounds__(SSDR_WF_BLOCK, 4) void ssdr_wf_kernel(SsdrWfArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];     // the kernel's only LDS object: address 0
+    load_tables(smem, a.win, a.tw_stage, a.lut);
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, l = lane & 31;
-    float *xch = &s_xch[wave][h][0];
-    int16_t *x16 = reinterpret_cast<int16_t *>(xch);
-    const u32x4 *x128 = reinterpret_cast<const u32x4 *>(xch);
-    const uint32_t n_pairs = (a.n_ch + 1) >> 1;
-    const uint64_t n_items = (uint64_t)n_pairs * a.n_groups;
-    const uint64_t wave_stride = (uint64_t)gridDim.x * WAVES;
-
-    uint64_t item = (uint64_t)blockIdx.x * WAVES + wave;
-    if (item >= n_items) return;
-    WfItem it = wf_item(a, item, n_pairs, h);
-    uint32_t line = it.l0;
-    float cal = a.consts[it.ch].wf_cal_lin;
-
-    uint32_t raw[32];
-#if SSDR_WF_PREFETCH
-    load_line(a.iq + (uint64_t)it.ch * a.ch_stride + (uint64_t)line * SSDR_NFFT + l, raw);
+    float *xch_wave = reinterpret_cast<float *>(smem + LDS_XCH) + wave * 2 * XCH_FLOATS;      // wave-uniform
+    const uint32_t mask_fff8 = (SSDR_LUT_BITS == 4) ? 0xFFF8u : ~7u;
+#if SSDR_WF_LUT_GLOBAL      // table through the vector L1 (the TA path is nearly idle) instead of LDS
+    const unsigned char *lut0 = reinterpret_cast<const unsigned char *>(a.lut) - LDS_LUT0;
+#else
+    const unsigned char *lut0 = smem;
 #endif
-    uint32_t acc[AVG ? 16 : 1];
-#pragma unroll
-    for (int j = 0; j < (AVG ? 16 : 1); j++) acc[j] = 0;
+    const uint32_t n_pairs = (a.n_ch + 1) >> 1;
+    const uint32_t n_items = n_pairs * a.n_groups;
+    const uint32_t wave_stride = gridDim.x * WAVES;
 
-    for (;;) {
-        f32x2 z[32];
-#if !SSDR_WF_PREFETCH
+    for (uint32_t item = blockIdx.x * WAVES + wave; item < n_items; item += wave_stride) {
+        const WfItem it = wf_item(a, item, n_pairs, h);
+        const float cal = a.consts[it.ch].wf_cal_lin;
+        uint32_t acc[AVG ? 16 : 1];
+#pragma unroll
+        for (int j = 0; j < (AVG ? 16 : 1); j++) acc[j] = 0;
+        const uint32_t *src = a.iq + (uint64_t)it.ch * a.ch_stride + (uint64_t)it.l0 * SSDR_NFFT + l;
+
+        for (uint32_t line = it.l0; line < it.l1; line++, src += SSDR_NFFT) {
+            f32x2 z[32];
+            uint32_t raw[32];
 #if SSDR_WF_ABLATE == 2      // ablation: no global loads
 #pragma unroll
-        for (int r = 0; r < 32; r++) raw[r] = (uint32_t)(line * 2654435761u + r * 40503u + lane * 97u) & 0x1FFF1FFFu;
+            for (int r = 0; r < 32; r++) raw[r] = (uint32_t)(line * 2654435761u + r * 40503u + lane * 97u) & 0x1FFF1FFFu;
 #else
-        load_line(a.iq + (uint64_t)it.ch * a.ch_stride + (uint64_t)line * SSDR_NFFT + l, raw);
+            load_line(src, raw);
 #endif
-#endif
-#if SSDR_WF_ABLATE != 1
-        window_line(raw, s_win + l, z);
-        SCHED_FENCE();
-#endif
-
-        // what comes next: the following line of this group, or the first line of the next item
-        const bool group_end = (line + 1 == it.l1);
-        uint64_t nitem = item;
-        WfItem nit = it;
-        uint32_t nline = line + 1;
-        if (group_end) {
-            nitem = item + wave_stride;
-            if (nitem < n_items) { nit = wf_item(a, nitem, n_pairs, h); nline = nit.l0; }
-        }
-        const bool has_next = !group_end || nitem < n_items;
-#if SSDR_WF_PREFETCH
-        if (has_next)
-            load_line(a.iq + (uint64_t)nit.ch * a.ch_stride + (uint64_t)nline * SSDR_NFFT + l, raw);
-        SCHED_FENCE();
-#endif
-
 #if SSDR_WF_ABLATE == 1      // ablation: memory traffic only
 #pragma unroll
-        for (int j = 0; j < 32; j++) x16[32 * ((j + 16) & 31) + l] = (int16_t)(raw[j] & 0xFF);
+            int16_t *x16 = reinterpret_cast<int16_t *>(xch_wave + opaque(h) * XCH_FLOATS) + opaque(l);
+            for (int j = 0; j < 32; j++) x16[32 * ((j + 16) & 31)] = (int16_t)(raw[j] & 0xFF);
 #else
-        fft_line(z, s_tw + l, xch, l);
+            window_line(raw, smem, l, z);
+            SCHED_FENCE();
+            fft_line(z, smem, xch_wave, h, l);
 
-        // |X|^2 -> 1-dB byte; bin k = 32 j + l lands at fftshifted position 32 ((j+16)&31) + l
-        if (AVG) {
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const float p0 = fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal;
-                const float p1 = fmaf(z[j + 16].x, z[j + 16].x, z[j + 16].y * z[j + 16].y) * cal;
-                acc[j] += (uint32_t)ssdr_quantise(p0, s_thr) | ((uint32_t)ssdr_quantise(p1, s_thr) << 16);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 32; j++) {
-                const float p = fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal;
-                x16[32 * ((j + 16) & 31) + l] = (int16_t)ssdr_quantise(p, s_thr);
-                if ((j & 7) == 7) SCHED_FENCE();
-            }
-        }
-
-#endif   // SSDR_WF_ABLATE == 1
-        if (group_end) {
+            // |X|^2 -> 1-dB byte; bin k = 32 j + l lands at fftshifted position 32 ((j+16)&31) + l
+            int16_t *x16 = reinterpret_cast<int16_t *>(xch_wave + opaque(h) * XCH_FLOATS) + opaque(l);
             if (AVG) {
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
-                    x16[32 * (j + 16) + l] = (int16_t)(acc[j] & 0xFFFFu);
-                    x16[32 * j + l] = (int16_t)(acc[j] >> 16);
-                    acc[j] = 0;
+                    const float p0 = fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal;
+                    const float p1 = fmaf(z[j + 16].x, z[j + 16].x, z[j + 16].y * z[j + 16].y) * cal;
+                    acc[j] += quantise(p0, lut0, mask_fff8) + (quantise(p1, lut0, mask_fff8) << 16);
+                    if ((j & 3) == 3) SCHED_FENCE();
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    const float p = fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal;
+                    x16[32 * ((j + 16) & 31)] = (int16_t)quantise(p, lut0, mask_fff8);
+                    if ((j & 7) == 7) SCHED_FENCE();
                 }
             }
-            wave_lds_sync();
-            int16_t *dst = it.complete ? a.out + ((uint64_t)it.grp * a.n_ch + it.ch) * SSDR_NFFT
-                                       : a.acc_out + (uint64_t)it.ch * SSDR_NFFT;
-            const int16_t *cin = a.acc_in + (uint64_t)it.ch * SSDR_NFFT;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                u32x4 v = x128[q * 32 + l];
-                if (AVG && it.carry_in)         // wave-uniform; sums stay < 2^15 so a 32-bit add is a packed 2x16 add
-                    v += reinterpret_cast<const u32x4 *>(cin)[q * 32 + l];
-                if (it.ch_ok && (SSDR_WF_ABLATE != 3 || v.x == 0x12345u)) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst) + q * 32 + l);
-            }
-            wave_lds_sync();
-            if (!has_next) break;
-            cal = a.consts[nit.ch].wf_cal_lin;
+#endif
         }
-        item = nitem;
-        it = nit;
-        line = nline;
+
+        float *xch = xch_wave + opaque(h) * XCH_FLOATS;
+        if (AVG) {
+            int16_t *x16 = reinterpret_cast<int16_t *>(xch) + opaque(l);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                x16[32 * (j + 16)] = (int16_t)(acc[j] & 0xFFFFu);
+                x16[32 * j] = (int16_t)(acc[j] >> 16);
+            }
+        }
+        wave_lds_sync();
+        const u32x4 *x128 = reinterpret_cast<const u32x4 *>(xch);
+        int16_t *dst = it.complete ? a.out + ((uint64_t)it.grp * a.n_ch + it.ch) * SSDR_NFFT
+                                   : a.acc_out + (uint64_t)it.ch * SSDR_NFFT;
+        const int16_t *cin = a.acc_in + (uint64_t)it.ch * SSDR_NFFT;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            u32x4 v = x128[q * 32 + l];
+            if (AVG && it.carry_in)         // wave-uniform; sums stay < 2^15 so a 32-bit add is a packed 2x16 add
+                v += reinterpret_cast<const u32x4 *>(cin)[q * 32 + l];
+            if (it.ch_ok) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst) + q * 32 + l);
+        }
+        wave_lds_sync();
     }
 }
 
-// exhaustive quantiser self-test: every positive finite float against a binary search
-__global__ void ssdr_quant_selftest_kernel(const float *thr_g, unsigned long long *mismatch)
+// exhaustive quantiser self-test: every positive finite float against a binary search over T[]
+__global__ __launch_bounds__(256) void ssdr_quant_selftest_kernel(const float *thr_g, const uint2 *lut,
+                                                                    unsigned long long *mismatch)
 {
-    __shared__ float s_thr[256];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_LUT_END + 16 + 1024];
+    float *s_thr = reinterpret_cast<float *>(smem + ((LDS_LUT_END + 15) & ~15));
+    uint2 *s_lut = reinterpret_cast<uint2 *>(smem + LDS_LUT0);
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_thr[i] = thr_g[i];
+    for (int i = threadIdx.x; i < SSDR_LUT_N; i += blockDim.x) s_lut[i] = lut[i];
     __syncthreads();
     unsigned long long bad = 0;
+    const uint32_t mask_fff8 = (SSDR_LUT_BITS == 4) ? 0xFFF8u : ~7u;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < 0x7F800000ull; u += stride) {
         const float p = __uint_as_float((uint32_t)u);
@@ -334,7 +379,7 @@ __global__ void ssdr_quant_selftest_kernel(const float *thr_g, unsigned long lon
             const int mid = (lo + hi + 1) >> 1;
             if (s_thr[mid] <= p) lo = mid; else hi = mid - 1;
         }
-        bad += (ssdr_quantise(p, s_thr) != lo);
+        bad += (quantise(p, smem, mask_fff8) != (uint32_t)lo);
     }
     if (bad) atomicAdd(mismatch, bad);
 }
@@ -360,8 +405,8 @@ hipError_t ssdr_wf_blocks_per_cu(int *blocks)
     return hipSuccess;
 }
 
-hipError_t ssdr_launch_quant_selftest(const float *thr, unsigned long long *mismatch, hipStream_t stream)
+hipError_t ssdr_launch_quant_selftest(const float *thr, const uint2 *lut, unsigned long long *mismatch, hipStream_t stream)
 {
-    hipLaunchKernelGGL(ssdr_quant_selftest_kernel, dim3(2048), dim3(256), 0, stream, thr, mismatch);
+    hipLaunchKernelGGL(ssdr_quant_selftest_kernel, dim3(2048), dim3(256), 0, stream, thr, lut, mismatch);
     return hipGetLastError();
 }

@@ -30,6 +30,21 @@ __global__ void k(float *out, int iters)
                 if (KIND == 9) asm volatile("v_lshlrev_b32 %0, 2, %0" : "+v"(a[i].x));
                 if (KIND == 10) asm volatile("v_floor_f32 %0, %0" : "+v"(a[i].x));
                 if (KIND == 11) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "s"(b), "v"(c));
+                if (KIND == 12) asm volatile("v_cmp_ge_f32 vcc, %0, %1\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(a[i].x) : "v"(b.x) : "vcc");
+                if (KIND == 13) asm volatile("v_cmp_ge_f32 vcc, %0, %1" : : "v"(a[i].x), "v"(b.x) : "vcc");
+                if (KIND == 14) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i].x) : "v"(b.x));
+                if (KIND == 15) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i].x) : "v"(b.x));
+                if (KIND == 16) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(a[i].x) : "v"(b.x));
+                if (KIND == 17) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
+                if (KIND == 18) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i].x) : "v"(b.x));
+                if (KIND == 19) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a[i].x));
+                if (KIND == 20) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i].x) : "v"(b.x) : "vcc");
+                if (KIND == 21) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i].x));
+                if (KIND == 22) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i].x));
+                if (KIND == 23) asm volatile("v_bfe_u32 %0, %0, 21, 11" : "+v"(a[i].x));
+                if (KIND == 24) asm volatile("v_sub_f32 %0, %0, %1\n v_mul_f32 %0, %0, %2 clamp" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
+                if (KIND == 25) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
+                if (KIND == 26) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
             }
         }
     }
@@ -42,7 +57,7 @@ template <int KIND>
 void run(const char *name, float *d)
 {
     int cus = 256;
-    for (int wpe : {1, 2, 4, 8}) {
+    for (int wpe : {2, 4}) {
         int threads = 256, blocks = cus * wpe;            // wpe waves per SIMD
         hipEvent_t e0, e1;
         hipEventCreate(&e0); hipEventCreate(&e1);
@@ -74,5 +89,20 @@ int main()
     run<8>("v_med3_i32", d);
     run<9>("v_lshlrev_b32", d);
     run<10>("v_floor_f32", d);
+    run<12>("v_cmp_ge_f32 + v_addc (2 instr)", d);
+    run<13>("v_cmp_ge_f32", d);
+    run<14>("v_add_u32", d);
+    run<15>("v_and_b32", d);
+    run<16>("v_lshl_add_u32", d);
+    run<17>("v_med3_f32", d);
+    run<18>("v_max_f32", d);
+    run<19>("v_cvt_i32_f32", d);
+    run<20>("v_cndmask_b32", d);
+    run<21>("v_sqrt_f32", d);
+    run<22>("v_rcp_f32", d);
+    run<23>("v_bfe_u32", d);
+    run<24>("v_sub_f32 + v_mul_f32 clamp (2 instr)", d);
+    run<25>("v_perm_b32", d);
+    run<26>("v_mad_u32_u24", d);
     return 0;
 }
