@@ -269,6 +269,42 @@ typedef struct {
     uint32_t pad[2];
 } twin_state;               /* 64 bytes */
 
+/* NCO step phasor cos/sin(2 pi dphi / 2^32): 20-bit evaluation + first-order term for the low 12 bits */
+static void step_phasor(uint32_t dphi, float *c, float *s)
+{
+    const float C_2PI_32 = 0x1.921fb6p-30f;         /* float32(2*pi/2^32) */
+    float c20, s20;
+    sincos20(dphi, &c20, &s20);
+    float eps = (float)(dphi & 0xFFFu) * C_2PI_32;
+    *c = fmaf(-s20, eps, c20);
+    *s = fmaf(c20, eps, s20);
+}
+
+/* block NCO: phasor of sample j of an 8-sample block = P20(block-start phase) * S^j */
+static void mix8(const int16_t *x /*[8][2]*/, uint32_t phase0, float cs, float ss, float *zr, float *zi)
+{
+    float c, s;
+    sincos20(phase0, &c, &s);
+    for (int j = 0; j < 8; j++) {
+        float xr = (float)x[2 * j], xi = (float)x[2 * j + 1];
+        zr[j] = fmaf(xr, c, xi * s);
+        zi[j] = fmaf(xi, c, -(xr * s));
+        float cn = fmaf(c, cs, -(s * ss)), sn = fmaf(s, cs, c * ss);
+        c = cn; s = sn;
+    }
+}
+
+/* The 64-lane inclusive scan "as the machine does it": Kogge-Stone inside each row of 16 lanes
+ * (distances 1, 2, 4, 8), then lane 15 of rows 0/2 into every lane of rows 1/3, then lane 31 into
+ * every lane of rows 2 and 3.  scan_src(step, lane) = source lane, or -1 if the lane sits out
+ * (it then combines with the identity, which leaves its value unchanged exactly). */
+static int scan_src(int step, int l)
+{
+    if (step < 4) { int d = 1 << step; return ((l & 15) >= d) ? l - d : -1; }
+    if (step == 4) return (((l >> 4) & 1) == 1) ? (l & ~15) - 1 : -1;
+    return (l >= 32) ? 31 : -1;
+}
+
 static const float DC_A = 0.9921875f, DC_AL = 0.0078125f;
 /* float32((127/128)^(j+1)), j = 0..7 */
 static const float DC_APOW[8] = { 0x1.fcp-1f, 0x1.f808p-1f, 0x1.f417fp-1f, 0x1.f02fcp-1f,
@@ -281,13 +317,13 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
 {
     static _Thread_local float z1r[HIST + FRAME], z1i[HIST + FRAME];
     float z2r[FRAME], z2i[FRAME], p[FRAME], aud[FRAME];
-    /* 1. NCO mix of history + frame */
-    for (int i = -HIST; i < FRAME; i++) {
-        const int16_t *s = (i < 0) ? hist + 2 * (HIST + i) : iq + 2 * i;
-        float xr = (float)s[0], xi = (float)s[1], co, si;
-        sincos20(st->phi1 + (uint32_t)i * c->dphi1, &co, &si);
-        z1r[HIST + i] = fmaf(xr, co, xi * si);
-        z1i[HIST + i] = fmaf(xi, co, -(xr * si));
+    /* 1. block NCO mix of history + frame (the history blocks are the last 16 blocks of the previous frame) */
+    float cs1, ss1, cs2, ss2;
+    step_phasor(c->dphi1, &cs1, &ss1);
+    step_phasor(c->dphi2, &cs2, &ss2);
+    for (int b = -HIST / 8; b < FRAME / 8; b++) {
+        const int16_t *x = (b < 0) ? hist + 2 * (HIST + 8 * b) : iq + 2 * 8 * b;
+        mix8(x, st->phi1 + (uint32_t)(8 * b) * c->dphi1, cs1, ss1, z1r + HIST + 8 * b, z1i + HIST + 8 * b);
     }
     /* 2. FIR, taps ascending, fma chain from zero */
     for (int n = 0; n < FRAME; n++) {
@@ -308,15 +344,17 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
             for (int j = 0; j < 8; j++) { s = fmaf(DC_A, s, DC_AL * env[8 * l + j]); loc[l][j] = s; }
             B[l] = s; A[l] = DC_APOW[7];
         }
-        for (int d = 1; d < NLANE; d <<= 1) {       /* Kogge-Stone over lanes */
+        for (int step = 0; step < 6; step++) {      /* affine maps m -> A m + B, composed lane after source */
             for (int l = 0; l < NLANE; l++) {
-                if (l >= d) { Bn[l] = fmaf(A[l], B[l - d], B[l]); An[l] = A[l] * A[l - d]; }
-                else { Bn[l] = B[l]; An[l] = A[l]; }
+                int src = scan_src(step, l);
+                float Al = (src < 0) ? 1.0f : A[src], Bl = (src < 0) ? 0.0f : B[src];
+                Bn[l] = fmaf(A[l], Bl, B[l]);
+                An[l] = A[l] * Al;
             }
             memcpy(A, An, sizeof A); memcpy(B, Bn, sizeof B);
         }
         for (int l = 0; l < NLANE; l++) {
-            float carry = (l == 0) ? st->dc : fmaf(A[l - 1], st->dc, B[l - 1]);
+            float carry = (l == 0) ? fmaf(1.0f, st->dc, 0.0f) : fmaf(A[l - 1], st->dc, B[l - 1]);
             for (int j = 0; j < 8; j++) {
                 float m = fmaf(DC_APOW[j], carry, loc[l][j]);
                 aud[8 * l + j] = env[8 * l + j] - m;
@@ -324,10 +362,15 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
             }
         }
     } else if (c->mode <= 3) {
-        for (int n = 0; n < FRAME; n++) {
+        for (int b = 0; b < FRAME / 8; b++) {
             float co, si;
-            sincos20(st->phi2 + (uint32_t)n * c->dphi2, &co, &si);
-            aud[n] = fmaf(z2r[n], co, -(z2i[n] * si));
+            sincos20(st->phi2 + (uint32_t)(8 * b) * c->dphi2, &co, &si);
+            for (int j = 0; j < 8; j++) {
+                int n = 8 * b + j;
+                aud[n] = fmaf(z2r[n], co, -(z2i[n] * si));
+                float cn = fmaf(co, cs2, -(si * ss2)), sn = fmaf(si, cs2, co * ss2);
+                co = cn; si = sn;
+            }
         }
     } else {
         float pr = st->prev_re, pi = st->prev_im;
@@ -377,13 +420,16 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
             pcm[8 * l + j] = (int16_t)(int32_t)y;
         }
     }
-    /* 5. rssi: xor-butterfly sum over lanes */
-    for (int d = 32; d >= 1; d >>= 1) {
+    /* 5. rssi: inclusive sum scan over lanes (same six steps), total = lane 63 */
+    for (int step = 0; step < 6; step++) {
         float t[NLANE];
-        for (int l = 0; l < NLANE; l++) t[l] = psum[l] + psum[l ^ d];
+        for (int l = 0; l < NLANE; l++) {
+            int src = scan_src(step, l);
+            t[l] = psum[l] + ((src < 0) ? 0.0f : psum[src]);
+        }
         memcpy(psum, t, sizeof t);
     }
-    *rssi = fmaf(log2p(fmaxf(psum[0], 1e-20f)) - 39.0f, 0x1.815182p+1f /* 10*log10(2) */, c->smeter_cal_db);
+    *rssi = fmaf(log2p(fmaxf(psum[NLANE - 1], 1e-20f)) - 39.0f, 0x1.815182p+1f /* 10*log10(2) */, c->smeter_cal_db);
     /* 6. state carry */
     st->phi1 += (uint32_t)FRAME * c->dphi1;
     st->phi2 += (uint32_t)FRAME * c->dphi2;

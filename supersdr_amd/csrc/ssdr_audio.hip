@@ -16,9 +16,10 @@
 //   * the mixed samples go to LDS once (80 B lane stride: ds_write_b128/ds_read_b128
 //     conflict-free); the FIR walks a 16-sample register window per 8-tap block, taps
 //     come through the scalar cache (wave-uniform), 128 FMAs per 4 LDS reads
-//   * the recurrences along time are exact or order-defined scans across lanes:
-//     AM DC block = affine Kogge-Stone scan, AGC envelope = (max,+) prefix max (exact),
-//     RSSI = xor-butterfly sum
+//   * the NCO is a block NCO: one polynomial sincos per 8 samples, complex rotations in between
+//   * the recurrences along time are exact or order-defined scans across lanes, done with DPP
+//     (row_shr / row_bcast / wave_shr: no LDS, no address arithmetic): AM DC block = affine scan,
+//     AGC envelope = (max,+) prefix max (exact), RSSI = sum scan
 //   * store: 8 int16 = 16 B per lane, 1 KB contiguous per wave
 #include "ssdr_math.h"
 #include "ssdr_kernels.h"
@@ -28,6 +29,7 @@ namespace {
 constexpr int OCT = 10;                         // LDS slots (float2) per 8 samples: 8 + 2 pad
 constexpr int NOCT = (SSDR_HIST + SSDR_FRAME) / 8;   // 80 octets
 constexpr int HOCT = SSDR_HIST / 8;             // 16 history octets
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 SSDR_DEV void lds_sync()
 {
@@ -36,13 +38,68 @@ SSDR_DEV void lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-SSDR_DEV float2 mix(uint32_t raw, uint32_t phase)
+// ---- cross-lane primitives: DPP, no LDS traffic and no address arithmetic.
+// dpp<CTRL, ROWMASK>(identity, x): lanes whose source is out of range or masked off receive `identity`.
+template <int CTRL, int ROWMASK>
+SSDR_DEV float dpp(float identity, float x)
 {
-    const float xr = (float)(int16_t)(raw & 0xFFFFu);
-    const float xi = (float)((int32_t)raw >> 16);
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(x), CTRL, ROWMASK, 0xF, false));
+}
+SSDR_DEV float lane63(float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63)); }
+SSDR_DEV float from_prev_lane(float lane0_value, float x) { return dpp<0x138, 0xF>(lane0_value, x); }   // wave_shr:1
+
+// Inclusive scan over the 64 lanes in six steps: Kogge-Stone inside each row of 16 (row_shr 1,2,4,8),
+// then lane 15 of rows 0/2 into rows 1/3 (row_bcast:15), then lane 31 into rows 2,3 (row_bcast:31).
+// STEP(ctrl, rowmask) is expanded once per step; the twin walks the same six steps.
+#define SSDR_SCAN6(STEP) STEP(0x111, 0xF) STEP(0x112, 0xF) STEP(0x114, 0xF) STEP(0x118, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
+
+SSDR_DEV float scan_max(float x)
+{
+#define STEP(C, M) x = fmaxf(x, dpp<C, M>(x, x));
+    SSDR_SCAN6(STEP)
+#undef STEP
+    return x;
+}
+SSDR_DEV float scan_sum(float x)
+{
+#define STEP(C, M) x = x + dpp<C, M>(0.0f, x);
+    SSDR_SCAN6(STEP)
+#undef STEP
+    return x;
+}
+// affine maps m -> A m + B: (A, B) of a lane := (A, B) of the lane composed after its source's
+SSDR_DEV void scan_affine(float &A, float &B)
+{
+#define STEP(C, M) { const float Al = dpp<C, M>(1.0f, A), Bl = dpp<C, M>(0.0f, B); B = fmaf(A, Bl, B); A = A * Al; }
+    SSDR_SCAN6(STEP)
+#undef STEP
+}
+
+// cos/sin of 2 pi dphi / 2^32 for the per-channel NCO step: 20-bit table-free evaluation plus the
+// first-order term for the 12 bits below it (|eps| < 6e-6, eps^2/2 < 2e-11).
+SSDR_DEV void step_phasor(uint32_t dphi, float &c, float &s)
+{
+    float c20, s20;
+    ssdr_sincos20(dphi, c20, s20);
+    const float eps = (float)(dphi & 0xFFFu) * SSDR_C_2PI_32;
+    c = fmaf(-s20, eps, c20);
+    s = fmaf(c20, eps, s20);
+}
+
+// Block NCO: the phasor of sample j of an 8-sample block is P20(phase of the block start) * S^j.
+// One polynomial sincos per 8 samples, a complex rotation (4 full-rate ops) for each of the others.
+SSDR_DEV void mix8(const uint32_t (&rw)[8], uint32_t phase0, float cs, float ss, float2 (&z)[8])
+{
     float c, s;
-    ssdr_sincos20(phase, c, s);
-    return make_float2(fmaf(xr, c, xi * s), fmaf(xi, c, -(xr * s)));
+    ssdr_sincos20(phase0, c, s);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float xr = (float)(int16_t)(rw[j] & 0xFFFFu);
+        const float xi = (float)((int32_t)rw[j] >> 16);
+        z[j] = make_float2(fmaf(xr, c, xi * s), fmaf(xi, c, -(xr * s)));          // x * (c - j s)
+        const float cn = fmaf(c, cs, -(s * ss)), sn = fmaf(s, cs, c * ss);
+        c = cn; s = sn;
+    }
 }
 
 SSDR_DEV void load_oct(const float2 *z, int q, float2 (&v)[8])
@@ -63,6 +120,21 @@ SSDR_DEV void store_oct(float2 *z, int q, const float2 (&v)[8])
     for (int i = 0; i < 4; i++) p[i] = make_float4(v[2 * i].x, v[2 * i].y, v[2 * i + 1].x, v[2 * i + 1].y);
 }
 
+// taps [k0, k0 + NK) of the FIR against the 16-sample register window (A = newer octet, B = older)
+template <int K0, int NK>
+SSDR_DEV void fir_taps(const float *h, const float2 (&A)[8], const float2 (&B)[8], float (&yr)[8], float (&yi)[8])
+{
+#pragma unroll
+    for (int kk = K0; kk < K0 + NK; kk++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const float2 v = (j - kk >= 0) ? A[(j - kk) & 7] : B[(8 + j - kk) & 7];
+            yr[j] = fmaf(h[kk], v.x, yr[j]);
+            yi[j] = fmaf(h[kk], v.y, yi[j]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioArgs a)
 {
     __shared__ __attribute__((aligned(16))) float2 s_z[NOCT * OCT];      // 6400 B
@@ -73,12 +145,17 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
     if (ch >= a.n_ch) return;
 
     const ssdr_chan_consts &kc = a.consts[ch];
-    const uint32_t mode = kc.mode, nblk = kc.ntap8 >> 3;
+    const uint32_t mode = kc.mode;
+    const uint32_t n4 = (kc.ntap + 3) >> 2;              // taps beyond ntap are zero: fma(0, z, acc) == acc exactly,
+    const uint32_t nblk = n4 >> 1, half_blk = n4 & 1;    // so the FIR stops at the next multiple of 4, not of 8
     const uint32_t dphi1 = kc.dphi1, dphi2 = kc.dphi2;
     const float c0 = kc.agc_c0, c1 = kc.agc_c1, knee = kc.agc_knee, d8 = kc.agc_delta8;
     const uint32_t K = kc.hang_frames;
     const float cal = kc.smeter_cal_db;
     const float *taps = a.taps + (size_t)ch * SSDR_NTAP_MAX;
+    float cs1, ss1, cs2, ss2;
+    step_phasor(dphi1, cs1, ss1);
+    step_phasor(dphi2, cs2, ss2);
 
     ssdr_chan_state st = a.state[ch];
     uint32_t phi1 = st.phi1, phi2 = st.phi2;
@@ -87,33 +164,30 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
 #pragma unroll
     for (int i = 0; i < 8; i++) agc_m[i] = st.agc_m[i];
 
-    // history z1[-128..-1] from the raw tail kept in HBM: 2 samples per lane
-    {
-        const uint2 hr = reinterpret_cast<const uint2 *>(a.hist + (size_t)ch * SSDR_HIST)[l];
-        const int i0 = -SSDR_HIST + 2 * l;
-        const float2 z0 = mix(hr.x, phi1 + (uint32_t)i0 * dphi1);
-        const float2 z1 = mix(hr.y, phi1 + (uint32_t)(i0 + 1) * dphi1);
-        const int s = 2 * l;                                   // slot index s = i + 128
-        *reinterpret_cast<float4 *>(&s_z[(s >> 3) * OCT + (s & 7)]) = make_float4(z0.x, z0.y, z1.x, z1.y);
+    // history z1[-128..-1]: re-mix the raw tail kept in HBM exactly as the previous frame mixed it
+    // (block t of the tail was block 48+t of that frame): lanes 0..15, one octet each
+    if (l < HOCT) {
+        const uint4 *hp = reinterpret_cast<const uint4 *>(a.hist + (size_t)ch * SSDR_HIST + 8 * l);
+        const uint4 h0 = hp[0], h1 = hp[1];
+        const uint32_t rw[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+        float2 H[8];
+        mix8(rw, phi1 - (uint32_t)(SSDR_HIST - 8 * l) * dphi1, cs1, ss1, H);
+        store_oct(s_z, l, H);
     }
 
     const uint32_t *src = a.iq + (uint64_t)ch * a.ch_stride + 8 * l;
     int16_t *dst = a.pcm + (uint64_t)ch * a.n_frames * SSDR_FRAME + 8 * l;
-    uint4 raw0, raw1;
+    u32x4 raw0, raw1;
 
     for (uint32_t f = 0; f < a.n_frames; f++, src += SSDR_FRAME, dst += SSDR_FRAME) {
-        raw0 = reinterpret_cast<const uint4 *>(src)[0];
-        raw1 = reinterpret_cast<const uint4 *>(src)[1];
+        raw0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src));
+        raw1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src) + 1);
         const uint32_t rw[8] = {raw0.x, raw0.y, raw0.z, raw0.w, raw1.x, raw1.y, raw1.z, raw1.w};
 
         // 1. NCO mix of this lane's 8 samples -> LDS
         float2 A[8], B[8];
-        {
-            const uint32_t ph0 = phi1 + (uint32_t)(8 * l) * dphi1;
-#pragma unroll
-            for (int j = 0; j < 8; j++) A[j] = mix(rw[j], ph0 + (uint32_t)j * dphi1);
-            store_oct(s_z, HOCT + l, A);
-        }
+        mix8(rw, phi1 + (uint32_t)(8 * l) * dphi1, cs1, ss1, A);
+        store_oct(s_z, HOCT + l, A);
         lds_sync();
 
         // 2. FIR: y[n] = sum_k h[k] z1[n-k], k ascending, fma chain from zero
@@ -125,17 +199,16 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
             float h[8];
 #pragma unroll
             for (int kk = 0; kk < 8; kk++) h[kk] = taps[8 * b + kk];
-#pragma unroll
-            for (int kk = 0; kk < 8; kk++) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    const float2 v = (j - kk >= 0) ? A[(j - kk) & 7] : B[(8 + j - kk) & 7];
-                    yr[j] = fmaf(h[kk], v.x, yr[j]);
-                    yi[j] = fmaf(h[kk], v.y, yi[j]);
-                }
-            }
+            fir_taps<0, 8>(h, A, B, yr, yi);
 #pragma unroll
             for (int j = 0; j < 8; j++) A[j] = B[j];
+        }
+        if (half_blk) {
+            load_oct(s_z, HOCT + l - 1 - (int)nblk, B);
+            float h[8];
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) h[kk] = taps[8 * nblk + kk];
+            fir_taps<0, 4>(h, A, B, yr, yi);
         }
 
         // 3. power, demodulation
@@ -152,33 +225,28 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
                 s = fmaf(SSDR_DC_A, s, SSDR_DC_AL * env[j]);
                 loc[j] = s;
             }
-            // inclusive Kogge-Stone scan of the affine maps m -> A*m + B over lanes
-            float Asc = DC_APOW[7], Bsc = s;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const float Ap = __shfl_up(Asc, d, 64), Bp = __shfl_up(Bsc, d, 64);
-                if (l >= d) { Bsc = fmaf(Asc, Bp, Bsc); Asc = Asc * Ap; }
-            }
-            const float Ae = __shfl_up(Asc, 1, 64), Be = __shfl_up(Bsc, 1, 64);
-            const float carry = (l == 0) ? dc : fmaf(Ae, dc, Be);
+            float Asc = DC_APOW[7], Bsc = s;                 // this lane's 8 samples as the map m -> A m + B
+            scan_affine(Asc, Bsc);
+            const float Ae = from_prev_lane(1.0f, Asc), Be = from_prev_lane(0.0f, Bsc);
+            const float carry = fmaf(Ae, dc, Be);            // lane 0: identity map -> dc
             float m = 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 m = fmaf(DC_APOW[j], carry, loc[j]);
                 aud[j] = env[j] - m;
             }
-            dc = __shfl(m, 63, 64);
+            dc = lane63(m);
         } else if (mode <= SSDR_MODE_CW) {
-            const uint32_t ph0 = phi2 + (uint32_t)(8 * l) * dphi2;
+            float c, s;
+            ssdr_sincos20(phi2 + (uint32_t)(8 * l) * dphi2, c, s);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                float c, s;
-                ssdr_sincos20(ph0 + (uint32_t)j * dphi2, c, s);
-                aud[j] = fmaf(yr[j], c, -(yi[j] * s));
+                aud[j] = fmaf(yr[j], c, -(yi[j] * s));       // Re{y * (c + j s)}
+                const float cn = fmaf(c, cs2, -(s * ss2)), sn = fmaf(s, cs2, c * ss2);
+                c = cn; s = sn;
             }
         } else {
-            float pr = __shfl_up(yr[7], 1, 64), pi = __shfl_up(yi[7], 1, 64);
-            if (l == 0) { pr = prev_re; pi = prev_im; }
+            float pr = from_prev_lane(prev_re, yr[7]), pi = from_prev_lane(prev_im, yi[7]);
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 const float dr = fmaf(yr[j], pr, yi[j] * pi);
@@ -187,8 +255,8 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
                 pr = yr[j]; pi = yi[j];
             }
         }
-        prev_re = __shfl(yr[7], 63, 64);
-        prev_im = __shfl(yi[7], 63, 64);
+        prev_re = lane63(yr[7]);
+        prev_im = lane63(yi[7]);
 
         // 4. AGC: block peak -> log2 -> (max,+) follower across lanes -> gain
         float pm = p[0], ps = p[0];
@@ -198,21 +266,11 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
         const float fl = (float)l;
         float e;
         if (K == 0) {
-            float P = fmaf(fl, d8, al);
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const float t = __shfl_up(P, d, 64);
-                if (l >= d) P = fmaxf(P, t);
-            }
+            const float P = scan_max(fmaf(fl, d8, al));
             e = fmaxf(fmaf(-fl, d8, P), fmaf(-(fl + 1.0f), d8, agc_d));
-            agc_d = __shfl(e, 63, 64);
+            agc_d = lane63(e);
         } else {
-            float P = al;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const float t = __shfl_up(P, d, 64);
-                if (l >= d) P = fmaxf(P, t);
-            }
+            const float P = scan_max(al);
             float maxM = agc_m[0], mK = agc_m[0];
 #pragma unroll
             for (int i = 1; i < 8; i++)
@@ -221,27 +279,25 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
             agc_d = fmaxf(fmaf(-64.0f, d8, agc_d), mK);
 #pragma unroll
             for (int i = 7; i > 0; i--) agc_m[i] = agc_m[i - 1];
-            agc_m[0] = __shfl(P, 63, 64);
+            agc_m[0] = lane63(P);
         }
         const float g = ssdr_exp2p(fmaf(c1, fmaxf(e, knee), c0));
 
         // 5. round-half-even, saturate, pack 8 x int16 = 16 B, store
-        uint32_t w[4];
+        u32x4 w;
 #pragma unroll
         for (int j = 0; j < 8; j += 2) {
-            float y0 = rintf(aud[j] * g), y1 = rintf(aud[j + 1] * g);
-            y0 = fminf(fmaxf(y0, -32768.0f), 32767.0f);
-            y1 = fminf(fmaxf(y1, -32768.0f), 32767.0f);
-            w[j >> 1] = ((uint32_t)(int32_t)y0 & 0xFFFFu) | ((uint32_t)(int32_t)y1 << 16);
+            // v_cvt_i32_f32 saturates, v_cvt_pk_i16_i32 saturates again to int16: same as clamp(rint(y))
+            const int i0 = __float2int_rn(aud[j] * g), i1 = __float2int_rn(aud[j + 1] * g);
+            w[j >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(i0, i1));
         }
-        *reinterpret_cast<uint4 *>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
+        __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(dst));
 
-        // 6. RSSI
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) ps = ps + __shfl_xor(ps, d, 64);
+        // 6. RSSI: sum over the frame = last lane of the inclusive sum scan
+        const float tot = lane63(scan_sum(ps));
         if (l == 0)
             a.rssi[(uint64_t)ch * a.n_frames + f] =
-                fmaf(ssdr_log2p(fmaxf(ps, 1e-20f)) - 39.0f, SSDR_DB_PER_LOG2, cal);
+                fmaf(ssdr_log2p(fmaxf(tot, 1e-20f)) - 39.0f, SSDR_DB_PER_LOG2, cal);
 
         // 7. carry: phases advance one frame; the frame tail becomes the FIR history
         phi1 += (uint32_t)SSDR_FRAME * dphi1;
@@ -257,7 +313,7 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
     // state back to HBM (raw tail of the last frame: lanes 48..63 hold it)
     if (a.n_frames) {
         if (l >= 64 - HOCT) {
-            uint4 *hp = reinterpret_cast<uint4 *>(a.hist + (size_t)ch * SSDR_HIST + 8 * (l - (64 - HOCT)));
+            u32x4 *hp = reinterpret_cast<u32x4 *>(a.hist + (size_t)ch * SSDR_HIST + 8 * (l - (64 - HOCT)));
             hp[0] = raw0;
             hp[1] = raw1;
         }
