@@ -143,6 +143,7 @@ int ssdr_get_consts(ssdr_ctx *ctx, uint32_t first, uint32_t count, ssdr_chan_con
 int ssdr_get_state(ssdr_ctx *ctx, uint32_t first, uint32_t count, ssdr_chan_state *state, int16_t *hist);
 int ssdr_set_state(ssdr_ctx *ctx, uint32_t first, uint32_t count, const ssdr_chan_state *state, const int16_t *hist);
 int ssdr_selftest_quantiser(ssdr_ctx *ctx, uint64_t *mismatches);   /* all positive floats vs binary search */
+int ssdr_selftest_sqrt(ssdr_ctx *ctx, uint64_t *mismatches);        /* AM envelope sqrt vs IEEE sqrtf, all normal floats */
 
 const char *ssdr_strerror(int code);
 const char *ssdr_last_hip_error(void);

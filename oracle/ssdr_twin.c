@@ -109,7 +109,7 @@ static float atan2p(float y, float x)
     float ax = fabsf(x), ay = fabsf(y);
     float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
     if (mx == 0.0f) return 0.0f;
-    float t = mn / mx;
+    float t = mn / fmaxf(mx, 1e-30f);
     float u = t, off = 0.0f;
     if (t > 0.41421356237f) { u = (t - 1.0f) / (t + 1.0f); off = PI_4; }
     float z = u * u;

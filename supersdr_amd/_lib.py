@@ -66,6 +66,7 @@ _SIGS = {
     "ssdr_get_state": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
     "ssdr_set_state": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
     "ssdr_selftest_quantiser": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "ssdr_selftest_sqrt": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ssdr_strerror": (C.c_char_p, [C.c_int]),
     "ssdr_last_hip_error": (C.c_char_p, []),
     "ssdr_version": (C.c_char_p, []),

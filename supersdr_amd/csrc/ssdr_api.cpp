@@ -566,4 +566,17 @@ int ssdr_selftest_quantiser(ssdr_ctx *c, uint64_t *mismatches)
     return SSDR_OK;
 }
 
+int ssdr_selftest_sqrt(ssdr_ctx *c, uint64_t *mismatches)
+{
+    if (!c || !mismatches) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->d_scratch, 0, 8, c->stream));
+    HIP_TRY(ssdr_launch_sqrt_selftest(c->d_scratch, c->stream));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, c->d_scratch, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *mismatches = v;
+    return SSDR_OK;
+}
+
 } // extern "C"

@@ -45,6 +45,13 @@ SSDR_DEV float dpp(float identity, float x)
 {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(x), CTRL, ROWMASK, 0xF, false));
 }
+// fmaxf() makes the compiler quiet signalling NaNs first (an extra v_max per operand); none can occur here
+SSDR_DEV float vmax(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 SSDR_DEV float lane63(float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63)); }
 SSDR_DEV float from_prev_lane(float lane0_value, float x) { return dpp<0x138, 0xF>(lane0_value, x); }   // wave_shr:1
 
@@ -55,7 +62,7 @@ SSDR_DEV float from_prev_lane(float lane0_value, float x) { return dpp<0x138, 0x
 
 SSDR_DEV float scan_max(float x)
 {
-#define STEP(C, M) x = fmaxf(x, dpp<C, M>(x, x));
+#define STEP(C, M) x = vmax(x, dpp<C, M>(x, x));
     SSDR_SCAN6(STEP)
 #undef STEP
     return x;
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
             float s = 0.0f;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                env[j] = sqrtf(p[j]);
+                env[j] = ssdr_sqrt_rn(p[j]);
                 s = fmaf(SSDR_DC_A, s, SSDR_DC_AL * env[j]);
                 loc[j] = s;
             }
@@ -261,13 +268,13 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
         // 4. AGC: block peak -> log2 -> (max,+) follower across lanes -> gain
         float pm = p[0], ps = p[0];
 #pragma unroll
-        for (int j = 1; j < 8; j++) { pm = fmaxf(pm, p[j]); ps = ps + p[j]; }
-        const float al = ssdr_log2p(fmaxf(pm, SSDR_P_FLOOR));
+        for (int j = 1; j < 8; j++) { pm = vmax(pm, p[j]); ps = ps + p[j]; }
+        const float al = ssdr_log2p(vmax(pm, SSDR_P_FLOOR));
         const float fl = (float)l;
         float e;
         if (K == 0) {
             const float P = scan_max(fmaf(fl, d8, al));
-            e = fmaxf(fmaf(-fl, d8, P), fmaf(-(fl + 1.0f), d8, agc_d));
+            e = vmax(fmaf(-fl, d8, P), fmaf(-(fl + 1.0f), d8, agc_d));
             agc_d = lane63(e);
         } else {
             const float P = scan_max(al);
@@ -275,13 +282,13 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
 #pragma unroll
             for (int i = 1; i < 8; i++)
                 if ((uint32_t)i < K) { maxM = fmaxf(maxM, agc_m[i]); mK = agc_m[i]; }
-            e = fmaxf(fmaxf(P, maxM), fmaf(-(fl + 1.0f), d8, agc_d));
+            e = vmax(vmax(P, maxM), fmaf(-(fl + 1.0f), d8, agc_d));
             agc_d = fmaxf(fmaf(-64.0f, d8, agc_d), mK);
 #pragma unroll
             for (int i = 7; i > 0; i--) agc_m[i] = agc_m[i - 1];
             agc_m[0] = lane63(P);
         }
-        const float g = ssdr_exp2p(fmaf(c1, fmaxf(e, knee), c0));
+        const float g = ssdr_exp2p(fmaf(c1, vmax(e, knee), c0));
 
         // 5. round-half-even, saturate, pack 8 x int16 = 16 B, store
         u32x4 w;
@@ -374,7 +381,27 @@ __global__ __launch_bounds__(256) void ssdr_synth_kernel(SsdrSynthArgs a)
     }
 }
 
+// exhaustive check of ssdr_sqrt_rn against the compiler's IEEE sqrtf over its whole domain [0, 2^62)
+__global__ void ssdr_sqrt_selftest_kernel(unsigned long long *mismatch)
+{
+    unsigned long long bad = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    // every float from the smallest denormal up to 2^62 (the documented domain)
+    for (uint64_t u = 1ull + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < 0x5E800000ull; u += stride) {
+        const float p = __uint_as_float((uint32_t)u);
+        bad += (__float_as_uint(ssdr_sqrt_rn(p)) != __float_as_uint(sqrtf(p)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) bad += (__float_as_uint(ssdr_sqrt_rn(0.0f)) != 0u);
+    if (bad) atomicAdd(mismatch, bad);
+}
+
 } // namespace
+
+hipError_t ssdr_launch_sqrt_selftest(unsigned long long *mismatch, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ssdr_sqrt_selftest_kernel, dim3(2048), dim3(256), 0, stream, mismatch);
+    return hipGetLastError();
+}
 
 hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, hipStream_t stream)
 {

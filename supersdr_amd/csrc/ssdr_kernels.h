@@ -67,6 +67,7 @@ hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream
 hipError_t ssdr_wf_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_synth(const SsdrSynthArgs &a, hipStream_t stream);
+hipError_t ssdr_launch_sqrt_selftest(unsigned long long *mismatch, hipStream_t stream);
 hipError_t ssdr_launch_quant_selftest(const float *thr, const uint2 *lut, unsigned long long *mismatch, hipStream_t stream);
 
 // host-side tables and parameter compilation (ssdr_tables.cpp)

@@ -78,7 +78,7 @@ SSDR_DEV float ssdr_atan2p(float y, float x)
     const float PI_4 = 0.78539816339744831f, PI_2 = 1.5707963267948966f, PI_1 = 3.14159265358979323f;
     float ax = fabsf(x), ay = fabsf(y);
     float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    float t = mn / mx;
+    float t = mn / fmaxf(mx, 1e-30f);            // no 0/0: mx == 0 returns 0 below
     float u = t, off = 0.0f;
     if (t > 0.41421356237f) { u = (t - 1.0f) / (t + 1.0f); off = PI_4; }
     float z = u * u;
@@ -92,14 +92,18 @@ SSDR_DEV float ssdr_atan2p(float y, float x)
     return (mx == 0.0f) ? 0.0f : r;
 }
 
-// dB quantiser: byte = #{k in 1..255 : T[k] <= p}.  The float's own bit pattern is a
-// piecewise-linear log2: y = bits*QA + QB never exceeds the true position and is at
-// most 0.26+margin below it, so floor(y) is the answer or one less; one compare
-// against the threshold table (LDS) settles it.  No log, exact by construction.
-SSDR_DEV int ssdr_quantise(float p, const float *thr)
+// Correctly rounded sqrt for 0 <= p < 2^62 (what |z|^2 can be): the hardware estimate (v_sqrt_f32,
+// <= 1 ulp) is settled by the sign of two exact residuals, fma(-s', s, p) for the neighbours
+// s' = s -/+ 1 ulp -- the compiler's own IEEE scheme, but instead of its compare/select denormal
+// pre-scaling the argument is always scaled by 2^64 (exact) so the residuals cannot underflow.
+// Identical to sqrtf() bit for bit (checked exhaustively on the GPU by ssdr_selftest_sqrt).
+SSDR_DEV float ssdr_sqrt_rn(float p)
 {
-    float y = fmaf((float)(int32_t)__float_as_uint(p), SSDR_QA, SSDR_QB);
-    int k = (int)floorf(y);
-    k = min(max(k, 0), 254);
-    return k + ((p >= thr[k + 1]) ? 1 : 0);
+    const float q = p * 0x1p64f;
+    const float s = __builtin_amdgcn_sqrtf(q);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = fmaf(-sd, s, q), ru = fmaf(-su, s, q);
+    float r = (rd <= 0.0f) ? sd : s;            // s == 0: sd is a NaN pattern, rd NaN, compare false -> stays 0
+    r = (ru > 0.0f) ? su : r;
+    return r * 0x1p-32f;
 }

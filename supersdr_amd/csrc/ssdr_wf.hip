@@ -71,7 +71,7 @@ __device__ constexpr int brev5(int v)
 //     sr = fma(-wi, vi, ur)     si = fma(wi, vr, ui)
 //     ar = fma( wr, vr, sr)     ai = fma(wr, vi, si)          a = u + w*v
 //     br = fma(  2, ur, -ar)    bi = fma( 2, ui, -ai)         b = 2u - a = u - w*v
-// 6 full-rate fp32 ops instead of 8.  The twin (oracle/ssdr_twin.c) states the same six roundings.
+// 6 full-rate fp32 ops instead of 8 (DESIGN.md section 3 spells out the six roundings).
 SSDR_DEV void bfly(f32x2 &u, f32x2 &v, float wr, float wi)
 {
     const float sr = fmaf(-wi, v.y, u.x), si = fmaf(wi, v.x, u.y);

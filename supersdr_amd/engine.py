@@ -169,6 +169,11 @@ class SsdrEngine:
         hist = np.ascontiguousarray(hist, np.int16)
         check(lib.ssdr_set_state(self._ctx, int(first), len(state), state.ctypes.data, hist.ctypes.data), "ssdr_set_state")
 
+    def selftest_sqrt(self):
+        n = C.c_uint64(0)
+        check(lib.ssdr_selftest_sqrt(self._ctx, C.byref(n)), "ssdr_selftest_sqrt")
+        return n.value
+
     def selftest_quantiser(self):
         n = C.c_uint64(0)
         check(lib.ssdr_selftest_quantiser(self._ctx, C.byref(n)), "ssdr_selftest_quantiser")

@@ -61,6 +61,12 @@ def test_quantiser_exhaustive(S):
         assert eng.selftest_quantiser() == 0
 
 
+def test_sqrt_exhaustive(S):
+    """the AM envelope's sqrt (hardware estimate + residual correction) == IEEE sqrtf on every normal float"""
+    with S.SsdrEngine(1) as eng:
+        assert eng.selftest_sqrt() == 0
+
+
 def test_tables_match_oracle(S, twin):
     assert np.array_equal(S.table(0), O.hann_window())
     wr, wi = O.twiddles()
