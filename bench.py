@@ -170,10 +170,23 @@ def main():
         stages["ssdr_audio_kernel"] = {"avg_ms": avg, "launches": au_n, "bytes": au_bytes, "GBps": au_bytes / avg / 1e6}
     dom = max(stages, key=lambda k: stages[k]["avg_ms"])
 
+    # HBM bytes per launch from the PMC passes committed under profiles/ (collected with rocprofv3 in separate
+    # runs, corrected as MI355X_MICROARCH.md prescribes; tools/profile_round.sh + tools/traffic_json.py).
+    # Only used when it was measured on exactly this workload shape; otherwise null.
+    measured = {}
+    try:
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json"))):
+            t = json.load(open(path))
+            if (t.get("workload"), t.get("channels_per_gpu"), t.get("superframes_per_step")) == (args.workload, channels, sframes):
+                measured = {k: v["hbm_bytes_per_launch"] for k, v in t["kernels"].items()}
+    except Exception:
+        measured = {}
+
     def roof(name):
         s = stages[name]
         return {"kernel": name, "bound": "hbm", "achieved": s["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": s["GBps"] / HBM_PEAK_GBPS, "traffic": None, "avg_kernel_ms": s["avg_ms"],
+                "frac": s["GBps"] / HBM_PEAK_GBPS, "traffic": measured.get(name), "avg_kernel_ms": s["avg_ms"],
                 "algorithmic_bytes_per_launch": s["bytes"]}
 
     out = {

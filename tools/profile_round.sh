@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round profile on the GPU box: kernel trace (stats) + HBM traffic PMC passes for the default bench command.
+#   tools/profile_round.sh r01        (run through gpurun; results under gpurun_out/prof_<tag>/)
+TAG=${1:-r01}; OUT=gpurun_out/prof_$TAG
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p $OUT
+BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT -o trace -- $BENCH > $OUT/trace.log 2>&1
+python tools/rocpd_stats.py $OUT/trace_results.db 2 > $OUT/kernel_stats.txt
+# PMC: separate passes, kernel-trace only (TCC has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2)
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- $BENCH > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- $BENCH > $OUT/write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES --output-format csv -d $OUT -o sq1 -- $BENCH > $OUT/sq1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT -o sq2 -- $BENCH > $OUT/sq2.log 2>&1
+python tools/pmc_summary.py $OUT/fetch_counter_collection.csv $OUT/write_counter_collection.csv $OUT/sq1_counter_collection.csv $OUT/sq2_counter_collection.csv > $OUT/pmc_summary.txt
+$BENCH 2>/dev/null | tail -1 > $OUT/bench_unprofiled.json
+grep '"metric"' $OUT/trace.log > $OUT/bench_under_trace.json
+cat $OUT/kernel_stats.txt; grep -E "FETCH|WRITE" $OUT/pmc_summary.txt
