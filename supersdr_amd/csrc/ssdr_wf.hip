@@ -55,7 +55,7 @@ static_assert(LDS_WIN + 2064 <= LDS_LUT0, "tables overlap");
 #endif
 constexpr int LDS_TOTAL = LDS_XCH + WAVES * 2 * XCH_FLOATS * 4;
 static_assert(LDS_XCH % 16 == 0 && LDS_TW % 8 == 0, "alignment");
-static_assert(LDS_TOTAL * (1024 / SSDR_WF_BLOCK) <= 163840, "LDS budget: 16 waves per CU");
+static_assert(LDS_TOTAL <= 163840, "LDS budget");
 
 // The register budget only holds if the phases of a line stay phases: without these fences
 // the machine scheduler hoists later phases' LDS table reads across the whole FFT and spills.
@@ -269,7 +269,7 @@ SSDR_DEV void load_tables(unsigned char *smem, const float *win, const float2 *t
 
 // AVG == false: averaging N == 1, every line is an output line (no accumulators at all).
 template <bool AVG>
-__global__ __launch_bounds__(SSDR_WF_BLOCK, 4) void ssdr_wf_kernel(SsdrWfArgs a)
+__global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_kernel(SsdrWfArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];     // the kernel's only LDS object: address 0
     load_tables(smem, a.win, a.tw_stage, a.lut);
@@ -287,6 +287,89 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, 4) void ssdr_wf_kernel(SsdrWfArgs a)
     const uint32_t n_items = n_pairs * a.n_groups;
     const uint32_t wave_stride = gridDim.x * WAVES;
 
+#if SSDR_WF_PREFETCH
+    // Software pipeline over the flattened (item, line) sequence of this wave: the next line's 32 loads per
+    // lane are issued as soon as the current line has been converted to float and stay in flight under the
+    // whole FFT, so every wave keeps 8 KB of HBM reads outstanding all the time (memory-level parallelism
+    // is what the un-pipelined loop lacks: its loads are in flight only ~15 % of the time).
+    uint32_t item = blockIdx.x * WAVES + wave;
+    if (item >= n_items) return;
+    WfItem it = wf_item(a, item, n_pairs, h);
+    uint32_t line = it.l0;
+    float cal = a.consts[it.ch].wf_cal_lin;
+    uint32_t raw[32];
+    load_line(a.iq + (uint64_t)it.ch * a.ch_stride + (uint64_t)line * SSDR_NFFT + l, raw);
+    uint32_t acc[AVG ? 16 : 1];
+#pragma unroll
+    for (int j = 0; j < (AVG ? 16 : 1); j++) acc[j] = 0;
+
+    for (;;) {
+        f32x2 z[32];
+        window_line(raw, smem, l, z);
+        SCHED_FENCE();
+
+        const bool group_end = (line + 1 == it.l1);
+        uint32_t nitem = item, nline = line + 1;
+        WfItem nit = it;
+        if (group_end) {
+            nitem = item + wave_stride;
+            if (nitem < n_items) { nit = wf_item(a, nitem, n_pairs, h); nline = nit.l0; }
+        }
+        const bool has_next = !group_end || nitem < n_items;
+        if (has_next)
+            load_line(a.iq + (uint64_t)nit.ch * a.ch_stride + (uint64_t)nline * SSDR_NFFT + opaque(l), raw);
+        SCHED_FENCE();
+
+        fft_line(z, smem, xch_wave, h, l);
+        {
+            int16_t *x16 = reinterpret_cast<int16_t *>(xch_wave + opaque(h) * XCH_FLOATS) + opaque(l);
+            if (AVG) {
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const float p0 = fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal;
+                    const float p1 = fmaf(z[j + 16].x, z[j + 16].x, z[j + 16].y * z[j + 16].y) * cal;
+                    acc[j] += quantise(p0, lut0, mask_fff8) + (quantise(p1, lut0, mask_fff8) << 16);
+                    if ((j & 3) == 3) SCHED_FENCE();
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    const float p = fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal;
+                    x16[32 * ((j + 16) & 31)] = (int16_t)quantise(p, lut0, mask_fff8);
+                    if ((j & 7) == 7) SCHED_FENCE();
+                }
+            }
+        }
+        if (group_end) {
+            float *xch = xch_wave + opaque(h) * XCH_FLOATS;
+            if (AVG) {
+                int16_t *x16 = reinterpret_cast<int16_t *>(xch) + opaque(l);
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    x16[32 * (j + 16)] = (int16_t)(acc[j] & 0xFFFFu);
+                    x16[32 * j] = (int16_t)(acc[j] >> 16);
+                    acc[j] = 0;
+                }
+            }
+            wave_lds_sync();
+            const u32x4 *x128 = reinterpret_cast<const u32x4 *>(xch);
+            int16_t *dst = it.complete ? a.out + ((uint64_t)it.grp * a.n_ch + it.ch) * SSDR_NFFT
+                                       : a.acc_out + (uint64_t)it.ch * SSDR_NFFT;
+            const int16_t *cin = a.acc_in + (uint64_t)it.ch * SSDR_NFFT;
+            const int lo = opaque(l);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u32x4 v = x128[q * 32 + lo];
+                if (AVG && it.carry_in) v += reinterpret_cast<const u32x4 *>(cin)[q * 32 + lo];
+                if (it.ch_ok) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst) + q * 32 + lo);
+            }
+            wave_lds_sync();
+            if (!has_next) break;
+            cal = a.consts[nit.ch].wf_cal_lin;
+        }
+        item = nitem; it = nit; line = nline;
+    }
+#else
     for (uint32_t item = blockIdx.x * WAVES + wave; item < n_items; item += wave_stride) {
         const WfItem it = wf_item(a, item, n_pairs, h);
         const float cal = a.consts[it.ch].wf_cal_lin;
@@ -357,6 +440,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, 4) void ssdr_wf_kernel(SsdrWfArgs a)
         }
         wave_lds_sync();
     }
+#endif
 }
 
 // exhaustive quantiser self-test: every positive finite float against a binary search over T[]
