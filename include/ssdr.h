@@ -119,6 +119,36 @@ int ssdr_run_wf(ssdr_ctx *ctx, int16_t *wf_sum_out, uint32_t *lines_ready, int o
 int ssdr_run_audio(ssdr_ctx *ctx, int16_t *pcm_out, float *rssi_out, int out_is_device);
 int ssdr_sync(ssdr_ctx *ctx);
 
+/* -- the reference's own post-processing of the two streams, on the GPU.
+ *    Per-channel display state of kiwi_waterfall.spectrum_db2col (utils_supersdr.py:787-813). 48 B. */
+typedef struct ssdr_db2col_chan {
+    int32_t zoom;                   /* kiwi_waterfall.zoom                                           */
+    int32_t auto_scale;             /* wf_auto_scaling                                               */
+    int32_t delta_low_db, delta_high_db;
+    float low_clip_db, high_clip_db, dynamic_range;     /* in (when !auto_scale) / out               */
+    float wf_min_db, wf_max_db;                         /* out (:807-808)                            */
+    uint32_t pad[3];
+} ssdr_db2col_chan;
+/* spectrum_db2col for every channel and every line produced by the last ssdr_run_wf:
+ * color_out float32 [lines][n_ch][1024] in 0..254 (wf_color), chans[] updated in place (host memory). */
+int ssdr_run_db2col(ssdr_ctx *ctx, ssdr_db2col_chan *chans, float *color_out, int out_is_device);
+
+/* kiwi_sound.play_buffer (utils_supersdr.py:1106-1148) for every channel and every frame of the last
+ * ssdr_run_audio: volume, x4 interpolation with filtering(KIWI_RATE/2, AUDIO_RATE) (:999), pan^2,
+ * truncating int16 stereo pack.  out int16 [n_ch][n_frames*2048][2].  The (n_tap-1)-sample history
+ * (old_buffer, :1005,1133) is carried per channel in the ctx. */
+typedef struct ssdr_play_chan {
+    double volume;                  /* kiwi_sound.volume, percent (:921, supersdr.py:397-406)        */
+    double balance;                 /* kiwi_sound.audio_balance in [-1, 1] (:945)                    */
+} ssdr_play_chan;
+int ssdr_run_playbuffer(ssdr_ctx *ctx, const ssdr_play_chan *chans, int16_t *out, int out_is_device);
+
+/* KiwiSDRStream._process_aud, IQ branch (kiwi/client.py:384-389, 443-454): n_frames SND bodies per channel
+ * (each 7 B flags/seq/smeter + 10 B GPS + 512 big-endian I,Q pairs = 2065 B, layout [n_ch][n_frames][2065],
+ * host memory) become the current input batch, as ssdr_push_iq would; rssi_out (may be NULL) receives
+ * 0.1*smeter - 127 per frame. */
+int ssdr_push_iq_wire(ssdr_ctx *ctx, const uint8_t *bodies, uint32_t n_frames, float *rssi_out);
+
 /* -- device-resident results of the last run_* (for zero-copy consumers and bench) */
 int ssdr_wf_device(ssdr_ctx *ctx, int16_t **ptr, uint32_t *lines);
 int ssdr_audio_device(ssdr_ctx *ctx, int16_t **pcm, float **rssi);
@@ -126,7 +156,7 @@ int ssdr_audio_device(ssdr_ctx *ctx, int16_t **pcm, float **rssi);
 /* -- measurement */
 int ssdr_set_stream(ssdr_ctx *ctx, void *hip_stream);           /* NULL = ctx's own stream */
 int ssdr_set_profiling(ssdr_ctx *ctx, int on);                  /* HIP-event pair around every launch */
-enum { SSDR_K_WF = 0, SSDR_K_AUDIO = 1, SSDR_K_SYNTH = 2, SSDR_K_COUNT = 3 };
+enum { SSDR_K_WF = 0, SSDR_K_AUDIO = 1, SSDR_K_SYNTH = 2, SSDR_K_DB2COL = 3, SSDR_K_PLAY = 4, SSDR_K_WIRE = 5, SSDR_K_COUNT = 6 };
 int ssdr_kernel_stats(ssdr_ctx *ctx, int which, float *total_ms, uint32_t *launches, int reset);
 int ssdr_elapsed_ms(ssdr_ctx *ctx, float *ms);                  /* last run_* call, device time */
 
@@ -142,6 +172,9 @@ int ssdr_compile_params(const ssdr_chan_params *p, ssdr_chan_consts *consts, flo
 int ssdr_get_consts(ssdr_ctx *ctx, uint32_t first, uint32_t count, ssdr_chan_consts *consts, float *taps);
 int ssdr_get_state(ssdr_ctx *ctx, uint32_t first, uint32_t count, ssdr_chan_state *state, int16_t *hist);
 int ssdr_set_state(ssdr_ctx *ctx, uint32_t first, uint32_t count, const ssdr_chan_state *state, const int16_t *hist);
+/* inject results as if ssdr_run_wf / ssdr_run_audio had produced them (golden-vector tests of the post-processing) */
+int ssdr_set_wf_lines(ssdr_ctx *ctx, const int16_t *wf_sum /*[lines][n_ch][1024]*/, uint32_t lines);
+int ssdr_set_pcm(ssdr_ctx *ctx, const int16_t *pcm /*[n_ch][n_frames*512]*/, uint32_t n_frames);
 int ssdr_selftest_quantiser(ssdr_ctx *ctx, uint64_t *mismatches);   /* all positive floats vs binary search */
 int ssdr_selftest_sqrt(ssdr_ctx *ctx, uint64_t *mismatches);        /* AM envelope sqrt vs IEEE sqrtf, all normal floats */
 

@@ -13,7 +13,7 @@ NFFT, FRAME, RATE, NTAP_MAX, HIST = 1024, 512, 12000, 128, 128
 OK, EINVAL, ENOMEM, EHIP, ENODEV, ESTATE = 0, -1, -2, -3, -4, -5
 MODE_AM, MODE_LSB, MODE_USB, MODE_CW, MODE_NBFM = range(5)
 MODE_BY_NAME = {"am": 0, "lsb": 1, "usb": 2, "cw": 3, "nbfm": 4, "nfm": 4}
-K_WF, K_AUDIO, K_SYNTH = 0, 1, 2
+K_WF, K_AUDIO, K_SYNTH, K_DB2COL, K_PLAY, K_WIRE = range(6)
 T_WINDOW, T_TWIDDLE_RE, T_TWIDDLE_IM, T_DB_THRESH = range(4)
 
 
@@ -33,12 +33,26 @@ class ChanConsts(C.Structure):
                 ("hang_frames", C.c_uint32), ("ntap", C.c_uint32), ("pad", C.c_uint32 * 4)]
 
 
+class Db2colChan(C.Structure):
+    """ssdr_db2col_chan: display state of kiwi_waterfall.spectrum_db2col (utils_supersdr.py:787-813)."""
+    _fields_ = [("zoom", C.c_int32), ("auto_scale", C.c_int32), ("delta_low_db", C.c_int32), ("delta_high_db", C.c_int32),
+                ("low_clip_db", C.c_float), ("high_clip_db", C.c_float), ("dynamic_range", C.c_float),
+                ("wf_min_db", C.c_float), ("wf_max_db", C.c_float), ("pad", C.c_uint32 * 3)]
+
+
+class PlayChan(C.Structure):
+    """ssdr_play_chan: kiwi_sound.volume / audio_balance (utils_supersdr.py:921, 945)."""
+    _fields_ = [("volume", C.c_double), ("balance", C.c_double)]
+
+
 class ChanState(C.Structure):
     _fields_ = [("phi1", C.c_uint32), ("phi2", C.c_uint32), ("dc", C.c_float), ("agc_d", C.c_float),
                 ("agc_m", C.c_float * 8), ("prev_re", C.c_float), ("prev_im", C.c_float), ("pad", C.c_uint32 * 2)]
 
 
 assert C.sizeof(ChanConsts) == 64 and C.sizeof(ChanState) == 64 and C.sizeof(ChanParams) == 88
+assert C.sizeof(Db2colChan) == 48 and C.sizeof(PlayChan) == 16
+WIRE_BODY = 17 + FRAME * 4
 
 _P = C.c_void_p
 _SIGS = {
@@ -52,6 +66,9 @@ _SIGS = {
     "ssdr_run_wf": (C.c_int, [_P, _P, C.POINTER(C.c_uint32), C.c_int]),
     "ssdr_run_audio": (C.c_int, [_P, _P, _P, C.c_int]),
     "ssdr_sync": (C.c_int, [_P]),
+    "ssdr_run_db2col": (C.c_int, [_P, C.POINTER(Db2colChan), _P, C.c_int]),
+    "ssdr_run_playbuffer": (C.c_int, [_P, C.POINTER(PlayChan), _P, C.c_int]),
+    "ssdr_push_iq_wire": (C.c_int, [_P, _P, C.c_uint32, _P]),
     "ssdr_wf_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32)]),
     "ssdr_audio_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "ssdr_set_stream": (C.c_int, [_P, _P]),
@@ -65,6 +82,8 @@ _SIGS = {
     "ssdr_get_consts": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
     "ssdr_get_state": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
     "ssdr_set_state": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
+    "ssdr_set_wf_lines": (C.c_int, [_P, _P, C.c_uint32]),
+    "ssdr_set_pcm": (C.c_int, [_P, _P, C.c_uint32]),
     "ssdr_selftest_quantiser": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ssdr_selftest_sqrt": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ssdr_strerror": (C.c_char_p, [C.c_int]),

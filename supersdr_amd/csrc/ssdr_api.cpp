@@ -55,11 +55,22 @@ struct ssdr_ctx {
     struct Pending { hipEvent_t e0, e1; int which; };
     std::vector<Pending> pending;                       // profiling: resolved lazily, no sync per launch
     std::vector<hipEvent_t> free_events;
-    float k_ms[SSDR_K_COUNT] = {0, 0, 0};
-    uint32_t k_n[SSDR_K_COUNT] = {0, 0, 0};
+    float k_ms[SSDR_K_COUNT] = {};
+    uint32_t k_n[SSDR_K_COUNT] = {};
     float last_ms = 0.0f;
     uint32_t wf_grid = 0;
     unsigned long long *d_scratch = nullptr;
+    // post-processing
+    ssdr_db2col_chan *d_db2col = nullptr;
+    float *d_color = nullptr;
+    size_t color_lines = 0;
+    ssdr_play_chan *d_play = nullptr;
+    double *d_play_taps = nullptr, *d_play_hist = nullptr;
+    int16_t *d_play_out = nullptr;
+    size_t play_frames = 0;
+    uint8_t *d_wire = nullptr;
+    size_t wire_frames = 0;
+    float *d_wire_rssi = nullptr;
 };
 
 static int get_event(ssdr_ctx *c, hipEvent_t *e)
@@ -131,7 +142,8 @@ void ssdr_destroy(ssdr_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_wf_acc[0], c->d_wf_acc[1],
-                    c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_scratch};
+                    c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
+                    c->d_play_taps, c->d_play_hist, c->d_play_out, c->d_wire, c->d_wire_rssi};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -563,6 +575,149 @@ int ssdr_selftest_quantiser(ssdr_ctx *c, uint64_t *mismatches)
     HIP_TRY(hipMemcpyAsync(&v, c->d_scratch, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *mismatches = v;
+    return SSDR_OK;
+}
+
+int ssdr_run_db2col(ssdr_ctx *c, ssdr_db2col_chan *chans, float *color_out, int out_is_device)
+{
+    if (!c || !chans) return SSDR_EINVAL;
+    if (!c->d_wf_out && c->wf_lines_ready) return SSDR_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t lines = c->wf_lines_ready;
+    if (!c->d_db2col) HIP_TRY(hipMalloc(&c->d_db2col, (size_t)c->n_ch * sizeof(ssdr_db2col_chan)));
+    if (lines == 0) return SSDR_OK;
+    if (c->color_lines < lines) {
+        if (c->d_color) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_color)); c->d_color = nullptr; c->color_lines = 0; }
+        HIP_TRY(hipMalloc(&c->d_color, (size_t)lines * c->n_ch * SSDR_NFFT * sizeof(float)));
+        c->color_lines = lines;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_db2col, chans, (size_t)c->n_ch * sizeof(ssdr_db2col_chan), hipMemcpyHostToDevice, c->stream));
+    SsdrDb2colArgs a;
+    a.wf = c->d_wf_out;
+    a.n_ch = c->n_ch;
+    a.n_lines = lines;
+    a.n_avg = c->n_avg;
+    a.chans = c->d_db2col;
+    a.color = c->d_color;
+    int rc;
+    if ((rc = timed_begin(c)) != SSDR_OK) return rc;
+    HIP_TRY(ssdr_launch_db2col(a, c->stream));
+    if ((rc = timed_end(c, SSDR_K_DB2COL)) != SSDR_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(chans, c->d_db2col, (size_t)c->n_ch * sizeof(ssdr_db2col_chan), hipMemcpyDeviceToHost, c->stream));
+    if (color_out)
+        HIP_TRY(hipMemcpyAsync(color_out, c->d_color, (size_t)lines * c->n_ch * SSDR_NFFT * sizeof(float),
+                               out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, int out_is_device)
+{
+    if (!c || !chans) return SSDR_EINVAL;
+    if (!c->d_pcm || c->in_frames == 0 || c->audio_frames < c->in_frames) return SSDR_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t nf = c->in_frames;
+    if (!c->d_play) {
+        HIP_TRY(hipMalloc(&c->d_play, (size_t)c->n_ch * sizeof(ssdr_play_chan)));
+        HIP_TRY(hipMalloc(&c->d_play_taps, 33 * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_play_hist, (size_t)c->n_ch * 8 * sizeof(double)));
+        HIP_TRY(hipMemsetAsync(c->d_play_hist, 0, (size_t)c->n_ch * 8 * sizeof(double), c->stream));   // old_buffer = zeros (:1005)
+        double h[64];
+        if (ssdr_design_lowpass(SSDR_RATE / 2.0, 48000.0, 63, h) != 33) return SSDR_EINVAL;             // filtering(KIWI_RATE/2, AUDIO_RATE)
+        HIP_TRY(hipMemcpyAsync(c->d_play_taps, h, 33 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (c->play_frames < nf) {
+        if (c->d_play_out) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_play_out)); c->d_play_out = nullptr; c->play_frames = 0; }
+        HIP_TRY(hipMalloc(&c->d_play_out, (size_t)c->n_ch * nf * 2048 * 2 * sizeof(int16_t)));
+        c->play_frames = nf;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_play, chans, (size_t)c->n_ch * sizeof(ssdr_play_chan), hipMemcpyHostToDevice, c->stream));
+    SsdrPlayArgs a;
+    a.pcm = c->d_pcm;
+    a.n_ch = c->n_ch;
+    a.n_frames = nf;
+    a.chans = c->d_play;
+    a.taps = c->d_play_taps;
+    a.hist = c->d_play_hist;
+    a.out = c->d_play_out;
+    int rc;
+    if ((rc = timed_begin(c)) != SSDR_OK) return rc;
+    HIP_TRY(ssdr_launch_play(a, c->stream));
+    if ((rc = timed_end(c, SSDR_K_PLAY)) != SSDR_OK) return rc;
+    if (out)
+        HIP_TRY(hipMemcpyAsync(out, c->d_play_out, (size_t)c->n_ch * nf * 2048 * 2 * sizeof(int16_t),
+                               out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_push_iq_wire(ssdr_ctx *c, const uint8_t *bodies, uint32_t n_frames, float *rssi_out)
+{
+    if (!c || !bodies || n_frames == 0) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    int rc = ensure_input(c, n_frames);
+    if (rc != SSDR_OK) return rc;
+    if (c->wire_frames < n_frames) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_wire) { HIP_TRY(hipFree(c->d_wire)); c->d_wire = nullptr; }
+        if (c->d_wire_rssi) { HIP_TRY(hipFree(c->d_wire_rssi)); c->d_wire_rssi = nullptr; }
+        c->wire_frames = 0;
+        HIP_TRY(hipMalloc(&c->d_wire, (size_t)c->n_ch * n_frames * SSDR_WIRE_BODY));
+        HIP_TRY(hipMalloc(&c->d_wire_rssi, (size_t)c->n_ch * n_frames * sizeof(float)));
+        c->wire_frames = n_frames;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_wire, bodies, (size_t)c->n_ch * n_frames * SSDR_WIRE_BODY, hipMemcpyHostToDevice, c->stream));
+    SsdrWireArgs a;
+    a.bodies = c->d_wire;
+    a.n_ch = c->n_ch;
+    a.n_frames = n_frames;
+    a.iq = c->d_iq_own;
+    a.ch_stride = (uint64_t)n_frames * SSDR_FRAME;
+    a.rssi = c->d_wire_rssi;
+    if ((rc = timed_begin(c)) != SSDR_OK) return rc;
+    HIP_TRY(ssdr_launch_iqwire(a, c->stream));
+    if ((rc = timed_end(c, SSDR_K_WIRE)) != SSDR_OK) return rc;
+    if (rssi_out)
+        HIP_TRY(hipMemcpyAsync(rssi_out, c->d_wire_rssi, (size_t)c->n_ch * n_frames * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->d_iq = c->d_iq_own;
+    c->in_frames = n_frames;
+    c->have_input = true;
+    return SSDR_OK;
+}
+
+int ssdr_set_wf_lines(ssdr_ctx *c, const int16_t *wf_sum, uint32_t lines)
+{
+    if (!c || !wf_sum || lines == 0) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->wf_out_lines < lines) {
+        if (c->d_wf_out) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_wf_out)); c->d_wf_out = nullptr; c->wf_out_lines = 0; }
+        HIP_TRY(hipMalloc(&c->d_wf_out, (size_t)lines * c->n_ch * SSDR_NFFT * 2));
+        c->wf_out_lines = lines;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_wf_out, wf_sum, (size_t)lines * c->n_ch * SSDR_NFFT * 2, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->wf_lines_ready = lines;
+    return SSDR_OK;
+}
+
+int ssdr_set_pcm(ssdr_ctx *c, const int16_t *pcm, uint32_t n_frames)
+{
+    if (!c || !pcm || n_frames == 0) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->audio_frames < n_frames) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_pcm) { HIP_TRY(hipFree(c->d_pcm)); c->d_pcm = nullptr; }
+        if (c->d_rssi) { HIP_TRY(hipFree(c->d_rssi)); c->d_rssi = nullptr; }
+        c->audio_frames = 0;
+        HIP_TRY(hipMalloc(&c->d_pcm, (size_t)c->n_ch * n_frames * SSDR_FRAME * 2));
+        HIP_TRY(hipMalloc(&c->d_rssi, (size_t)c->n_ch * n_frames * sizeof(float)));
+        c->audio_frames = n_frames;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_pcm, pcm, (size_t)c->n_ch * n_frames * SSDR_FRAME * 2, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->in_frames = n_frames;
     return SSDR_OK;
 }
 

@@ -69,6 +69,35 @@ struct SsdrSynthArgs {
     uint64_t sample0;                        // absolute index of the first sample (phase continuity)
 };
 
+#define SSDR_WIRE_BODY (17 + SSDR_FRAME * 4)  // SND body in IQ mode: 7 B header + 10 B GPS + 512 x (I,Q) int16 BE
+
+struct SsdrDb2colArgs {
+    const int16_t *wf;                       // [n_lines][n_ch][1024] sums of n_avg byte lines
+    uint32_t n_ch, n_lines, n_avg;
+    ssdr_db2col_chan *chans;                 // [n_ch] in/out
+    float *color;                            // [n_lines][n_ch][1024]
+};
+
+struct SsdrPlayArgs {
+    const int16_t *pcm;                      // [n_ch][n_frames*512]
+    uint32_t n_ch, n_frames;
+    const ssdr_play_chan *chans;             // [n_ch]
+    const double *taps;                      // [33] filtering(KIWI_RATE/2, AUDIO_RATE).h
+    double *hist;                            // [n_ch][8] last 8 volume-scaled samples (the non-zero part of old_buffer)
+    int16_t *out;                            // [n_ch][n_frames*2048][2]
+};
+
+struct SsdrWireArgs {
+    const uint8_t *bodies;                   // [n_ch][n_frames][SSDR_WIRE_BODY]
+    uint32_t n_ch, n_frames;
+    uint32_t *iq;                            // [n_ch][ch_stride] dwords
+    uint64_t ch_stride;
+    float *rssi;                             // [n_ch][n_frames] or null: 0.1*smeter - 127 of each frame header
+};
+
+hipError_t ssdr_launch_db2col(const SsdrDb2colArgs &a, hipStream_t stream);
+hipError_t ssdr_launch_play(const SsdrPlayArgs &a, hipStream_t stream);
+hipError_t ssdr_launch_iqwire(const SsdrWireArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream);
 hipError_t ssdr_wf_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, hipStream_t stream);
@@ -83,3 +112,4 @@ void ssdr_make_tw_stage(float2 *tw);                  // [992]
 void ssdr_make_thresholds(float *thr);                // [256]
 int ssdr_make_quant_lut(uint2 *lut);                  // [SSDR_LUT_N]; returns 0, or -1 if a segment held two thresholds
 int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps);
+int ssdr_design_lowpass(double fl, double fs, int n_max, double *h);   // utils_supersdr.py:334-344; returns tap count

@@ -1,0 +1,229 @@
+// ssdr_post.hip -- the reference's own post-processing of the two streams, on the GPU:
+//
+//   ssdr_db2col_kernel   kiwi_waterfall.spectrum_db2col (utils_supersdr.py:787-813): byte line -> dBm ->
+//                        40th-percentile / max autoscale -> palette index 0..254, float32 op for op as
+//                        NumPy evaluates it on a float32 line
+//   ssdr_play_kernel     kiwi_sound.play_buffer (utils_supersdr.py:1106-1148): volume, x4 zero-stuffing
+//                        interpolation with the reference's 33-tap filter (:999-1005), pan^2, truncating
+//                        int16 stereo pack -- float64 like the reference
+//   ssdr_iqwire_kernel   KiwiSDRStream._process_aud, IQ branch (kiwi/client.py:443-454): strips the 17-byte
+//                        SND/GPS header of each frame and turns big-endian int16 I,Q into the kernels' layout
+//
+// These are pinned by golden vectors produced by the real reference (tests/golden/*.npz).
+#include "ssdr_math.h"
+#include "ssdr_kernels.h"
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CTRL, int ROWMASK>
+SSDR_DEV int dpp_i(int identity, int x)
+{
+    return __builtin_amdgcn_update_dpp(identity, x, CTRL, ROWMASK, 0xF, false);
+}
+SSDR_DEV int wave_sum_i(int x)          // total over the 64 lanes, returned to every lane (uniform)
+{
+    x += dpp_i<0x111, 0xF>(0, x);
+    x += dpp_i<0x112, 0xF>(0, x);
+    x += dpp_i<0x114, 0xF>(0, x);
+    x += dpp_i<0x118, 0xF>(0, x);
+    x += dpp_i<0x142, 0xA>(0, x);
+    x += dpp_i<0x143, 0xC>(0, x);
+    return __builtin_amdgcn_readlane(x, 63);
+}
+SSDR_DEV int wave_max_i(int x)
+{
+    x = max(x, dpp_i<0x111, 0xF>(x, x));
+    x = max(x, dpp_i<0x112, 0xF>(x, x));
+    x = max(x, dpp_i<0x114, 0xF>(x, x));
+    x = max(x, dpp_i<0x118, 0xF>(x, x));
+    x = max(x, dpp_i<0x142, 0xA>(x, x));
+    x = max(x, dpp_i<0x143, 0xC>(x, x));
+    return __builtin_amdgcn_readlane(x, 63);
+}
+SSDR_DEV int wave_min_i(int x) { return -wave_max_i(-x); }
+
+// One wave per channel, lines in order; lane l owns bins 16l .. 16l+15.
+//
+// NumPy on a float32 line (restated, utils_supersdr.py:787-813):
+//   wf_db   = (-(255 - s) - 13) + 3 zoom               three float32 roundings
+//   wf_db[0] = wf_db[1]
+//   low     = a + (b - a) * G,  a, b = sorted[409], sorted[410], G = float32(0.2000122)   (np.percentile(.,40)
+//             on float32: q = 40/float32(100), virtual index 1024 q + (1 - q) - 1 in float32 -> gamma G)
+//   high    = max;  dyn = max(high - low, 40)
+//   color   = clip(clip((wf_db - (low + dlo)) / ((dyn + dhi) - dlo), 0, 1) * 254, 0, 255)
+// The order statistics are taken on the int16 sums (the map sum -> wf_db is monotone), by bisection on the
+// value with wave-wide counting: exact, no sort.
+__global__ __launch_bounds__(64) void ssdr_db2col_kernel(SsdrDb2colArgs a)
+{
+    const int l = threadIdx.x;
+    const uint32_t ch = blockIdx.x;
+    if (ch >= a.n_ch) return;
+    ssdr_db2col_chan st = a.chans[ch];
+    const float z3 = (float)(3 * st.zoom), dlo = (float)st.delta_low_db, dhi = (float)st.delta_high_db;
+    const float fn = (float)a.n_avg;
+    const float G = 0x1.99ap-3f;
+
+    for (uint32_t line = 0; line < a.n_lines; line++) {
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(a.wf + ((uint64_t)line * a.n_ch + ch) * SSDR_NFFT) + 2 * l;
+        const u32x4 r0 = src[0], r1 = src[1];
+        const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+        int s[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { s[2 * i] = (int)(rw[i] & 0xFFFFu); s[2 * i + 1] = (int)(rw[i] >> 16); }
+        if (l == 0) s[0] = s[1];                                    // "first bin is broken" (:791)
+
+        float wf_db[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float sp = (float)s[i] / fn;                       // float32(sum) / float32(N) == np.mean
+            wf_db[i] = (-(255.0f - sp) - 13.0f) + z3;
+        }
+
+        if (st.auto_scale) {
+            // smallest v with #{s <= v} >= 410  ==  sorted[409]
+            int lo = 0, hi = 32767;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                int c = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) c += (s[i] <= mid) ? 1 : 0;
+                if (wave_sum_i(c) >= 410) hi = mid; else lo = mid + 1;
+            }
+            const int v409 = lo;
+            int c = 0, above = 0x7FFF, mx = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                c += (s[i] <= v409) ? 1 : 0;
+                above = min(above, (s[i] > v409) ? s[i] : 0x7FFF);
+                mx = max(mx, s[i]);
+            }
+            const int v410 = (wave_sum_i(c) >= 411) ? v409 : wave_min_i(above);
+            const int vmax = wave_max_i(mx);
+            const float fa = (-(255.0f - (float)v409 / fn) - 13.0f) + z3;
+            const float fb = (-(255.0f - (float)v410 / fn) - 13.0f) + z3;
+            const float fh = (-(255.0f - (float)vmax / fn) - 13.0f) + z3;
+            const float d = fb - fa;
+            const float t = d * G;
+            st.low_clip_db = fa + t;
+            st.high_clip_db = fh;
+            const float span = fh - st.low_clip_db;
+            st.dynamic_range = (span > 40.0f) ? span : 40.0f;
+        }
+        const float lo2 = st.low_clip_db + dlo;
+        const float nf = st.dynamic_range + dhi;
+        const float den = nf - dlo;
+        st.wf_min_db = lo2 - z3;
+        st.wf_max_db = (st.low_clip_db + nf) - z3;
+
+        f32x4 *dst = reinterpret_cast<f32x4 *>(a.color + ((uint64_t)line * a.n_ch + ch) * SSDR_NFFT) + 4 * l;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float c = (wf_db[4 * q + i] - lo2) / den;
+                c = fminf(fmaxf(c, 0.0f), 1.0f) * 254.0f;
+                o[i] = fminf(fmaxf(c, 0.0f), 255.0f);
+            }
+            dst[q] = o;
+        }
+    }
+    if (l == 0) a.chans[ch] = st;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// play_buffer: out[4n + r] for r = 0..3.  With zero stuffing only every 4th term of the 33-tap convolution
+// is non-zero:  y[i] = 4 * sum_j h[j] U[i + 32 - j],  U = [history(32) | stuffed frame],  U[m] != 0 only for
+// m = 0 mod 4.  One wave per channel; lane l produces outputs 32l .. 32l+31 of each 2048-sample block.
+__global__ __launch_bounds__(64) void ssdr_play_kernel(SsdrPlayArgs a)
+{
+    __shared__ double s_x[8 + SSDR_FRAME];                          // 8 carried samples + the frame, volume applied
+    const int l = threadIdx.x;
+    const uint32_t ch = blockIdx.x;
+    if (ch >= a.n_ch) return;
+    const ssdr_play_chan pc = a.chans[ch];
+    const double vol = pc.volume / 100.0;
+    const double lv = fmin(1.0 - pc.balance, 1.0), rv = fmin(1.0 + pc.balance, 1.0);
+    const double l2 = lv * lv, r2 = rv * rv;
+    double h[33];
+#pragma unroll
+    for (int j = 0; j < 33; j++) h[j] = a.taps[j];
+    if (l < 8) s_x[l] = a.hist[(size_t)ch * 8 + l];
+    __syncthreads();
+
+    for (uint32_t f = 0; f < a.n_frames; f++) {
+        const int16_t *src = a.pcm + ((uint64_t)ch * a.n_frames + f) * SSDR_FRAME;
+#pragma unroll
+        for (int i = 0; i < 8; i++) s_x[8 + 8 * l + i] = (double)src[8 * l + i] * vol;
+        __syncthreads();
+        // stuffed index m = 4 * (k) holds X[k], X = s_x (k = 0..519; k < 8 is history)
+        uint32_t *dst = reinterpret_cast<uint32_t *>(a.out + (((uint64_t)ch * a.n_frames + f) * 2048 + 32 * l) * 2);
+        for (int o4 = 0; o4 < 32; o4 += 4) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {                           // i = 32 l + o4 + r, so i mod 4 == r (static)
+                const int i = 32 * l + o4 + r;
+                // terms j with (i + 32 - j) = 0 mod 4  ->  j = r + 4 t (j <= 32), summed in ascending sample order
+                double acc = 0.0;
+#pragma unroll
+                for (int t = 8; t >= 0; t--) {
+                    const int j = r + 4 * t;
+                    if (j <= 32) acc += h[j] * s_x[(i + 32 - j) >> 2];
+                }
+                acc *= 4.0;
+                const int li = (int)(acc * l2), ri = (int)(acc * r2);    // trunc toward zero, then wrap to int16
+                dst[o4 + r] = ((uint32_t)li & 0xFFFFu) | ((uint32_t)ri << 16);
+            }
+        }
+        __syncthreads();
+        if (l < 8) s_x[l] = s_x[SSDR_FRAME + l];
+        __syncthreads();
+    }
+    if (l < 8) a.hist[(size_t)ch * 8 + l] = s_x[l];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SND body in IQ mode: 7 bytes (flags, seq, smeter) + 10 bytes GPS + 512 x (I,Q) big-endian int16.
+// One wave per (channel, frame): lane l converts samples 8l .. 8l+7 (32 payload bytes at byte offset 17 + 32 l).
+__global__ __launch_bounds__(64) void ssdr_iqwire_kernel(SsdrWireArgs a)
+{
+    const int l = threadIdx.x;
+    const uint32_t f = blockIdx.x % a.n_frames, ch = blockIdx.x / a.n_frames;
+    if (ch >= a.n_ch) return;
+    const uint8_t *body = a.bodies + ((uint64_t)ch * a.n_frames + f) * SSDR_WIRE_BODY;
+    const uint8_t *p = body + 17 + 32 * l;
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        // I = p[0..1] big-endian, Q = p[2..3] big-endian -> dword I | Q << 16 (little-endian halves)
+        const uint32_t b0 = p[4 * i], b1 = p[4 * i + 1], b2 = p[4 * i + 2], b3 = p[4 * i + 3];
+        w[i] = ((b0 << 8) | b1) | (((b2 << 8) | b3) << 16);
+    }
+    u32x4 *dst = reinterpret_cast<u32x4 *>(a.iq + (uint64_t)ch * a.ch_stride + (uint64_t)f * SSDR_FRAME) + 2 * l;
+    dst[0] = u32x4{w[0], w[1], w[2], w[3]};
+    dst[1] = u32x4{w[4], w[5], w[6], w[7]};
+    if (l == 0 && a.rssi) {
+        const uint32_t smeter = ((uint32_t)body[5] << 8) | body[6];
+        a.rssi[(uint64_t)ch * a.n_frames + f] = 0.1f * (float)smeter - 127.0f;
+    }
+}
+
+} // namespace
+
+hipError_t ssdr_launch_db2col(const SsdrDb2colArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ssdr_db2col_kernel, dim3(a.n_ch), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t ssdr_launch_play(const SsdrPlayArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ssdr_play_kernel, dim3(a.n_ch), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t ssdr_launch_iqwire(const SsdrWireArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ssdr_iqwire_kernel, dim3(a.n_ch * a.n_frames), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}

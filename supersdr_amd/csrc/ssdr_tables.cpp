@@ -76,7 +76,7 @@ static double sinc_pi(double x)
 }
 
 // utils_supersdr.py:334-344, with the tap count capped at n_max (odd)
-static int design_lowpass(double fl, double fs, int n_max, double *h)
+int ssdr_design_lowpass(double fl, double fs, int n_max, double *h)
 {
     const double b = fl / fs;
     int N = (int)std::ceil(4.0 / b);
@@ -116,7 +116,7 @@ int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, flo
     }
     fl = std::min(std::max(fl, 50.0), SSDR_RATE / 2.0);
     double h[SSDR_NTAP_MAX];
-    const int ntap = design_lowpass(fl, (double)SSDR_RATE, SSDR_NTAP_MAX - 1, h);
+    const int ntap = ssdr_design_lowpass(fl, (double)SSDR_RATE, SSDR_NTAP_MAX - 1, h);
     for (int i = 0; i < SSDR_NTAP_MAX; i++) taps[i] = (i < ntap) ? (float)h[i] : 0.0f;
     c->mode = (uint32_t)p->mode;
     c->ntap = (uint32_t)ntap;

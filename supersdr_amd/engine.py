@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
-from ._lib import ChanParams, ChanConsts, ChanState, check, lib
+from ._lib import ChanParams, ChanConsts, ChanState, Db2colChan, PlayChan, check, lib
 
 CONSTS_DTYPE = np.dtype([("mode", "<u4"), ("ntap8", "<u4"), ("dphi1", "<u4"), ("dphi2", "<u4"),
                          ("wf_cal_lin", "<f4"), ("smeter_cal_db", "<f4"), ("agc_c0", "<f4"), ("agc_c1", "<f4"),
@@ -131,6 +131,46 @@ class SsdrEngine:
 
     def sync(self):
         check(lib.ssdr_sync(self._ctx), "ssdr_sync")
+
+    # ---- the reference's post-processing on the GPU
+    def run_db2col(self, chans, lines, fetch=True):
+        """spectrum_db2col for the lines of the last run_wf.  chans: list of Db2colChan (updated in place).
+        -> float32 [lines, n_ch, 1024] wf_color."""
+        arr = (Db2colChan * self.n_ch)(*chans)
+        out = np.empty((lines, self.n_ch, L.NFFT), np.float32) if fetch else None
+        check(lib.ssdr_run_db2col(self._ctx, arr, out.ctypes.data if fetch else None, 0), "ssdr_run_db2col")
+        for i in range(self.n_ch):
+            chans[i] = arr[i]
+        return out
+
+    def run_playbuffer(self, chans, fetch=True):
+        """play_buffer for the frames of the last run_audio -> int16 [n_ch, n_frames*2048, 2]."""
+        arr = (PlayChan * self.n_ch)(*chans)
+        out = np.empty((self.n_ch, self.in_frames * 2048, 2), np.int16) if fetch else None
+        check(lib.ssdr_run_playbuffer(self._ctx, arr, out.ctypes.data if fetch else None, 0), "ssdr_run_playbuffer")
+        return out
+
+    def set_wf_lines(self, wf_sum):
+        """int16 [lines, n_ch, 1024]: stand in for the output of run_wf (golden-vector tests of run_db2col)."""
+        wf_sum = np.ascontiguousarray(wf_sum, np.int16)
+        check(lib.ssdr_set_wf_lines(self._ctx, wf_sum.ctypes.data, wf_sum.shape[0]), "ssdr_set_wf_lines")
+
+    def set_pcm(self, pcm):
+        """int16 [n_ch, n_frames*512]: stand in for the output of run_audio (golden-vector tests of run_playbuffer)."""
+        pcm = np.ascontiguousarray(pcm, np.int16).reshape(self.n_ch, -1)
+        self.in_frames = pcm.shape[1] // L.FRAME
+        check(lib.ssdr_set_pcm(self._ctx, pcm.ctypes.data, self.in_frames), "ssdr_set_pcm")
+
+    def push_iq_wire(self, bodies):
+        """bodies: uint8 [n_ch, n_frames, 2065] SND bodies in IQ mode (kiwi/client.py:384-389, 443-454).
+        -> float32 [n_ch, n_frames] rssi from the frame headers."""
+        bodies = np.ascontiguousarray(bodies, np.uint8)
+        if bodies.ndim != 3 or bodies.shape[0] != self.n_ch or bodies.shape[2] != L.WIRE_BODY:
+            raise ValueError("bodies must be uint8[n_ch=%d, n_frames, %d]" % (self.n_ch, L.WIRE_BODY))
+        self.in_frames = bodies.shape[1]
+        rssi = np.empty((self.n_ch, self.in_frames), np.float32)
+        check(lib.ssdr_push_iq_wire(self._ctx, bodies.ctypes.data, self.in_frames, rssi.ctypes.data), "ssdr_push_iq_wire")
+        return rssi
 
     # ---- measurement
     def set_profiling(self, on):
