@@ -17,10 +17,12 @@ Both are fed by an `IQHub`, which owns one SsdrEngine (one GPU context) for a bl
 receiver channels, batches the channels' IQ frames and runs the two kernels once per
 superframe (1024 samples = 1 waterfall line + 2 audio frames).
 
-Everything numeric that the reference computes on the host AFTER those seams (time
-binning, spectrum_db2col, scrolling, the playback interpolator) is kept on the host here
-and restated from the reference with citations; the numbers coming out of the seams are
-produced by the HIP kernels only.
+What the reference computes on the host AFTER those seams is restated here with citations
+(time binning by division, scrolling, pacing, TX mute).  Two of those steps -- spectrum_db2col
+(utils_supersdr.py:787-813) and the play_buffer interpolator (:1106-1148) -- also exist as HIP
+kernels (ssdr_run_db2col / ssdr_run_playbuffer, bit-exact against golden vectors of the real
+reference); with `IQHub(gpu_post=True)` (default) the workers use those results and keep the
+host restatement only as the path for frames that did not come with one.
 """
 import queue
 import threading
@@ -30,6 +32,7 @@ from collections import deque
 import numpy as np
 
 from . import _lib as L
+from ._lib import Db2colChan, PlayChan
 from .engine import SsdrEngine, default_params
 
 # module constants of the reference (utils_supersdr.py:42-50)
@@ -60,9 +63,13 @@ class IQHub:
         snd_queue[c] : (int16[512] pcm, float rssi) per audio frame
     """
 
-    def __init__(self, n_channels, device=0, engine=None, max_queue=64):
+    def __init__(self, n_channels, device=0, engine=None, max_queue=64, gpu_post=True):
         self.n_ch = int(n_channels)
         self.engine = engine if engine is not None else SsdrEngine(self.n_ch, device)
+        # spectrum_db2col and play_buffer on the GPU too (SURVEY.md 8f) when the engine offers them
+        self.gpu_post = bool(gpu_post) and hasattr(self.engine, "run_db2col")
+        self.wf_clients = [None] * self.n_ch        # kiwi_waterfall objects: display state for db2col
+        self.snd_clients = [None] * self.n_ch       # kiwi_sound objects: volume / balance for play_buffer
         self._buf = [np.zeros((0, 2), np.int16) for _ in range(self.n_ch)]
         self.wf_queue = [queue.Queue(max_queue) for _ in range(self.n_ch)]
         self.snd_queue = [queue.Queue(2 * max_queue) for _ in range(self.n_ch)]
@@ -101,13 +108,34 @@ class IQHub:
             self.engine.push_iq(batch)
             n_avg = self.averaging_n
             wf = self.engine.run_wf()                 # [lines, n_ch, 1024]
+            color = chans = None
+            if self.gpu_post and len(wf) and any(w is not None for w in self.wf_clients):
+                chans = [self._db2col_chan(w) for w in self.wf_clients]
+                color = self.engine.run_db2col(chans, len(wf))          # [lines, n_ch, 1024] float32 0..254
             pcm, rssi = self.engine.run_audio()       # [n_ch, 1024], [n_ch, 2]
+            play = None
+            if self.gpu_post and any(s is not None for s in self.snd_clients):
+                play = self.engine.run_playbuffer([PlayChan(float(s.volume), float(s.audio_balance)) if s is not None
+                                                   else PlayChan(100.0, 0.0) for s in self.snd_clients])
             self.superframes += 1
             for c in range(self.n_ch):
-                for line in wf:
-                    _put_drop_oldest(self.wf_queue[c], (line[c].copy(), n_avg))
+                for i, line in enumerate(wf):
+                    post = None
+                    if color is not None and self.wf_clients[c] is not None:
+                        k = chans[c]
+                        post = (color[i, c].copy(), k.low_clip_db, k.high_clip_db, k.dynamic_range, k.wf_min_db, k.wf_max_db)
+                    _put_drop_oldest(self.wf_queue[c], (line[c].copy(), n_avg, post))
                 for f in range(2):
-                    _put_drop_oldest(self.snd_queue[c], (pcm[c, f * L.FRAME:(f + 1) * L.FRAME].copy(), float(rssi[c, f])))
+                    blk = play[c, f * 2048:(f + 1) * 2048].copy() if play is not None else None
+                    _put_drop_oldest(self.snd_queue[c], (pcm[c, f * L.FRAME:(f + 1) * L.FRAME].copy(), float(rssi[c, f]), blk))
+
+    @staticmethod
+    def _db2col_chan(w):
+        if w is None:
+            return Db2colChan(auto_scale=1, low_clip_db=-120.0, high_clip_db=-60.0, dynamic_range=40.0)
+        return Db2colChan(zoom=int(w.zoom), auto_scale=int(bool(w.wf_auto_scaling)), delta_low_db=int(w.delta_low_db),
+                          delta_high_db=int(w.delta_high_db), low_clip_db=float(w.low_clip_db),
+                          high_clip_db=float(w.high_clip_db), dynamic_range=float(w.dynamic_range))
 
     def close(self):
         self.engine.close()
@@ -176,6 +204,9 @@ class kiwi_waterfall:
         if hub is None:
             raise ValueError("the GPU-backed kiwi_waterfall needs an IQHub (there is no server-side FFT to fall back to)")
         self.hub, self.channel, self._timeout = hub, channel, timeout
+        self._gpu_post = None
+        if hasattr(hub, "wf_clients"):
+            hub.wf_clients[channel] = self
 
     # ---- frequency / zoom arithmetic: utils_supersdr.py:747-778 (scalar UI math)
     def zoom_to_span(self):
@@ -266,7 +297,7 @@ class kiwi_waterfall:
         """Leaves self.spectrum = float32[WF_BINS] in byte units (dBm = byte - 255)."""
         self.hub.set_averaging(1)                        # binning is done by run() exactly like the reference
         try:
-            line, n = self.hub.wf_queue[self.channel].get(timeout=self._timeout)
+            line, n, self._gpu_post = self.hub.wf_queue[self.channel].get(timeout=self._timeout)
         except queue.Empty:
             self.terminate = True
             return
@@ -278,7 +309,7 @@ class kiwi_waterfall:
         self.hub.set_averaging(n)
         while not self.terminate:
             try:
-                line, n_used = self.hub.wf_queue[self.channel].get(timeout=self._timeout)
+                line, n_used, self._gpu_post = self.hub.wf_queue[self.channel].get(timeout=self._timeout)
             except queue.Empty:
                 self.terminate = True
                 return
@@ -287,6 +318,11 @@ class kiwi_waterfall:
                 return
 
     def spectrum_db2col(self):                           # utils_supersdr.py:787-813
+        if self._gpu_post is not None:                   # computed by ssdr_run_db2col with this object's display state
+            (self.wf_color, self.low_clip_db, self.high_clip_db, self.dynamic_range,
+             self.wf_min_db, self.wf_max_db) = self._gpu_post
+            self._gpu_post = None
+            return
         wf = self.spectrum
         wf = -(255 - wf)
         wf_db = wf - 13 + (3 * self.zoom)
@@ -385,6 +421,9 @@ class kiwi_sound:
         self.channel = kiwi_wf.channel if channel is None else channel
         self._timeout = timeout
         self.center_khz = float(kiwi_wf.freq)            # the IQ band's centre: tuning is relative to it
+        self._play_blocks = {}
+        if hasattr(self.hub, "snd_clients"):
+            self.hub.snd_clients[self.channel] = self
         self.set_mode_freq_pb()
         self.set_agc_params()
 
@@ -438,12 +477,14 @@ class kiwi_sound:
     # ---- the seam: utils_supersdr.py:1044-1076
     def process_audio_stream(self):
         try:
-            samples, rssi = self.hub.snd_queue[self.channel].get(timeout=self._timeout)
+            samples, rssi, blk = self.hub.snd_queue[self.channel].get(timeout=self._timeout)
         except queue.Empty:
             self.terminate = True
             self.kiwi_wf.terminate = True
             raise
         self.rssi = rssi
+        if blk is not None:
+            self._play_blocks[id(samples)] = blk         # the frame's 48 kHz stereo block from ssdr_run_playbuffer
         return samples
 
     def get_audio_chunk(self):                           # utils_supersdr.py:1031-1042
@@ -459,7 +500,13 @@ class kiwi_sound:
         if self.late_flag:
             outdata[:] = 0
             return
-        popped = np.array([self.audio_buffer.get() for _ in range(self.CHUNKS)]).flatten()
+        frames = [self.audio_buffer.get() for _ in range(self.CHUNKS)]
+        blocks = [self._play_blocks.pop(id(f), None) for f in frames]
+        if all(b is not None for b in blocks):           # interpolated, panned and packed on the GPU
+            outdata[:] = np.concatenate(blocks)
+            self._mute_logic(outdata)
+            return
+        popped = np.array(frames).flatten()
         popped = popped.astype(np.float64) * (self.volume / 100)
         ratio = int(self.SAMPLE_RATIO)
         buf = np.zeros(ratio * len(popped))
@@ -471,6 +518,9 @@ class kiwi_sound:
         with np.errstate(invalid="ignore"):
             outdata[:, 0] = (buf * left ** 2).astype(np.int16)
             outdata[:, 1] = (buf * right ** 2).astype(np.int16)
+        self._mute_logic(outdata)
+
+    def _mute_logic(self, outdata):                      # utils_supersdr.py:1142-1147
         if self.rssi > self.max_rssi_before_mute:
             self.mute_counter = self.muting_delay
         elif self.mute_counter > 0:
