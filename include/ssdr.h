@@ -149,6 +149,11 @@ int ssdr_run_playbuffer(ssdr_ctx *ctx, const ssdr_play_chan *chans, int16_t *out
  * 0.1*smeter - 127 per frame. */
 int ssdr_push_iq_wire(ssdr_ctx *ctx, const uint8_t *bodies, uint32_t n_frames, float *rssi_out);
 
+/* IMA ADPCM decoder of compressed SND / W-F payloads (kiwi/client.py:33-87, 461-464, 476-479): n_streams
+ * independent streams of n_bytes each (host memory, [n_streams][n_bytes]); state int32 [n_streams][2] =
+ * {index, prev} in/out (zero it per W/F line, keep it across SND frames); out int16 [n_streams][2*n_bytes]. */
+int ssdr_adpcm_decode(ssdr_ctx *ctx, const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state, int16_t *out);
+
 /* -- device-resident results of the last run_* (for zero-copy consumers and bench) */
 int ssdr_wf_device(ssdr_ctx *ctx, int16_t **ptr, uint32_t *lines);
 int ssdr_audio_device(ssdr_ctx *ctx, int16_t **pcm, float **rssi);

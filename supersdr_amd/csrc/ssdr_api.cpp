@@ -687,6 +687,32 @@ int ssdr_push_iq_wire(ssdr_ctx *c, const uint8_t *bodies, uint32_t n_frames, flo
     return SSDR_OK;
 }
 
+int ssdr_adpcm_decode(ssdr_ctx *c, const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state, int16_t *out)
+{
+    if (!c || !data || !state || !out || n_streams == 0 || n_bytes == 0) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    uint8_t *d_in = nullptr;
+    int32_t *d_st = nullptr;
+    int16_t *d_out = nullptr;
+    const size_t nin = (size_t)n_streams * n_bytes;
+    int rc = [&]() -> int {
+        HIP_TRY(hipMalloc(&d_in, nin));
+        HIP_TRY(hipMalloc(&d_st, (size_t)n_streams * 8));
+        HIP_TRY(hipMalloc(&d_out, nin * 4));
+        HIP_TRY(hipMemcpyAsync(d_in, data, nin, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_st, state, (size_t)n_streams * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(ssdr_launch_adpcm(d_in, n_streams, n_bytes, d_st, d_out, c->stream));
+        HIP_TRY(hipMemcpyAsync(out, d_out, nin * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(state, d_st, (size_t)n_streams * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return SSDR_OK;
+    }();
+    if (d_in) (void)hipFree(d_in);
+    if (d_st) (void)hipFree(d_st);
+    if (d_out) (void)hipFree(d_out);
+    return rc;
+}
+
 int ssdr_set_wf_lines(ssdr_ctx *c, const int16_t *wf_sum, uint32_t lines)
 {
     if (!c || !wf_sum || lines == 0) return SSDR_EINVAL;

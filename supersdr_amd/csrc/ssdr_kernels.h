@@ -98,6 +98,8 @@ struct SsdrWireArgs {
 hipError_t ssdr_launch_db2col(const SsdrDb2colArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_play(const SsdrPlayArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_iqwire(const SsdrWireArgs &a, hipStream_t stream);
+hipError_t ssdr_launch_adpcm(const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state, int16_t *out,
+                             hipStream_t stream);
 hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream);
 hipError_t ssdr_wf_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, hipStream_t stream);

@@ -210,7 +210,53 @@ __global__ __launch_bounds__(64) void ssdr_iqwire_kernel(SsdrWireArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// IMA ADPCM (kiwi/client.py:33-87): sequential within a stream, parallel across streams: one lane per stream.
+// Low nibble first; diff = step>>3 (+step>>2, +step>>1, +step by code bits 0..2), negated by bit 3; sample and
+// index clamped; (index, prev) persist across calls for SND audio, are reset per line for W/F (:476-477).
+__constant__ int c_ima_step[89] = {
+    7, 8, 9, 10, 11, 12, 13, 14, 16, 17, 19, 21, 23, 25, 28, 31, 34, 37, 41, 45, 50, 55, 60, 66, 73, 80, 88, 97, 107, 118,
+    130, 143, 157, 173, 190, 209, 230, 253, 279, 307, 337, 371, 408, 449, 494, 544, 598, 658, 724, 796, 876, 963, 1060,
+    1166, 1282, 1411, 1552, 1707, 1878, 2066, 2272, 2499, 2749, 3024, 3327, 3660, 4026, 4428, 4871, 5358, 5894, 6484,
+    7132, 7845, 8630, 9493, 10442, 11487, 12635, 13899, 15289, 16818, 18500, 20350, 22385, 24623, 27086, 29794, 32767};
+
+__global__ void ssdr_adpcm_kernel(const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state /*[n][2]*/,
+                                  int16_t *out /*[n][2*n_bytes]*/)
+{
+    const uint32_t sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= n_streams) return;
+    int index = state[2 * sidx], prev = state[2 * sidx + 1];
+    const uint8_t *p = data + (uint64_t)sidx * n_bytes;
+    int16_t *o = out + (uint64_t)sidx * 2 * n_bytes;
+    for (uint32_t i = 0; i < n_bytes; i++) {
+        const int byte = p[i];
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int code = half ? (byte >> 4) : (byte & 0x0F);
+            const int step = c_ima_step[index];
+            const int adj = (code & 4) ? 2 * (code & 3) + 2 : -1;           // -1,-1,-1,-1,2,4,6,8 (twice)
+            index = min(max(index + adj, 0), 88);
+            int diff = step >> 3;
+            if (code & 1) diff += step >> 2;
+            if (code & 2) diff += step >> 1;
+            if (code & 4) diff += step;
+            if (code & 8) diff = -diff;
+            prev = min(max(prev + diff, -32768), 32767);
+            o[2 * i + half] = (int16_t)prev;
+        }
+    }
+    state[2 * sidx] = index;
+    state[2 * sidx + 1] = prev;
+}
+
 } // namespace
+
+hipError_t ssdr_launch_adpcm(const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state, int16_t *out,
+                             hipStream_t stream)
+{
+    hipLaunchKernelGGL(ssdr_adpcm_kernel, dim3((n_streams + 63) / 64), dim3(64), 0, stream, data, n_streams, n_bytes, state, out);
+    return hipGetLastError();
+}
 
 hipError_t ssdr_launch_db2col(const SsdrDb2colArgs &a, hipStream_t stream)
 {

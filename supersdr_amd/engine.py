@@ -150,6 +150,18 @@ class SsdrEngine:
         check(lib.ssdr_run_playbuffer(self._ctx, arr, out.ctypes.data if fetch else None, 0), "ssdr_run_playbuffer")
         return out
 
+    def adpcm_decode(self, data, state=None):
+        """data uint8 [n_streams, n_bytes]; state int32 [n_streams, 2] {index, prev} (updated in place)
+        -> int16 [n_streams, 2*n_bytes].  IMA ADPCM of compressed SND / W-F payloads (kiwi/client.py:58-87)."""
+        data = np.ascontiguousarray(data, np.uint8)
+        if state is None:
+            state = np.zeros((data.shape[0], 2), np.int32)
+        assert state.dtype == np.int32 and state.flags.c_contiguous
+        out = np.empty((data.shape[0], 2 * data.shape[1]), np.int16)
+        check(lib.ssdr_adpcm_decode(self._ctx, data.ctypes.data, data.shape[0], data.shape[1], state.ctypes.data,
+                                    out.ctypes.data), "ssdr_adpcm_decode")
+        return out
+
     def set_wf_lines(self, wf_sum):
         """int16 [lines, n_ch, 1024]: stand in for the output of run_wf (golden-vector tests of run_db2col)."""
         wf_sum = np.ascontiguousarray(wf_sum, np.int16)

@@ -50,6 +50,31 @@ def int16_to_wire(iq, seq=0, smeter=0, flags=0, gps=(0, 0, 0, 0)):
             iq.astype(">i2").tobytes())
 
 
+def read_kiwi_iq_wav(path_or_bytes):
+    """Kiwi IQ recording (kiwi/wavreader.py:29-65, 74-85): RIFF/WAVE, 'fmt ' (PCM, 2 channels, block align 4),
+    then repeating ['kiwi' chunk '<BBII' GNSS stamp]['data' chunk little-endian int16 I,Q].  Returns
+    (int16 [n_blocks, n, 2], [(last_gps_solution, dummy, gpssec, gpsnsec), ...]).  The samples are already in
+    the kernels' layout, so blocks go straight to IQHub.feed / ssdr_push_iq (the reference scales by 1/65535
+    for its complex64 view, wavreader.py:84; the int16 values are what was recorded)."""
+    data = path_or_bytes if isinstance(path_or_bytes, (bytes, bytearray)) else open(path_or_bytes, "rb").read()
+    if data[0:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise ValueError("not a RIFF/WAVE file")
+    pos, blocks, stamps = 12, [], []
+    while pos + 8 <= len(data):
+        name, size = bytes(data[pos:pos + 4]), struct.unpack("<I", bytes(data[pos + 4:pos + 8]))[0]
+        body = data[pos + 8:pos + 8 + size]
+        if name == b"fmt ":
+            tag, nch, _, _, align = struct.unpack("<HHLLH", bytes(body[:14]))
+            if not (tag == 1 and nch == 2 and align == 4):
+                raise ValueError("this is not a KiwiSDR IQ wav file")
+        elif name == b"kiwi":
+            stamps.append(struct.unpack("<BBII", bytes(body[:10])))
+        elif name == b"data":
+            blocks.append(np.frombuffer(bytes(body), dtype="<i2").reshape(-1, 2).astype(np.int16))
+        pos += 8 + size + (size & 1)
+    return np.stack(blocks), stamps
+
+
 class IQBatcher:
     """Mixin: IQ frames -> IQHub.  `samples` arrives as the reference builds it (kiwi/client.py:
     449-453): complex64 with unscaled int16 values in re/im, so the conversion back is exact."""

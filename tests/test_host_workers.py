@@ -276,3 +276,15 @@ def test_channel_blocks_partition():
         covered = np.concatenate([np.arange(f, f + n) for f, n in blocks])
         assert np.array_equal(covered, np.arange(total))
         assert max(n for _, n in blocks) - min(n for _, n in blocks) <= 1
+
+
+def test_kiwi_wav_reader_vs_reference_golden():
+    from supersdr_amd.iqstream import read_kiwi_iq_wav
+    g = np.load(os.path.join(GOLD, "wavreader.npz"))
+    blocks, stamps = read_kiwi_iq_wav(g["wav_bytes"].tobytes())
+    assert np.array_equal(blocks, g["blocks"]) and blocks.dtype == np.int16
+    z = blocks[2:].astype(np.float32).reshape(-1, 2).view(np.complex64).reshape(-1) / 65535      # wavreader.py:84
+    assert np.array_equal(z.astype(np.complex64), g["z"])
+    assert [s[3] for s in stamps] == [42666667 * i for i in range(5)]
+    with pytest.raises(ValueError):
+        read_kiwi_iq_wav(b"RIFX" + bytes(40))
