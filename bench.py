@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--channels", type=int, default=0, help="override channels per GPU")
     ap.add_argument("--superframes", type=int, default=0, help="override superframes per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--concurrent", type=int, default=0, help="1: audio kernel on a second stream beside the waterfall kernel")
     args = ap.parse_args()
 
     import torch
@@ -125,6 +126,7 @@ def main():
         eng.set_params(first, params[: min(len(params), channels - first)])
     eng.reset_state()
     eng.set_averaging(n_avg)
+    eng.set_concurrent(args.concurrent)
     eng.synth_iq(n_frames, seed=0x5D5D, first_channel_id=rank * channels)    # resident in HBM from here on
     eng.sync()
 

@@ -161,6 +161,8 @@ int ssdr_audio_device(ssdr_ctx *ctx, int16_t **pcm, float **rssi);
 /* -- measurement */
 int ssdr_set_stream(ssdr_ctx *ctx, void *hip_stream);           /* NULL = ctx's own stream */
 int ssdr_set_profiling(ssdr_ctx *ctx, int on);                  /* HIP-event pair around every launch */
+/* run the audio kernel on a second stream beside the waterfall kernel (which then takes one workgroup per CU) */
+int ssdr_set_concurrent(ssdr_ctx *ctx, int on);
 enum { SSDR_K_WF = 0, SSDR_K_AUDIO = 1, SSDR_K_SYNTH = 2, SSDR_K_DB2COL = 3, SSDR_K_PLAY = 4, SSDR_K_WIRE = 5, SSDR_K_COUNT = 6 };
 int ssdr_kernel_stats(ssdr_ctx *ctx, int which, float *total_ms, uint32_t *launches, int reset);
 int ssdr_elapsed_ms(ssdr_ctx *ctx, float *ms);                  /* last run_* call, device time */

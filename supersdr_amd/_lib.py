@@ -74,6 +74,7 @@ _SIGS = {
     "ssdr_audio_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "ssdr_set_stream": (C.c_int, [_P, _P]),
     "ssdr_set_profiling": (C.c_int, [_P, C.c_int]),
+    "ssdr_set_concurrent": (C.c_int, [_P, C.c_int]),
     "ssdr_kernel_stats": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_int]),
     "ssdr_elapsed_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "ssdr_synth_iq": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),

@@ -24,6 +24,9 @@ struct ssdr_ctx {
     uint32_t n_ch = 0;
     uint32_t n_avg = 1, wf_phase = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    hipStream_t stream2 = nullptr;                      // audio kernel when running concurrently with the waterfall
+    hipEvent_t ev_in = nullptr, ev_a = nullptr;
+    bool concurrent = false, audio_pending = false;
     // tables
     float *d_win = nullptr, *d_thr = nullptr;
     float2 *d_tw = nullptr;
@@ -58,7 +61,7 @@ struct ssdr_ctx {
     float k_ms[SSDR_K_COUNT] = {};
     uint32_t k_n[SSDR_K_COUNT] = {};
     float last_ms = 0.0f;
-    uint32_t wf_grid = 0;
+    uint32_t wf_grid = 0, wf_grid_1 = 0;
     unsigned long long *d_scratch = nullptr;
     // post-processing
     ssdr_db2col_chan *d_db2col = nullptr;
@@ -80,27 +83,29 @@ static int get_event(ssdr_ctx *c, hipEvent_t *e)
     return SSDR_OK;
 }
 // HIP events on the stream the kernel is launched on, bracketing exactly one launch.
-static int timed_begin(ssdr_ctx *c)
+static int timed_begin(ssdr_ctx *c, hipStream_t s = nullptr)
 {
+    if (!s) s = c->stream;
     if (c->profiling) {
         ssdr_ctx::Pending p{nullptr, nullptr, -1};
         int rc;
         if ((rc = get_event(c, &p.e0)) != SSDR_OK) return rc;
         if ((rc = get_event(c, &p.e1)) != SSDR_OK) return rc;
         c->pending.push_back(p);
-        HIP_TRY(hipEventRecord(p.e0, c->stream));
+        HIP_TRY(hipEventRecord(p.e0, s));
     } else {
-        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        HIP_TRY(hipEventRecord(c->ev0, s));
     }
     return SSDR_OK;
 }
-static int timed_end(ssdr_ctx *c, int which)
+static int timed_end(ssdr_ctx *c, int which, hipStream_t s = nullptr)
 {
+    if (!s) s = c->stream;
     if (c->profiling) {
         c->pending.back().which = which;
-        HIP_TRY(hipEventRecord(c->pending.back().e1, c->stream));
+        HIP_TRY(hipEventRecord(c->pending.back().e1, s));
     } else {
-        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(hipEventRecord(c->ev1, s));
     }
     return SSDR_OK;
 }
@@ -150,6 +155,9 @@ void ssdr_destroy(ssdr_ctx *c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     for (auto &p : c->pending) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
     for (auto e : c->free_events) (void)hipEventDestroy(e);
+    if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -266,6 +274,9 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         c->stream = c->own_stream;
         HIP_TRY(hipEventCreate(&c->ev0));
         HIP_TRY(hipEventCreate(&c->ev1));
+        HIP_TRY(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
         HIP_TRY(hipMalloc(&c->d_win, SSDR_NFFT * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_thr, 256 * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_tw, SSDR_TW_STAGE_N * sizeof(float2)));
@@ -295,6 +306,7 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         if (per_cu < 1) per_cu = 1;
         // persistent grid == exactly the resident workgroups (a larger grid would run a ragged second round)
         c->wf_grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+        c->wf_grid_1 = (uint32_t)prop.multiProcessorCount;        // one workgroup per CU (concurrent mode)
         return SSDR_OK;
     }();
     if (rc == SSDR_OK) {
@@ -327,6 +339,17 @@ int ssdr_set_stream(ssdr_ctx *c, void *hip_stream)
 {
     if (!c) return SSDR_EINVAL;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return SSDR_OK;
+}
+
+int ssdr_set_concurrent(ssdr_ctx *c, int on)
+{
+    if (!c) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream2));
+    c->concurrent = on != 0;
+    c->audio_pending = false;
     return SSDR_OK;
 }
 
@@ -369,11 +392,19 @@ int ssdr_sync(ssdr_ctx *c)
     if (!c) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->concurrent) HIP_TRY(hipStreamSynchronize(c->stream2));
+    return SSDR_OK;
+}
+
+static int join_audio(ssdr_ctx *c)
+{
+    if (c->audio_pending) { HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_a, 0)); c->audio_pending = false; }
     return SSDR_OK;
 }
 
 static int ensure_input(ssdr_ctx *c, uint32_t n_frames)
 {
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     if (c->iq_own_frames < n_frames) {
         if (c->d_iq_own) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_iq_own)); c->d_iq_own = nullptr; c->iq_own_frames = 0; }
         HIP_TRY(hipMalloc(&c->d_iq_own, (size_t)c->n_ch * n_frames * SSDR_FRAME * 4));
@@ -386,6 +417,7 @@ int ssdr_push_iq(ssdr_ctx *c, const int16_t *iq, uint32_t n_frames, int is_devic
 {
     if (!c || !iq || n_frames == 0) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     if (is_device) {
         c->d_iq = reinterpret_cast<const uint32_t *>(iq);
     } else {
@@ -466,7 +498,8 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
     a.lut = c->d_lut;
     const uint64_t items = (uint64_t)((c->n_ch + 1) / 2) * n_groups;
     const uint64_t need = (items + SSDR_WF_BLOCK / 64 - 1) / (SSDR_WF_BLOCK / 64);
-    const uint32_t grid = (uint32_t)(need < c->wf_grid ? need : c->wf_grid);
+    const uint32_t wf_grid = c->concurrent ? c->wf_grid_1 : c->wf_grid;
+    const uint32_t grid = (uint32_t)(need < wf_grid ? need : wf_grid);
     int rc;
     if ((rc = timed_begin(c)) != SSDR_OK) return rc;
     HIP_TRY(ssdr_launch_wf(a, grid ? grid : 1, c->stream));
@@ -509,13 +542,25 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
     a.pcm = c->d_pcm;
     a.rssi = c->d_rssi;
     int rc;
-    if ((rc = timed_begin(c)) != SSDR_OK) return rc;
-    HIP_TRY(ssdr_launch_audio(a, c->stream));
-    if ((rc = timed_end(c, SSDR_K_AUDIO)) != SSDR_OK) return rc;
+    hipStream_t s = c->stream;
+    if (c->concurrent) {
+        // the audio kernel only depends on the input batch (and on its own previous launch): run it beside the
+        // waterfall kernel on a second stream so that its waves fill the issue slots the waterfall leaves idle
+        s = c->stream2;
+        HIP_TRY(hipEventRecord(c->ev_in, c->stream));          // everything queued so far, incl. the input copy/synth
+        HIP_TRY(hipStreamWaitEvent(s, c->ev_in, 0));
+    }
+    if ((rc = timed_begin(c, s)) != SSDR_OK) return rc;
+    HIP_TRY(ssdr_launch_audio(a, s));
+    if ((rc = timed_end(c, SSDR_K_AUDIO, s)) != SSDR_OK) return rc;
     const hipMemcpyKind kind = out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-    if (pcm_out) HIP_TRY(hipMemcpyAsync(pcm_out, c->d_pcm, (size_t)c->n_ch * c->in_frames * SSDR_FRAME * 2, kind, c->stream));
-    if (rssi_out) HIP_TRY(hipMemcpyAsync(rssi_out, c->d_rssi, (size_t)c->n_ch * c->in_frames * sizeof(float), kind, c->stream));
-    if ((pcm_out || rssi_out) && !out_is_device) HIP_TRY(hipStreamSynchronize(c->stream));
+    if (pcm_out) HIP_TRY(hipMemcpyAsync(pcm_out, c->d_pcm, (size_t)c->n_ch * c->in_frames * SSDR_FRAME * 2, kind, s));
+    if (rssi_out) HIP_TRY(hipMemcpyAsync(rssi_out, c->d_rssi, (size_t)c->n_ch * c->in_frames * sizeof(float), kind, s));
+    if ((pcm_out || rssi_out) && !out_is_device) HIP_TRY(hipStreamSynchronize(s));
+    if (c->concurrent) {                                       // later work on the main stream (next input, playbuffer) follows the audio
+        HIP_TRY(hipEventRecord(c->ev_a, s));
+        c->audio_pending = true;
+    }
     return SSDR_OK;
 }
 
@@ -616,6 +661,7 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
     if (!c || !chans) return SSDR_EINVAL;
     if (!c->d_pcm || c->in_frames == 0 || c->audio_frames < c->in_frames) return SSDR_ESTATE;
     HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     const uint32_t nf = c->in_frames;
     if (!c->d_play) {
         HIP_TRY(hipMalloc(&c->d_play, (size_t)c->n_ch * sizeof(ssdr_play_chan)));

@@ -188,6 +188,9 @@ class SsdrEngine:
     def set_profiling(self, on):
         check(lib.ssdr_set_profiling(self._ctx, int(bool(on))), "ssdr_set_profiling")
 
+    def set_concurrent(self, on):
+        check(lib.ssdr_set_concurrent(self._ctx, int(bool(on))), "ssdr_set_concurrent")
+
     def kernel_stats(self, which, reset=False):
         ms, n = C.c_float(0), C.c_uint32(0)
         check(lib.ssdr_kernel_stats(self._ctx, int(which), C.byref(ms), C.byref(n), int(reset)), "ssdr_kernel_stats")
