@@ -77,7 +77,8 @@ typedef struct ssdr_chan_consts {
     float wf_cal_lin, smeter_cal_db;
     float agc_c0, agc_c1, agc_knee, agc_delta8;
     uint32_t hang_frames, ntap;
-    uint32_t pad[4];
+    uint32_t tap_groups;            /* bit g set: taps 4g..4g+3 are not all zero (the FIR skips the others) */
+    uint32_t pad[3];
 } ssdr_chan_consts;
 
 /* Per-channel carried state (read back / restored for tests and checkpointing). 64 B. */

@@ -258,7 +258,8 @@ typedef struct {            /* per-channel kernel constants; same layout as the 
     float wf_cal_lin, smeter_cal_db;
     float agc_c0, agc_c1, agc_knee, agc_delta8;
     uint32_t hang_frames, ntap;
-    uint32_t pad[4];
+    uint32_t tap_groups;    /* unused here: zero taps are exact no-ops in the fma chain */
+    uint32_t pad[3];
 } twin_consts;              /* 64 bytes */
 
 typedef struct {

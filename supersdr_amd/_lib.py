@@ -30,7 +30,7 @@ class ChanConsts(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("ntap8", C.c_uint32), ("dphi1", C.c_uint32), ("dphi2", C.c_uint32),
                 ("wf_cal_lin", C.c_float), ("smeter_cal_db", C.c_float),
                 ("agc_c0", C.c_float), ("agc_c1", C.c_float), ("agc_knee", C.c_float), ("agc_delta8", C.c_float),
-                ("hang_frames", C.c_uint32), ("ntap", C.c_uint32), ("pad", C.c_uint32 * 4)]
+                ("hang_frames", C.c_uint32), ("ntap", C.c_uint32), ("tap_groups", C.c_uint32), ("pad", C.c_uint32 * 3)]
 
 
 class Db2colChan(C.Structure):

@@ -153,8 +153,8 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
 
     const ssdr_chan_consts &kc = a.consts[ch];
     const uint32_t mode = kc.mode;
-    const uint32_t n4 = (kc.ntap + 3) >> 2;              // taps beyond ntap are zero: fma(0, z, acc) == acc exactly,
-    const uint32_t nblk = n4 >> 1, half_blk = n4 & 1;    // so the FIR stops at the next multiple of 4, not of 8
+    const uint32_t tap_groups = kc.tap_groups;           // fma(0, z, acc) == acc exactly: all-zero 4-tap groups are skipped
+    const uint32_t nblk = (kc.ntap + 7) >> 3;
     const uint32_t dphi1 = kc.dphi1, dphi2 = kc.dphi2;
     const float c0 = kc.agc_c0, c1 = kc.agc_c1, knee = kc.agc_knee, d8 = kc.agc_delta8;
     const uint32_t K = kc.hang_frames;
@@ -201,21 +201,20 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
         float yr[8], yi[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) { yr[j] = 0.0f; yi[j] = 0.0f; }
+        uint32_t a_blk = 0;                                      // A currently holds octet (l - a_blk)
         for (uint32_t b = 0; b < nblk; b++) {
+            const uint32_t m2 = (tap_groups >> (2 * b)) & 3u;    // wave-uniform
+            if (m2 == 0) continue;
+            if (a_blk != b) load_oct(s_z, HOCT + l - (int)b, A);
             load_oct(s_z, HOCT + l - 1 - (int)b, B);
             float h[8];
 #pragma unroll
             for (int kk = 0; kk < 8; kk++) h[kk] = taps[8 * b + kk];
-            fir_taps<0, 8>(h, A, B, yr, yi);
+            if (m2 & 1u) fir_taps<0, 4>(h, A, B, yr, yi);
+            if (m2 & 2u) fir_taps<4, 4>(h, A, B, yr, yi);
 #pragma unroll
             for (int j = 0; j < 8; j++) A[j] = B[j];
-        }
-        if (half_blk) {
-            load_oct(s_z, HOCT + l - 1 - (int)nblk, B);
-            float h[8];
-#pragma unroll
-            for (int kk = 0; kk < 4; kk++) h[kk] = taps[8 * nblk + kk];
-            fir_taps<0, 4>(h, A, B, yr, yi);
+            a_blk = b + 1;
         }
 
         // 3. power, demodulation

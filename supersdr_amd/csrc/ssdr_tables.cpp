@@ -118,9 +118,21 @@ int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, flo
     double h[SSDR_NTAP_MAX];
     const int ntap = ssdr_design_lowpass(fl, (double)SSDR_RATE, SSDR_NTAP_MAX - 1, h);
     for (int i = 0; i < SSDR_NTAP_MAX; i++) taps[i] = (i < ntap) ? (float)h[i] : 0.0f;
+    // The windowed-sinc formula leaves numerical dust where a tap is mathematically zero (sinc at integers,
+    // Blackman end points: 1e-17 .. 1e-34 against a peak of ~1).  Taps below 2^-40 of the largest are set to
+    // exactly zero, and the kernel skips 4-tap groups that are all zero (AM at the full 12 kHz band is a
+    // pure delay: one group instead of three).
+    float hmax = 0.0f;
+    for (int i = 0; i < ntap; i++) hmax = std::max(hmax, std::fabs(taps[i]));
+    uint32_t groups = 0;
+    for (int i = 0; i < ntap; i++) {
+        if (std::fabs(taps[i]) < hmax * 0x1p-40f) taps[i] = 0.0f;
+        if (taps[i] != 0.0f) groups |= 1u << (i >> 2);
+    }
     c->mode = (uint32_t)p->mode;
     c->ntap = (uint32_t)ntap;
     c->ntap8 = (uint32_t)((ntap + 7) & ~7);
+    c->tap_groups = groups;
     c->dphi1 = dphi_of(p->f_shift_hz + f_bc);
     c->dphi2 = dphi_of(f_bc);
     c->wf_cal_lin = (float)std::pow(10.0, p->wf_cal_db / 10.0);
