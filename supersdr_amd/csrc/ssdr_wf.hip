@@ -113,21 +113,29 @@ SSDR_DEV void stage_const(f32x2 (&z)[32])
 
 // stages 6..10 (T = s - 6) on x[j] = a[32 j + lane]; twiddle W_1024[(lane + 32 (j mod 2^T)) << (4 - T)].
 // Every butterfly takes the general form here, also where a lane's twiddle happens to be 1 or -j.
-template <int T>
-SSDR_DEV void stage_lane(f32x2 (&z)[32], const f32x2 *tw_lane)
+// The twiddles are passed in registers: the caller loads them from the LDS table one stage (or half a
+// stage) AHEAD of their use, so that no butterfly ever waits for an LDS round trip.
+template <int T, int JL0, int NJL>
+SSDR_DEV void stage_lane(f32x2 (&z)[32], const f32x2 (&w)[NJL])
 {
     constexpr int half = 1 << T;
-    constexpr int off = 32 * (half - 1);
 #pragma unroll
-    for (int jl = 0; jl < half; jl++) {
-        const f32x2 w = tw_lane[off + jl * 32];
+    for (int q = 0; q < NJL; q++) {
+        const int jl = JL0 + q;
 #pragma unroll
         for (int blk = 0; blk < 32; blk += 2 * half) {
             const int i = blk + jl, j = i + half;
-            bfly(z[i], z[j], w.x, w.y);
+            bfly(z[i], z[j], w[q].x, w[q].y);
         }
-        if ((jl & 3) == 3) SCHED_FENCE();
     }
+}
+
+template <int T, int JL0, int NJL>
+SSDR_DEV void load_tw(f32x2 (&w)[NJL], const f32x2 *tw_lane)
+{
+    constexpr int off = 32 * ((1 << T) - 1);
+#pragma unroll
+    for (int q = 0; q < NJL; q++) w[q] = tw_lane[off + (JL0 + q) * 32];
 }
 
 // Per-lane LDS base addresses are all cheap functions of the lane id.  Left alone, the compiler keeps
@@ -156,19 +164,58 @@ SSDR_DEV void wave_lds_sync()
 //     byte = lut[seg].base + (p >= lut[seg].next)
 // p is clamped to [2^-37, 2^50] (below T[1] / above T[255]).  The table sits in LDS such that the
 // segment index scaled by the entry size is the LDS address.
-SSDR_DEV uint32_t quantise(float p, const unsigned char *lut0, uint32_t mask)
+// Split in two so that the table reads of a whole batch are in flight together (and the next batch's are
+// issued before this batch's compares): quant_addr -> load -> quant_result.
+SSDR_DEV float quant_clamp(float p) { return __builtin_amdgcn_fmed3f(p, SSDR_LUT_PLO, SSDR_LUT_PHI); }
+SSDR_DEV uint32_t quant_addr(float pc, uint32_t mask)
 {
-    const float pc = __builtin_amdgcn_fmed3f(p, SSDR_LUT_PLO, SSDR_LUT_PHI);
-    uint32_t off;
 #if SSDR_LUT_BITS == 4
-    // one full-rate op: SDWA picks the upper half-word, the mask (0xFFF8) drops the low mantissa bits
+    uint32_t off;      // one full-rate op: SDWA picks the upper half-word, the mask (0xFFF8) drops the low mantissa bits
     asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
         : "=v"(off) : "v"(__float_as_uint(pc)), "v"(mask));
+    return off;
 #else
-    off = (__float_as_uint(pc) >> (SSDR_LUT_SHIFT - 3)) & mask;          // mask = ~7
+    return (__float_as_uint(pc) >> (SSDR_LUT_SHIFT - 3)) & mask;            // mask = ~7
 #endif
-    const uint2 e = *reinterpret_cast<const uint2 *>(lut0 + off);
-    return e.x + ((pc >= __uint_as_float(e.y)) ? 1u : 0u);
+}
+SSDR_DEV uint32_t quant_result(float pc, uint2 e) { return e.x + ((pc >= __uint_as_float(e.y)) ? 1u : 0u); }
+SSDR_DEV uint32_t quantise(float p, const unsigned char *lut0, uint32_t mask)
+{
+    const float pc = quant_clamp(p);
+    return quant_result(pc, *reinterpret_cast<const uint2 *>(lut0 + quant_addr(pc, mask)));
+}
+
+// power + quantiser for the 32 bins of a lane, in 4 batches of 8 (bins 0-7, 16-23, 8-15, 24-31) with the table
+// reads software-pipelined one batch ahead and no LDS store in between, so nothing orders one look-up behind
+// another.  `sink(j, byte_j, byte_{j+16})` receives the results pairwise (j = 0..15).
+template <typename Sink>
+SSDR_DEV void quantise32(const f32x2 (&z)[32], float cal, const unsigned char *lut0, uint32_t mask, Sink sink)
+{
+    constexpr int ORDER[4] = {0, 16, 8, 24};
+    float pc[2][8];
+    uint2 e[2][8];
+    uint32_t lo[8];
+#pragma unroll
+    for (int b = 0; b < 5; b++) {
+        if (b < 4) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int j = ORDER[b] + i;
+                pc[b & 1][i] = quant_clamp(fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal);
+                e[b & 1][i] = *reinterpret_cast<const uint2 *>(lut0 + quant_addr(pc[b & 1][i], mask));
+            }
+        }
+        SCHED_FENCE();
+        if (b > 0) {
+            const int pb = b - 1;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t r = quant_result(pc[pb & 1][i], e[pb & 1][i]);
+                if ((pb & 1) == 0) lo[i] = r;                       // bins j (batch 0 or 2)
+                else sink(ORDER[pb - 1] + i, lo[i], r);             // bins j+16 arrive one batch later
+            }
+        }
+    }
 }
 
 SSDR_DEV void load_line(const uint32_t *__restrict__ src /* + lane */, uint32_t (&raw)[32])
@@ -185,11 +232,15 @@ SSDR_DEV void window_line(const uint32_t (&raw)[32], const unsigned char *smem, 
     const int ll = opaque(l);
     const float *win_up = reinterpret_cast<const float *>(smem + LDS_WIN) + ll;
     const float *win_dn = reinterpret_cast<const float *>(smem + LDS_WIN) - ll;
+    // all 32 window values first: their LDS latency hides under the HBM latency of the line's samples
+    float w[32];
+#pragma unroll
+    for (int r = 0; r < 32; r++) w[r] = (r < 16) ? win_up[32 * r] : win_dn[32 * (32 - r)];
+    SCHED_FENCE();
 #pragma unroll
     for (int r = 0; r < 32; r++) {
-        const float w = (r < 16) ? win_up[32 * r] : win_dn[32 * (32 - r)];
         const f32x2 x = {(float)(int16_t)(raw[r] & 0xFFFFu), (float)((int32_t)raw[r] >> 16)};
-        z[brev5(r)] = x * w;
+        z[brev5(r)] = x * w[r];
         if ((r & 7) == 7) SCHED_FENCE();
     }
 }
@@ -222,15 +273,33 @@ SSDR_DEV void fft_line(f32x2 (&z)[32], const unsigned char *smem, float *xch_wav
     for (int j = 0; j < 32; j++) z[j].y = xch[j * XPAD + lx];
     wave_lds_sync();
 
-    SCHED_FENCE();
+    // stages 6..10.  Twiddle loads are issued well ahead of the butterflies that use them: stages 6-8 (7 values)
+    // right behind the transpose reads, stage 9 under stage 8's arithmetic, stage 10 in two halves under stage 9
+    // and under its own first half.
     const f32x2 *s_tw_lane = reinterpret_cast<const f32x2 *>(smem + LDS_TW) + opaque(l);
-    stage_lane<0>(z, s_tw_lane);
-    stage_lane<1>(z, s_tw_lane);
-    stage_lane<2>(z, s_tw_lane);
+    f32x2 w0[1], w1[2], w2[4];
+    load_tw<0, 0, 1>(w0, s_tw_lane);
+    load_tw<1, 0, 2>(w1, s_tw_lane);
+    load_tw<2, 0, 4>(w2, s_tw_lane);
     SCHED_FENCE();
-    stage_lane<3>(z, s_tw_lane);
+    stage_lane<0, 0, 1>(z, w0);
+    stage_lane<1, 0, 2>(z, w1);
+    f32x2 w3[8];
+    load_tw<3, 0, 8>(w3, s_tw_lane);
     SCHED_FENCE();
-    stage_lane<4>(z, s_tw_lane);
+    stage_lane<2, 0, 4>(z, w2);
+    SCHED_FENCE();
+    f32x2 w4a[8];
+    load_tw<4, 0, 8>(w4a, s_tw_lane);
+    SCHED_FENCE();
+    stage_lane<3, 0, 8>(z, w3);
+    SCHED_FENCE();
+    f32x2 w4b[8];
+    load_tw<4, 8, 8>(w4b, s_tw_lane);
+    SCHED_FENCE();
+    stage_lane<4, 0, 8>(z, w4a);
+    SCHED_FENCE();
+    stage_lane<4, 8, 8>(z, w4b);
     SCHED_FENCE();
 }
 
@@ -322,21 +391,16 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
 
         fft_line(z, smem, xch_wave, h, l);
         {
-            int16_t *x16 = reinterpret_cast<int16_t *>(xch_wave + opaque(h) * XCH_FLOATS) + opaque(l);
             if (AVG) {
+                quantise32(z, cal, lut0, mask_fff8, [&](int j, uint32_t q0, uint32_t q1) { acc[j] += q0 + (q1 << 16); });
+            } else {
+                uint32_t q[16];                                     // bins j | j+16, written out after the last look-up
+                quantise32(z, cal, lut0, mask_fff8, [&](int j, uint32_t q0, uint32_t q1) { q[j] = q0 | (q1 << 16); });
+                int16_t *x16 = reinterpret_cast<int16_t *>(xch_wave + opaque(h) * XCH_FLOATS) + opaque(l);
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
-                    const float p0 = fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal;
-                    const float p1 = fmaf(z[j + 16].x, z[j + 16].x, z[j + 16].y * z[j + 16].y) * cal;
-                    acc[j] += quantise(p0, lut0, mask_fff8) + (quantise(p1, lut0, mask_fff8) << 16);
-                    if ((j & 3) == 3) SCHED_FENCE();
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 32; j++) {
-                    const float p = fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal;
-                    x16[32 * ((j + 16) & 31)] = (int16_t)quantise(p, lut0, mask_fff8);
-                    if ((j & 7) == 7) SCHED_FENCE();
+                    x16[32 * (j + 16)] = (int16_t)(q[j] & 0xFFFFu);
+                    x16[32 * j] = (int16_t)(q[j] >> 16);
                 }
             }
         }
@@ -397,21 +461,16 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
             fft_line(z, smem, xch_wave, h, l);
 
             // |X|^2 -> 1-dB byte; bin k = 32 j + l lands at fftshifted position 32 ((j+16)&31) + l
-            int16_t *x16 = reinterpret_cast<int16_t *>(xch_wave + opaque(h) * XCH_FLOATS) + opaque(l);
             if (AVG) {
+                quantise32(z, cal, lut0, mask_fff8, [&](int j, uint32_t q0, uint32_t q1) { acc[j] += q0 + (q1 << 16); });
+            } else {
+                uint32_t q[16];                                     // bins j | j+16, written out after the last look-up
+                quantise32(z, cal, lut0, mask_fff8, [&](int j, uint32_t q0, uint32_t q1) { q[j] = q0 | (q1 << 16); });
+                int16_t *x16 = reinterpret_cast<int16_t *>(xch_wave + opaque(h) * XCH_FLOATS) + opaque(l);
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
-                    const float p0 = fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal;
-                    const float p1 = fmaf(z[j + 16].x, z[j + 16].x, z[j + 16].y * z[j + 16].y) * cal;
-                    acc[j] += quantise(p0, lut0, mask_fff8) + (quantise(p1, lut0, mask_fff8) << 16);
-                    if ((j & 3) == 3) SCHED_FENCE();
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < 32; j++) {
-                    const float p = fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal;
-                    x16[32 * ((j + 16) & 31)] = (int16_t)quantise(p, lut0, mask_fff8);
-                    if ((j & 7) == 7) SCHED_FENCE();
+                    x16[32 * (j + 16)] = (int16_t)(q[j] & 0xFFFFu);
+                    x16[32 * j] = (int16_t)(q[j] >> 16);
                 }
             }
 #endif
