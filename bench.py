@@ -108,6 +108,8 @@ def main():
     rank, local_rank, world = env_rank()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+    if "SSDR_BENCH_DEVICE" in os.environ:          # test hook: several ranks on one GPU (exercises the N>1 control flow on a 1-GPU box)
+        local_rank = int(os.environ["SSDR_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     rdv = Rendezvous("nccl", torch.device("cuda", local_rank))     # barrier + max-over-ranks only
 
@@ -199,7 +201,7 @@ def main():
                                 "wf": "4096 channels batched 1024-pt FFT + log-mag waterfall only, BASELINE configs[1]",
                                 "mixed": "65536 channels mixed AM/USB/LSB/NBFM + 10x time binning, BASELINE configs[3]"}[args.workload],
                    "channels_per_gpu": channels, "superframes_per_step": sframes, "averaging_n": n_avg,
-                   "sharding": "channel blocks per GPU, no collectives"},
+                   "sharding": "channel blocks per GPU, no collectives", "rendezvous": rdv.backend if world > 1 else "none"},
         "roofline": roof(dom),
     }
     if "ssdr_wf_kernel" in stages:

@@ -33,10 +33,21 @@ class Rendezvous:
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            kw = {}
-            if backend == "nccl" and device is not None:
-                kw["device_id"] = device
-            dist.init_process_group(backend=backend, **kw)
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on these hosts
+            try:
+                kw = {}
+                if backend == "nccl" and device is not None:
+                    kw["device_id"] = device
+                dist.init_process_group(backend=backend, **kw)
+                if backend == "nccl":
+                    dist.barrier()                    # forces communicator creation now, not inside the timed region
+            except Exception:
+                # The rendezvous carries no data (a barrier and two scalars): if RCCL cannot come up, gloo does the
+                # same job over TCP and the measurement is unaffected.
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                self.backend = backend = "gloo"
+                dist.init_process_group(backend="gloo")
             self._dist = dist
 
     def barrier(self):
