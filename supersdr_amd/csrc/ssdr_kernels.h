@@ -7,14 +7,8 @@
 #ifndef SSDR_WF_BLOCK
 #define SSDR_WF_BLOCK 512                    // two workgroups per CU: 16 waves = 4 per SIMD, <= 128 VGPRs
 #endif
-#ifndef SSDR_WF_PREFETCH
-#define SSDR_WF_PREFETCH 0                   // 1: register software pipeline (needs ~32 more VGPRs: 3 waves/SIMD)
-#endif
 #ifndef SSDR_WF_WAVES_PER_EU
 #define SSDR_WF_WAVES_PER_EU 4
-#endif
-#ifndef SSDR_WF_LUT_GLOBAL
-#define SSDR_WF_LUT_GLOBAL 0
 #endif
 #ifndef SSDR_WF_ABLATE
 #define SSDR_WF_ABLATE 0                     // profiling ablations only (1 memory-only, 2 no loads, 3 no stores)

@@ -347,93 +347,11 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
     const int h = lane >> 5, l = lane & 31;
     float *xch_wave = reinterpret_cast<float *>(smem + LDS_XCH) + wave * 2 * XCH_FLOATS;      // wave-uniform
     const uint32_t mask_fff8 = (SSDR_LUT_BITS == 4) ? 0xFFF8u : ~7u;
-#if SSDR_WF_LUT_GLOBAL      // table through the vector L1 (the TA path is nearly idle) instead of LDS
-    const unsigned char *lut0 = reinterpret_cast<const unsigned char *>(a.lut) - LDS_LUT0;
-#else
     const unsigned char *lut0 = smem;
-#endif
     const uint32_t n_pairs = (a.n_ch + 1) >> 1;
     const uint32_t n_items = n_pairs * a.n_groups;
     const uint32_t wave_stride = gridDim.x * WAVES;
 
-#if SSDR_WF_PREFETCH
-    // Software pipeline over the flattened (item, line) sequence of this wave: the next line's 32 loads per
-    // lane are issued as soon as the current line has been converted to float and stay in flight under the
-    // whole FFT, so every wave keeps 8 KB of HBM reads outstanding all the time (memory-level parallelism
-    // is what the un-pipelined loop lacks: its loads are in flight only ~15 % of the time).
-    uint32_t item = blockIdx.x * WAVES + wave;
-    if (item >= n_items) return;
-    WfItem it = wf_item(a, item, n_pairs, h);
-    uint32_t line = it.l0;
-    float cal = a.consts[it.ch].wf_cal_lin;
-    uint32_t raw[32];
-    load_line(a.iq + (uint64_t)it.ch * a.ch_stride + (uint64_t)line * SSDR_NFFT + l, raw);
-    uint32_t acc[AVG ? 16 : 1];
-#pragma unroll
-    for (int j = 0; j < (AVG ? 16 : 1); j++) acc[j] = 0;
-
-    for (;;) {
-        f32x2 z[32];
-        window_line(raw, smem, l, z);
-        SCHED_FENCE();
-
-        const bool group_end = (line + 1 == it.l1);
-        uint32_t nitem = item, nline = line + 1;
-        WfItem nit = it;
-        if (group_end) {
-            nitem = item + wave_stride;
-            if (nitem < n_items) { nit = wf_item(a, nitem, n_pairs, h); nline = nit.l0; }
-        }
-        const bool has_next = !group_end || nitem < n_items;
-        if (has_next)
-            load_line(a.iq + (uint64_t)nit.ch * a.ch_stride + (uint64_t)nline * SSDR_NFFT + opaque(l), raw);
-        SCHED_FENCE();
-
-        fft_line(z, smem, xch_wave, h, l);
-        {
-            if (AVG) {
-                quantise32(z, cal, lut0, mask_fff8, [&](int j, uint32_t q0, uint32_t q1) { acc[j] += q0 + (q1 << 16); });
-            } else {
-                uint32_t q[16];                                     // bins j | j+16, written out after the last look-up
-                quantise32(z, cal, lut0, mask_fff8, [&](int j, uint32_t q0, uint32_t q1) { q[j] = q0 | (q1 << 16); });
-                int16_t *x16 = reinterpret_cast<int16_t *>(xch_wave + opaque(h) * XCH_FLOATS) + opaque(l);
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    x16[32 * (j + 16)] = (int16_t)(q[j] & 0xFFFFu);
-                    x16[32 * j] = (int16_t)(q[j] >> 16);
-                }
-            }
-        }
-        if (group_end) {
-            float *xch = xch_wave + opaque(h) * XCH_FLOATS;
-            if (AVG) {
-                int16_t *x16 = reinterpret_cast<int16_t *>(xch) + opaque(l);
-#pragma unroll
-                for (int j = 0; j < 16; j++) {
-                    x16[32 * (j + 16)] = (int16_t)(acc[j] & 0xFFFFu);
-                    x16[32 * j] = (int16_t)(acc[j] >> 16);
-                    acc[j] = 0;
-                }
-            }
-            wave_lds_sync();
-            const u32x4 *x128 = reinterpret_cast<const u32x4 *>(xch);
-            int16_t *dst = it.complete ? a.out + ((uint64_t)it.grp * a.n_ch + it.ch) * SSDR_NFFT
-                                       : a.acc_out + (uint64_t)it.ch * SSDR_NFFT;
-            const int16_t *cin = a.acc_in + (uint64_t)it.ch * SSDR_NFFT;
-            const int lo = opaque(l);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                u32x4 v = x128[q * 32 + lo];
-                if (AVG && it.carry_in) v += reinterpret_cast<const u32x4 *>(cin)[q * 32 + lo];
-                if (it.ch_ok) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst) + q * 32 + lo);
-            }
-            wave_lds_sync();
-            if (!has_next) break;
-            cal = a.consts[nit.ch].wf_cal_lin;
-        }
-        item = nitem; it = nit; line = nline;
-    }
-#else
     for (uint32_t item = blockIdx.x * WAVES + wave; item < n_items; item += wave_stride) {
         const WfItem it = wf_item(a, item, n_pairs, h);
         const float cal = a.consts[it.ch].wf_cal_lin;
@@ -499,7 +417,6 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
         }
         wave_lds_sync();
     }
-#endif
 }
 
 // exhaustive quantiser self-test: every positive finite float against a binary search over T[]
