@@ -94,8 +94,11 @@ def cpu_baseline(workload, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--spinup", type=float, default=1.5,
+                    help="seconds of untimed steps before the W warmup steps: an idle MI355X sits at ~100 MHz and takes "
+                         "~0.5 s of load to settle at its sustained clock (profiles/README.md, clock ramp)")
     ap.add_argument("--workload", default="full", choices=sorted(WORKLOADS))
     ap.add_argument("--channels", type=int, default=0, help="override channels per GPU")
     ap.add_argument("--superframes", type=int, default=0, help="override superframes per step")
@@ -140,6 +143,11 @@ def main():
 
     barrier = rdv.barrier
 
+    t_spin = time.perf_counter()            # clock spin-up from the idle state, then the W warmup steps proper
+    while time.perf_counter() - t_spin < args.spinup:
+        for _ in range(8):
+            step()
+        eng.sync()
     for _ in range(args.warmup):
         step()
     eng.sync()
@@ -201,6 +209,7 @@ def main():
                                 "wf": "4096 channels batched 1024-pt FFT + log-mag waterfall only, BASELINE configs[1]",
                                 "mixed": "65536 channels mixed AM/USB/LSB/NBFM + 10x time binning, BASELINE configs[3]"}[args.workload],
                    "channels_per_gpu": channels, "superframes_per_step": sframes, "averaging_n": n_avg,
+                   "clock_spinup_s": args.spinup,
                    "sharding": "channel blocks per GPU, no collectives", "rendezvous": rdv.backend if world > 1 else "none"},
         "roofline": roof(dom),
     }

@@ -3,14 +3,15 @@
 #   tools/profile_round.sh r01        (run through gpurun; results under gpurun_out/prof_<tag>/)
 TAG=${1:-r01}; OUT=gpurun_out/prof_$TAG
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT; mkdir -p $OUT
-BENCH="python bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python bench.py --no-cpu-baseline"        # defaults: 100 timed steps after 1.5 s clock spin-up + 3 warm-up steps
+PMCBENCH="python bench.py --steps 10 --warmup 2 --spinup 0 --no-cpu-baseline"    # counters are per launch; clocks do not matter
 rocprofv3 --kernel-trace --stats -d $OUT -o trace -- $BENCH > $OUT/trace.log 2>&1
-python tools/rocpd_stats.py $OUT/trace_results.db 2 > $OUT/kernel_stats.txt
+python tools/rocpd_stats.py $OUT/trace_results.db -100 > $OUT/kernel_stats.txt
 # PMC: separate passes, kernel-trace only (TCC has 4 slots: FETCH_SIZE takes 3, WRITE_SIZE 2)
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- $BENCH > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- $BENCH > $OUT/write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES --output-format csv -d $OUT -o sq1 -- $BENCH > $OUT/sq1.log 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT -o sq2 -- $BENCH > $OUT/sq2.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT -o fetch -- $PMCBENCH > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT -o write -- $PMCBENCH > $OUT/write.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAVES --output-format csv -d $OUT -o sq1 -- $PMCBENCH > $OUT/sq1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $OUT -o sq2 -- $PMCBENCH > $OUT/sq2.log 2>&1
 python tools/pmc_summary.py $OUT/fetch_counter_collection.csv $OUT/write_counter_collection.csv $OUT/sq1_counter_collection.csv $OUT/sq2_counter_collection.csv > $OUT/pmc_summary.txt
 $BENCH 2>/dev/null | tail -1 > $OUT/bench_unprofiled.json
 grep '"metric"' $OUT/trace.log > $OUT/bench_under_trace.json
