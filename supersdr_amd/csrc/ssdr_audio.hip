@@ -15,7 +15,7 @@
 //   * loads: 2 x 16 B per lane, the whole 2 KB frame contiguous per wave
 //   * the mixed samples go to LDS once (80 B lane stride: ds_write_b128/ds_read_b128
 //     conflict-free); the FIR walks a 16-sample register window per 8-tap block, taps
-//     come through the scalar cache (wave-uniform), 128 FMAs per 4 LDS reads
+//     are staged in LDS once per call and read back as broadcasts, 128 FMAs per 6 LDS reads
 //   * the NCO is a block NCO: one polynomial sincos per 8 samples, complex rotations in between
 //   * the recurrences along time are exact or order-defined scans across lanes, done with DPP
 //     (row_shr / row_bcast / wave_shr: no LDS, no address arithmetic): AM DC block = affine scan,
@@ -145,6 +145,7 @@ SSDR_DEV void fir_taps(const float *h, const float2 (&A)[8], const float2 (&B)[8
 __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioArgs a)
 {
     __shared__ __attribute__((aligned(16))) float2 s_z[NOCT * OCT];      // 6400 B
+    __shared__ __attribute__((aligned(16))) float s_taps[SSDR_NTAP_MAX + 8];   // + one block of padding for odd block counts
     constexpr float DC_APOW[8] = SSDR_DC_APOW_INIT;
 
     const int l = threadIdx.x;
@@ -159,7 +160,12 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
     const float c0 = kc.agc_c0, c1 = kc.agc_c1, knee = kc.agc_knee, d8 = kc.agc_delta8;
     const uint32_t K = kc.hang_frames;
     const float cal = kc.smeter_cal_db;
-    const float *taps = a.taps + (size_t)ch * SSDR_NTAP_MAX;
+    {   // the channel's taps go to LDS once; the FIR reads them back as broadcasts
+        const float2 t = reinterpret_cast<const float2 *>(a.taps + (size_t)ch * SSDR_NTAP_MAX)[l];
+        s_taps[2 * l] = t.x;
+        s_taps[2 * l + 1] = t.y;
+        if (l < 8) s_taps[SSDR_NTAP_MAX + l] = 0.0f;
+    }
     float cs1, ss1, cs2, ss2;
     step_phasor(dphi1, cs1, ss1);
     step_phasor(dphi2, cs2, ss2);
@@ -197,24 +203,33 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
         store_oct(s_z, HOCT + l, A);
         lds_sync();
 
-        // 2. FIR: y[n] = sum_k h[k] z1[n-k], k ascending, fma chain from zero
+        // 2. FIR: y[n] = sum_k h[k] z1[n-k], k ascending, fma chain from zero.  Blocks of 8 taps go in pairs with the
+        //    two register octets swapping roles (newer, older) -> (older, newer), so no window is ever copied.
         float yr[8], yi[8];
 #pragma unroll
         for (int j = 0; j < 8; j++) { yr[j] = 0.0f; yi[j] = 0.0f; }
-        uint32_t a_blk = 0;                                      // A currently holds octet (l - a_blk)
-        for (uint32_t b = 0; b < nblk; b++) {
-            const uint32_t m2 = (tap_groups >> (2 * b)) & 3u;    // wave-uniform
-            if (m2 == 0) continue;
-            if (a_blk != b) load_oct(s_z, HOCT + l - (int)b, A);
-            load_oct(s_z, HOCT + l - 1 - (int)b, B);
-            float h[8];
-#pragma unroll
-            for (int kk = 0; kk < 8; kk++) h[kk] = taps[8 * b + kk];
-            if (m2 & 1u) fir_taps<0, 4>(h, A, B, yr, yi);
-            if (m2 & 2u) fir_taps<4, 4>(h, A, B, yr, yi);
-#pragma unroll
-            for (int j = 0; j < 8; j++) A[j] = B[j];
-            a_blk = b + 1;
+        uint32_t a_oct = 0;                                      // A currently holds octet (l - a_oct)
+        for (uint32_t b = 0; b < nblk; b += 2) {
+            const uint32_t m4 = (tap_groups >> (2 * b)) & 15u;   // wave-uniform
+            if (m4 == 0) continue;
+            const float4 *hq = reinterpret_cast<const float4 *>(s_taps + 8 * b);
+            if (m4 & 3u) {
+                if (a_oct != b) load_oct(s_z, HOCT + l - (int)b, A);
+                load_oct(s_z, HOCT + l - 1 - (int)b, B);
+                const float4 h0 = hq[0], h1 = hq[1];             // same address in all lanes: LDS broadcast
+                const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                if (m4 & 1u) fir_taps<0, 4>(h, A, B, yr, yi);
+                if (m4 & 2u) fir_taps<4, 4>(h, A, B, yr, yi);
+            }
+            if (m4 & 12u) {
+                if (!(m4 & 3u)) load_oct(s_z, HOCT + l - 1 - (int)b, B);
+                load_oct(s_z, HOCT + l - 2 - (int)b, A);
+                const float4 h0 = hq[2], h1 = hq[3];
+                const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                if (m4 & 4u) fir_taps<0, 4>(h, B, A, yr, yi);
+                if (m4 & 8u) fir_taps<4, 4>(h, B, A, yr, yi);
+                a_oct = b + 2;
+            }
         }
 
         // 3. power, demodulation
