@@ -57,27 +57,34 @@ SSDR_DEV float from_prev_lane(float lane0_value, float x) { return dpp<0x138, 0x
 
 // Inclusive scan over the 64 lanes in six steps: Kogge-Stone inside each row of 16 (row_shr 1,2,4,8),
 // then lane 15 of rows 0/2 into rows 1/3 (row_bcast:15), then lane 31 into rows 2,3 (row_bcast:31).
-// STEP(ctrl, rowmask) is expanded once per step; the twin walks the same six steps.
-#define SSDR_SCAN6(STEP) STEP(0x111, 0xF) STEP(0x112, 0xF) STEP(0x114, 0xF) STEP(0x118, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
+// STEP(dpp control, row mask) is expanded once per step; the twin walks the same six steps.
+// Each step is ONE instruction: the DPP operand is the scanned register itself, read from the source lane
+// before anything is written; lanes whose source is out of range or masked off are not written and keep
+// their value (which is what combining with the identity would give).  "s_nop 1": a VALU write needs two
+// wait states before a DPP read of the same register.
+#define SSDR_SCAN6(STEP) STEP("row_shr:1", "0xf") STEP("row_shr:2", "0xf") STEP("row_shr:4", "0xf") STEP("row_shr:8", "0xf") \
+                         STEP("row_bcast:15", "0xa") STEP("row_bcast:31", "0xc")
+#define SSDR_DPP(C, M) " " C " row_mask:" M " bank_mask:0xf"
 
 SSDR_DEV float scan_max(float x)
 {
-#define STEP(C, M) x = vmax(x, dpp<C, M>(x, x));
+#define STEP(C, M) asm("s_nop 1\n\tv_max_f32_dpp %0, %0, %0" SSDR_DPP(C, M) : "+v"(x));
     SSDR_SCAN6(STEP)
 #undef STEP
     return x;
 }
 SSDR_DEV float scan_sum(float x)
 {
-#define STEP(C, M) x = x + dpp<C, M>(0.0f, x);
+#define STEP(C, M) asm("s_nop 1\n\tv_add_f32_dpp %0, %0, %0" SSDR_DPP(C, M) : "+v"(x));
     SSDR_SCAN6(STEP)
 #undef STEP
     return x;
 }
-// affine maps m -> A m + B: (A, B) of a lane := (A, B) of the lane composed after its source's
+// affine maps m -> A m + B: (A, B) of a lane := (A, B) of the lane composed after its source's:
+// B = fma(A, B_src, B), then A = A * A_src
 SSDR_DEV void scan_affine(float &A, float &B)
 {
-#define STEP(C, M) { const float Al = dpp<C, M>(1.0f, A), Bl = dpp<C, M>(0.0f, B); B = fmaf(A, Bl, B); A = A * Al; }
+#define STEP(C, M) asm("s_nop 1\n\tv_fmac_f32_dpp %1, %1, %0" SSDR_DPP(C, M) "\n\tv_mul_f32_dpp %0, %0, %0" SSDR_DPP(C, M) : "+v"(A), "+v"(B));
     SSDR_SCAN6(STEP)
 #undef STEP
 }
