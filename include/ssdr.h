@@ -144,6 +144,16 @@ typedef struct ssdr_play_chan {
 } ssdr_play_chan;
 int ssdr_run_playbuffer(ssdr_ctx *ctx, const ssdr_play_chan *chans, int16_t *out, int out_is_device);
 
+/* kiwi_sound.KIWI_RATE as announced by the server ("audio_init ... audio_rate=", utils_supersdr.py:988-994):
+ * SSDR_RATE (12000, default) or SSDR_RATE_WIDE (20250, three-channel KiwiSDRs).  With 20250 SAMPLE_RATIO =
+ * 48000/20250 is fractional and play_buffer takes its resample_poly(popped, 64, 27, padtype="line")[:-1] branch
+ * (:1000-1001, 1125-1126): ssdr_run_playbuffer then writes int16 [n_ch][n_frames*1213][2], each frame resampled
+ * on its own.  ssdr_playbuffer_frame_len returns the stereo samples per frame of the selected path
+ * (2048 or 1213 = int(512 * SAMPLE_RATIO), the OutputStream blocksize of :1211). */
+#define SSDR_RATE_WIDE 20250
+int ssdr_set_kiwi_rate(ssdr_ctx *ctx, uint32_t kiwi_rate);
+int ssdr_playbuffer_frame_len(ssdr_ctx *ctx, uint32_t *samples_per_frame);
+
 /* KiwiSDRStream._process_aud, IQ branch (kiwi/client.py:384-389, 443-454): n_frames SND bodies per channel
  * (each 7 B flags/seq/smeter + 10 B GPS + 512 big-endian I,Q pairs = 2065 B, layout [n_ch][n_frames][2065],
  * host memory) become the current input batch, as ssdr_push_iq would; rssi_out (may be NULL) receives

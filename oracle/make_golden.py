@@ -153,6 +153,42 @@ def gold_playbuffer(U):
         case += 1
     out["count"] = np.int64(case)
     out["n_tap"] = np.int64(U.filtering(6000, 48000).n_tap)
+
+    # 20.25 kHz KiwiSDRs: SAMPLE_RATIO = 48000/20250 is fractional -> resample_poly(popped, 64, 27, padtype="line")[:-1]
+    # (utils_supersdr.py:994, 1000-1001, 1125-1126); blocksize int(512 * SAMPLE_RATIO) = 1213 (:1211)
+    case = 0
+    for volume, balance in ((100, 0.0), (150, 0.3), (60, -1.0)):
+        snd = U.kiwi_sound.__new__(U.kiwi_sound)
+        snd.audio_buffer = queue.Queue()
+        snd.volume = volume
+        snd.late_flag = False
+        snd.KIWI_RATE = 20250
+        snd.SAMPLE_RATIO = snd.AUDIO_RATE / snd.KIWI_RATE
+        gcd = np.gcd(snd.KIWI_RATE, snd.AUDIO_RATE)
+        snd.n_low, snd.n_high = int(snd.KIWI_RATE / gcd), int(snd.AUDIO_RATE / gcd)
+        snd.audio_balance = balance
+        snd.rssi = -80
+        snd.mute_counter = 0
+        snd.max_rssi_before_mute = -20
+        snd.muting_delay = 15
+        snd.audio_rec = types.SimpleNamespace(recording_flag=False)
+        frames = (rng.standard_normal((3, 512)) * 9000).clip(-32768, 32767).astype(np.int16)
+        frames[1, 200:210] = 32767
+        frames[2, 0], frames[2, -1] = -30000, 30000      # a steep line through the end points
+        n_out = int(512 * snd.SAMPLE_RATIO)
+        outs = []
+        for f in range(3):
+            snd.audio_buffer.put(frames[f])
+            o = np.zeros((n_out, 2), np.int16)
+            with np.errstate(invalid="ignore"):
+                snd.play_buffer(o, n_out, None, None)
+            outs.append(o.copy())
+        out["rs_in_%d" % case] = frames
+        out["rs_cfg_%d" % case] = np.array([volume, balance], np.float64)
+        out["rs_out_%d" % case] = np.stack(outs)
+        case += 1
+    out["rs_count"] = np.int64(case)
+    out["rs_ratio"] = np.array([64, 27], np.int64)
     return out
 
 

@@ -68,6 +68,8 @@ _SIGS = {
     "ssdr_sync": (C.c_int, [_P]),
     "ssdr_run_db2col": (C.c_int, [_P, C.POINTER(Db2colChan), _P, C.c_int]),
     "ssdr_run_playbuffer": (C.c_int, [_P, C.POINTER(PlayChan), _P, C.c_int]),
+    "ssdr_set_kiwi_rate": (C.c_int, [_P, C.c_uint32]),
+    "ssdr_playbuffer_frame_len": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "ssdr_push_iq_wire": (C.c_int, [_P, _P, C.c_uint32, _P]),
     "ssdr_adpcm_decode": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "ssdr_wf_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32)]),

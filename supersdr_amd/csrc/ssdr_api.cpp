@@ -2,6 +2,7 @@
 // device buffers, the per-channel state and the stream; launches the HIP kernels.
 // Never throws, never aborts: every failure is a negative return code.
 #include "ssdr_kernels.h"
+#include "ssdr_resample_taps.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -68,7 +69,8 @@ struct ssdr_ctx {
     float *d_color = nullptr;
     size_t color_lines = 0;
     ssdr_play_chan *d_play = nullptr;
-    double *d_play_taps = nullptr, *d_play_hist = nullptr;
+    double *d_play_taps = nullptr, *d_play_hist = nullptr, *d_play_rs_taps = nullptr;
+    uint32_t kiwi_rate = SSDR_RATE;         // kiwi_sound.KIWI_RATE: 12000, or 20250 (fractional SAMPLE_RATIO path)
     int16_t *d_play_out = nullptr;
     size_t play_frames = 0;
     uint8_t *d_wire = nullptr;
@@ -148,7 +150,7 @@ void ssdr_destroy(ssdr_ctx *c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
-                    c->d_play_taps, c->d_play_hist, c->d_play_out, c->d_wire, c->d_wire_rssi};
+                    c->d_play_taps, c->d_play_hist, c->d_play_rs_taps, c->d_play_out, c->d_wire, c->d_wire_rssi};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -656,6 +658,20 @@ int ssdr_run_db2col(ssdr_ctx *c, ssdr_db2col_chan *chans, float *color_out, int 
     return SSDR_OK;
 }
 
+int ssdr_set_kiwi_rate(ssdr_ctx *c, uint32_t kiwi_rate)
+{
+    if (!c || (kiwi_rate != SSDR_RATE && kiwi_rate != SSDR_RATE_WIDE)) return SSDR_EINVAL;
+    c->kiwi_rate = kiwi_rate;
+    return SSDR_OK;
+}
+
+int ssdr_playbuffer_frame_len(ssdr_ctx *c, uint32_t *samples_per_frame)
+{
+    if (!c || !samples_per_frame) return SSDR_EINVAL;
+    *samples_per_frame = (c->kiwi_rate == SSDR_RATE) ? 2048u : (uint32_t)SSDR_RS_OUT_PER_FRAME;   // int(512 * SAMPLE_RATIO) (:1211)
+    return SSDR_OK;
+}
+
 int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, int out_is_device)
 {
     if (!c || !chans) return SSDR_EINVAL;
@@ -663,17 +679,21 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
     HIP_TRY(hipSetDevice(c->device));
     { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     const uint32_t nf = c->in_frames;
+    const bool wide = c->kiwi_rate != SSDR_RATE;                  // SAMPLE_RATIO % 1 != 0 (:1125)
+    const size_t per_frame = wide ? (size_t)SSDR_RS_OUT_PER_FRAME : 2048;
     if (!c->d_play) {
         HIP_TRY(hipMalloc(&c->d_play, (size_t)c->n_ch * sizeof(ssdr_play_chan)));
         HIP_TRY(hipMalloc(&c->d_play_taps, 33 * sizeof(double)));
         HIP_TRY(hipMalloc(&c->d_play_hist, (size_t)c->n_ch * 8 * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_play_rs_taps, sizeof(SSDR_RS_TAPS)));
         HIP_TRY(hipMemsetAsync(c->d_play_hist, 0, (size_t)c->n_ch * 8 * sizeof(double), c->stream));   // old_buffer = zeros (:1005)
         double h[64];
         if (ssdr_design_lowpass(SSDR_RATE / 2.0, 48000.0, 63, h) != 33) return SSDR_EINVAL;             // filtering(KIWI_RATE/2, AUDIO_RATE)
         HIP_TRY(hipMemcpyAsync(c->d_play_taps, h, 33 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_play_rs_taps, SSDR_RS_TAPS, sizeof(SSDR_RS_TAPS), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    if (c->play_frames < nf) {
+    if (c->play_frames < nf) {          // sized for the longer (x4) form, either path fits
         if (c->d_play_out) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_play_out)); c->d_play_out = nullptr; c->play_frames = 0; }
         HIP_TRY(hipMalloc(&c->d_play_out, (size_t)c->n_ch * nf * 2048 * 2 * sizeof(int16_t)));
         c->play_frames = nf;
@@ -687,12 +707,13 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
     a.taps = c->d_play_taps;
     a.hist = c->d_play_hist;
     a.out = c->d_play_out;
+    a.rs_taps = c->d_play_rs_taps;
     int rc;
     if ((rc = timed_begin(c)) != SSDR_OK) return rc;
-    HIP_TRY(ssdr_launch_play(a, c->stream));
+    HIP_TRY(wide ? ssdr_launch_play_rs(a, c->stream) : ssdr_launch_play(a, c->stream));
     if ((rc = timed_end(c, SSDR_K_PLAY)) != SSDR_OK) return rc;
     if (out)
-        HIP_TRY(hipMemcpyAsync(out, c->d_play_out, (size_t)c->n_ch * nf * 2048 * 2 * sizeof(int16_t),
+        HIP_TRY(hipMemcpyAsync(out, c->d_play_out, (size_t)c->n_ch * nf * per_frame * 2 * sizeof(int16_t),
                                out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;

@@ -78,7 +78,8 @@ struct SsdrPlayArgs {
     const ssdr_play_chan *chans;             // [n_ch]
     const double *taps;                      // [33] filtering(KIWI_RATE/2, AUDIO_RATE).h
     double *hist;                            // [n_ch][8] last 8 volume-scaled samples (the non-zero part of old_buffer)
-    int16_t *out;                            // [n_ch][n_frames*2048][2]
+    int16_t *out;                            // [n_ch][n_frames*2048][2]   (resampled path: [n_ch][n_frames*1213][2])
+    const double *rs_taps;                   // resampled path: [64*21] polyphase taps (ssdr_resample_taps.h)
 };
 
 struct SsdrWireArgs {
@@ -91,6 +92,7 @@ struct SsdrWireArgs {
 
 hipError_t ssdr_launch_db2col(const SsdrDb2colArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_play(const SsdrPlayArgs &a, hipStream_t stream);
+hipError_t ssdr_launch_play_rs(const SsdrPlayArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_iqwire(const SsdrWireArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_adpcm(const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state, int16_t *out,
                              hipStream_t stream);

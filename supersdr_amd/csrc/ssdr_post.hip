@@ -6,12 +6,14 @@
 //   ssdr_play_kernel     kiwi_sound.play_buffer (utils_supersdr.py:1106-1148): volume, x4 zero-stuffing
 //                        interpolation with the reference's 33-tap filter (:999-1005), pan^2, truncating
 //                        int16 stereo pack -- float64 like the reference
+//   ssdr_play_rs_kernel  the same for 20.25 kHz KiwiSDRs (:1125-1126): resample_poly(popped, 64, 27, "line")[:-1]
 //   ssdr_iqwire_kernel   KiwiSDRStream._process_aud, IQ branch (kiwi/client.py:443-454): strips the 17-byte
 //                        SND/GPS header of each frame and turns big-endian int16 I,Q into the kernels' layout
 //
 // These are pinned by golden vectors produced by the real reference (tests/golden/*.npz).
 #include "ssdr_math.h"
 #include "ssdr_kernels.h"
+#include "ssdr_resample_taps.h"
 
 namespace {
 
@@ -185,6 +187,46 @@ __global__ __launch_bounds__(64) void ssdr_play_kernel(SsdrPlayArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// play_buffer for a fractional SAMPLE_RATIO (20.25 kHz KiwiSDRs, utils_supersdr.py:1125-1126): every 512-sample
+// frame goes through scipy.signal.resample_poly(popped, 64, 27, padtype="line") on its own (no history) and the
+// last output is dropped: 1213 stereo samples per frame.  Restated from scipy 1.15.3 (_upfirdn_apply.pyx,
+// _apply_impl with MODE_LINE): output y of the full polyphase convolution uses phase t = 27 y mod 64 ending at
+// sample 27 y div 64; its 21 taps are applied oldest sample first, one multiply and one add each in float64;
+// samples outside the frame lie on the line through the frame's first and last sample; outputs
+// y = 24 .. 24 + 1212 are kept.  One workgroup per (channel, frame).
+__global__ __launch_bounds__(256) void ssdr_play_rs_kernel(SsdrPlayArgs a)
+{
+    __shared__ double s_x[SSDR_FRAME];
+    const uint32_t ch = blockIdx.x / a.n_frames, f = blockIdx.x - ch * a.n_frames;
+    const ssdr_play_chan pc = a.chans[ch];
+    const double vol = pc.volume / 100.0;
+    const double lv = fmin(1.0 - pc.balance, 1.0), rv = fmin(1.0 + pc.balance, 1.0);
+    const double l2 = lv * lv, r2 = rv * rv;
+    const int16_t *src = a.pcm + ((uint64_t)ch * a.n_frames + f) * SSDR_FRAME;
+    for (int i = threadIdx.x; i < SSDR_FRAME; i += blockDim.x) s_x[i] = (double)src[i] * vol;
+    __syncthreads();
+    const double x0 = s_x[0], xl = s_x[SSDR_FRAME - 1];
+    const double slope = (xl - x0) / (double)(SSDR_FRAME - 1);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(a.out + ((uint64_t)ch * a.n_frames + f) * SSDR_RS_OUT_PER_FRAME * 2);
+    for (int k = threadIdx.x; k < SSDR_RS_OUT_PER_FRAME; k += blockDim.x) {
+        const int total = (k + SSDR_RS_PRE_REMOVE) * SSDR_RS_DOWN;
+        const int x_idx = total / SSDR_RS_UP, t = total % SSDR_RS_UP;
+        const double *h = a.rs_taps + t * SSDR_RS_HPP;
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < SSDR_RS_HPP; m++) {
+            const int xi = x_idx - SSDR_RS_HPP + 1 + m;
+            double xv;
+            if (xi < 0) xv = x0 + (double)xi * slope;
+            else if (xi >= SSDR_FRAME) xv = xl + (double)(xi - SSDR_FRAME + 1) * slope;
+            else xv = s_x[xi];
+            acc = acc + xv * h[m];
+        }
+        const int li = (int)(acc * l2), ri = (int)(acc * r2);            // trunc toward zero, then wrap to int16
+        dst[k] = ((uint32_t)li & 0xFFFFu) | ((uint32_t)ri << 16);
+    }
+}
+
 // SND body in IQ mode: 7 bytes (flags, seq, smeter) + 10 bytes GPS + 512 x (I,Q) big-endian int16.
 // One wave per (channel, frame): lane l converts samples 8l .. 8l+7 (32 payload bytes at byte offset 17 + 32 l).
 __global__ __launch_bounds__(64) void ssdr_iqwire_kernel(SsdrWireArgs a)
@@ -263,6 +305,13 @@ hipError_t ssdr_launch_db2col(const SsdrDb2colArgs &a, hipStream_t stream)
     hipLaunchKernelGGL(ssdr_db2col_kernel, dim3(a.n_ch), dim3(64), 0, stream, a);
     return hipGetLastError();
 }
+hipError_t ssdr_launch_play_rs(const SsdrPlayArgs &a, hipStream_t stream)
+{
+    if (a.n_ch == 0 || a.n_frames == 0) return hipSuccess;
+    hipLaunchKernelGGL(ssdr_play_rs_kernel, dim3(a.n_ch * a.n_frames), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t ssdr_launch_play(const SsdrPlayArgs &a, hipStream_t stream)
 {
     hipLaunchKernelGGL(ssdr_play_kernel, dim3(a.n_ch), dim3(64), 0, stream, a);

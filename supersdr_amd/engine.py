@@ -143,10 +143,20 @@ class SsdrEngine:
             chans[i] = arr[i]
         return out
 
+    def set_kiwi_rate(self, kiwi_rate):
+        """kiwi_sound.KIWI_RATE (utils_supersdr.py:991-994): 12000, or 20250 for play_buffer's resample_poly branch."""
+        check(lib.ssdr_set_kiwi_rate(self._ctx, int(kiwi_rate)), "ssdr_set_kiwi_rate")
+
+    def playbuffer_frame_len(self):
+        n = C.c_uint32()
+        check(lib.ssdr_playbuffer_frame_len(self._ctx, C.byref(n)), "ssdr_playbuffer_frame_len")
+        return int(n.value)
+
     def run_playbuffer(self, chans, fetch=True):
-        """play_buffer for the frames of the last run_audio -> int16 [n_ch, n_frames*2048, 2]."""
+        """play_buffer for the frames of the last run_audio -> int16 [n_ch, n_frames*L, 2], L = playbuffer_frame_len()
+        (2048 at 12 kHz, 1213 at 20.25 kHz)."""
         arr = (PlayChan * self.n_ch)(*chans)
-        out = np.empty((self.n_ch, self.in_frames * 2048, 2), np.int16) if fetch else None
+        out = np.empty((self.n_ch, self.in_frames * self.playbuffer_frame_len(), 2), np.int16) if fetch else None
         check(lib.ssdr_run_playbuffer(self._ctx, arr, out.ctypes.data if fetch else None, 0), "ssdr_run_playbuffer")
         return out
 

@@ -17,12 +17,14 @@ Both are fed by an `IQHub`, which owns one SsdrEngine (one GPU context) for a bl
 receiver channels, batches the channels' IQ frames and runs the two kernels once per
 superframe (1024 samples = 1 waterfall line + 2 audio frames).
 
-What the reference computes on the host AFTER those seams is restated here with citations
-(time binning by division, scrolling, pacing, TX mute).  Two of those steps -- spectrum_db2col
-(utils_supersdr.py:787-813) and the play_buffer interpolator (:1106-1148) -- also exist as HIP
-kernels (ssdr_run_db2col / ssdr_run_playbuffer, bit-exact against golden vectors of the real
-reference); with `IQHub(gpu_post=True)` (default) the workers use those results and keep the
-host restatement only as the path for frames that did not come with one.
+What the reference does on the host AFTER those seams and is pure control flow stays here, with
+citations (time binning by division of the GPU's integer sums, scrolling, pacing, TX mute).  The two
+arithmetic steps -- spectrum_db2col (utils_supersdr.py:787-813) and the play_buffer interpolator
+(:1106-1148, both the x4 and the 64/27 resample_poly branch) -- are HIP kernels (ssdr_run_db2col /
+ssdr_run_playbuffer, bit-exact against golden vectors of the real reference): the hub runs them with every
+superframe and the workers hand out their results.  There is no host implementation of either step:
+`IQHub(gpu_post=False)` skips the two kernels for consumers that only want raw lines and PCM, and
+spectrum_db2col() / play_buffer() then raise.
 """
 import queue
 import threading
@@ -42,17 +44,6 @@ LOW_CUT_CW, HIGH_CUT_CW = int(CW_PITCH * 1000 - 200), int(CW_PITCH * 1000 + 200)
 HIGHLOW_CUT_AM = 6000
 
 
-def design_lowpass(fl, fs):
-    """filtering.__init__ (utils_supersdr.py:334-344): Blackman-windowed sinc, odd length
-    ceil(4/(fl/fs)), unity DC gain.  Host-side design for the playback interpolator."""
-    b = fl / fs
-    n = int(np.ceil(4 / b))
-    if not n % 2:
-        n += 1
-    h = np.sinc(2.0 * fl / fs * (np.arange(n) - (n - 1) / 2.0)) * np.blackman(n)
-    return h / np.sum(h)
-
-
 class IQHub:
     """Batches per-channel IQ into superframes and runs the GPU path for all channels at once.
 
@@ -63,11 +54,16 @@ class IQHub:
         snd_queue[c] : (int16[512] pcm, float rssi) per audio frame
     """
 
-    def __init__(self, n_channels, device=0, engine=None, max_queue=64, gpu_post=True):
+    def __init__(self, n_channels, device=0, engine=None, max_queue=64, gpu_post=True, kiwi_rate=12000):
         self.n_ch = int(n_channels)
         self.engine = engine if engine is not None else SsdrEngine(self.n_ch, device)
-        # spectrum_db2col and play_buffer on the GPU too (SURVEY.md 8f) when the engine offers them
-        self.gpu_post = bool(gpu_post) and hasattr(self.engine, "run_db2col")
+        # spectrum_db2col and play_buffer run on the GPU with every superframe (SURVEY.md 8f-1, 8f-2)
+        self.gpu_post = bool(gpu_post)
+        self.kiwi_rate = int(kiwi_rate)              # kiwi_sound.KIWI_RATE: selects play_buffer's branch (:1125)
+        self.play_len = 2048
+        if self.gpu_post:
+            self.engine.set_kiwi_rate(self.kiwi_rate)
+            self.play_len = self.engine.playbuffer_frame_len()
         self.wf_clients = [None] * self.n_ch        # kiwi_waterfall objects: display state for db2col
         self.snd_clients = [None] * self.n_ch       # kiwi_sound objects: volume / balance for play_buffer
         self._buf = [np.zeros((0, 2), np.int16) for _ in range(self.n_ch)]
@@ -126,7 +122,7 @@ class IQHub:
                         post = (color[i, c].copy(), k.low_clip_db, k.high_clip_db, k.dynamic_range, k.wf_min_db, k.wf_max_db)
                     _put_drop_oldest(self.wf_queue[c], (line[c].copy(), n_avg, post))
                 for f in range(2):
-                    blk = play[c, f * 2048:(f + 1) * 2048].copy() if play is not None else None
+                    blk = play[c, f * self.play_len:(f + 1) * self.play_len].copy() if play is not None else None
                     _put_drop_oldest(self.snd_queue[c], (pcm[c, f * L.FRAME:(f + 1) * L.FRAME].copy(), float(rssi[c, f]), blk))
 
     @staticmethod
@@ -323,20 +319,8 @@ class kiwi_waterfall:
              self.wf_min_db, self.wf_max_db) = self._gpu_post
             self._gpu_post = None
             return
-        wf = self.spectrum
-        wf = -(255 - wf)
-        wf_db = wf - 13 + (3 * self.zoom)
-        wf_db[0] = wf_db[1]
-        if self.wf_auto_scaling:
-            self.low_clip_db = np.percentile(wf_db, self.CLIP_LOWP)
-            self.high_clip_db = np.percentile(wf_db, self.CLIP_HIGHP)
-            self.dynamic_range = max(self.high_clip_db - self.low_clip_db, self.MIN_DYN_RANGE)
-        wf_color_db = wf_db - (self.low_clip_db + self.delta_low_db)
-        normal_factor_db = self.dynamic_range + self.delta_high_db
-        self.wf_color = np.clip(wf_color_db / (normal_factor_db - self.delta_low_db), 0.0, 1.0)
-        self.wf_min_db = self.low_clip_db + self.delta_low_db - (3 * self.zoom)
-        self.wf_max_db = self.low_clip_db + normal_factor_db - (3 * self.zoom)
-        self.wf_color = np.clip(self.wf_color * 254, 0, 255)
+        raise RuntimeError("spectrum_db2col runs on the GPU (ssdr_run_db2col): no result came with this line -- "
+                           "the hub was built with gpu_post=False or the line was already converted")
 
     def set_white_flag(self):                            # utils_supersdr.py:875-877
         self.wf_color = np.ones_like(self.wf_color) * 255
@@ -412,13 +396,15 @@ class kiwi_sound:
         self.freq_offset = 0
         self.KIWI_RATE_TRUE = float(self.KIWI_RATE)
         self.late_flag = False
-        # playback interpolator: utils_supersdr.py:999-1005
-        self.kiwi_filter_h = design_lowpass(self.KIWI_RATE / 2, self.AUDIO_RATE)
-        self.n_tap = len(self.kiwi_filter_h)
-        self.old_buffer = np.zeros((self.n_tap - 1))
+        # playback interpolator (utils_supersdr.py:999-1005): taps and history live in the GPU context
+        self.n_tap = 33
         self.audio_rec = _NoRecording()
         self.hub = hub if hub is not None else kiwi_wf.hub
         self.channel = kiwi_wf.channel if channel is None else channel
+        if getattr(self.hub, "kiwi_rate", self.KIWI_RATE) != self.KIWI_RATE:     # "audio_init audio_rate=" (:988-994)
+            self.KIWI_RATE = int(self.hub.kiwi_rate)
+            self.KIWI_RATE_TRUE = float(self.KIWI_RATE)
+            self.SAMPLE_RATIO = self.AUDIO_RATE / self.KIWI_RATE
         self._timeout = timeout
         self.center_khz = float(kiwi_wf.freq)            # the IQ band's centre: tuning is relative to it
         self._play_blocks = {}
@@ -494,7 +480,7 @@ class kiwi_sound:
             self.terminate = True
             return None
 
-    # ---- playback stage, host side (restated; SURVEY.md 8f-2 moves it to the GPU)
+    # ---- playback stage: blocks interpolated, panned and packed by ssdr_run_playbuffer
     def play_buffer(self, outdata, frame_count, time_info, status):   # utils_supersdr.py:1106-1148
         self.status = status
         if self.late_flag:
@@ -506,19 +492,8 @@ class kiwi_sound:
             outdata[:] = np.concatenate(blocks)
             self._mute_logic(outdata)
             return
-        popped = np.array(frames).flatten()
-        popped = popped.astype(np.float64) * (self.volume / 100)
-        ratio = int(self.SAMPLE_RATIO)
-        buf = np.zeros(ratio * len(popped))
-        buf[::ratio] = popped
-        buf = np.concatenate([self.old_buffer, buf])
-        self.old_buffer = buf[-(self.n_tap - 1):]
-        buf = np.convolve(buf, self.kiwi_filter_h, mode="valid") * ratio
-        left, right = min(1 - self.audio_balance, 1.0), min(1 + self.audio_balance, 1.0)
-        with np.errstate(invalid="ignore"):
-            outdata[:, 0] = (buf * left ** 2).astype(np.int16)
-            outdata[:, 1] = (buf * right ** 2).astype(np.int16)
-        self._mute_logic(outdata)
+        raise RuntimeError("play_buffer runs on the GPU (ssdr_run_playbuffer): frames without a 48 kHz block -- "
+                           "the hub was built with gpu_post=False")
 
     def _mute_logic(self, outdata):                      # utils_supersdr.py:1142-1147
         if self.rssi > self.max_rssi_before_mute:

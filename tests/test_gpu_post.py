@@ -98,6 +98,45 @@ def test_play_buffer_matches_reference_golden(S):
         assert np.array_equal(out[c].reshape(4, 2048, 2), g["out_%d" % c])
 
 
+def test_play_buffer_resampled_matches_reference_golden(S):
+    """20.25 kHz KiwiSDRs (utils_supersdr.py:1125-1126): resample_poly(popped, 64, 27, padtype="line")[:-1] per frame;
+    goldens from the real reference, plus random frames and full-scale edge cases against the oracle restatement"""
+    from supersdr_amd._lib import PlayChan
+    g = np.load(os.path.join(GOLD, "playbuffer.npz"))
+    n = int(g["rs_count"])
+    frames = np.stack([g["rs_in_%d" % c] for c in range(n)])               # [n_ch, 3, 512]
+    with S.SsdrEngine(n) as eng:
+        assert eng.playbuffer_frame_len() == 2048
+        eng.set_kiwi_rate(20250)
+        assert eng.playbuffer_frame_len() == 1213
+        eng.set_pcm(frames.reshape(n, -1))
+        out = eng.run_playbuffer([PlayChan(*g["rs_cfg_%d" % c]) for c in range(n)])
+        assert out.shape == (n, 3 * 1213, 2)
+        for c in range(n):
+            assert np.array_equal(out[c].reshape(3, 1213, 2), g["rs_out_%d" % c]), c
+        with pytest.raises(S.SsdrError):
+            eng.set_kiwi_rate(44100)
+        eng.set_kiwi_rate(12000)                                            # and back: the x4 path again
+        assert eng.run_playbuffer([PlayChan(100.0, 0.0)] * n).shape == (n, 3 * 2048, 2)
+    rng = np.random.default_rng(11)
+    n_ch, nf = 5, 4
+    pcm = rng.integers(-32768, 32768, (n_ch, nf, 512)).astype(np.int16)
+    pcm[0, 0] = 32767
+    pcm[0, 1] = -32768
+    pcm[1, 0] = 0
+    pcm[1, 1, ::2], pcm[1, 1, 1::2] = 32767, -32768                        # Nyquist at full scale
+    pcm[2, 0] = np.arange(512) * 100 - 25000                               # already a line: the extension continues it
+    cfg = [(100.0, 0.0), (150.0, 0.25), (33.0, -0.7), (100.0, 1.0), (1.0, -1.0)]
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_kiwi_rate(20250)
+        eng.set_pcm(pcm.reshape(n_ch, -1))
+        out = eng.run_playbuffer([PlayChan(*k) for k in cfg])
+    ref = O.PlayBufferResampled()
+    for c in range(n_ch):
+        for f in range(nf):
+            assert np.array_equal(out[c, f * 1213:(f + 1) * 1213], ref(pcm[c, f], *cfg[c])), (c, f)
+
+
 def test_iq_wire_decode_matches_reference_golden(S):
     g = np.load(os.path.join(GOLD, "frames.npz"))
     body = g["iq_body"]

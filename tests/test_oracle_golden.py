@@ -74,6 +74,32 @@ def test_play_buffer_matches_reference():
             assert np.array_equal(out, g["out_%d" % c][f]), (c, f)
 
 
+def test_play_buffer_resampled_matches_reference():
+    """20.25 kHz KiwiSDRs: resample_poly(popped, 64, 27, padtype="line")[:-1] per frame (utils_supersdr.py:1125-1126)"""
+    g = gold("playbuffer.npz")
+    assert list(g["rs_ratio"]) == [O.RS_UP, O.RS_DOWN]
+    pb = O.PlayBufferResampled()
+    for c in range(int(g["rs_count"])):
+        volume, balance = g["rs_cfg_%d" % c]
+        frames = g["rs_in_%d" % c]
+        for f in range(frames.shape[0]):
+            out = pb(frames[f], volume=volume, balance=balance)
+            assert out.shape == (1213, 2)
+            assert np.array_equal(out, g["rs_out_%d" % c][f]), (c, f)
+
+
+def test_resample_tap_table_is_scipys():
+    """the committed tap table (csrc/ssdr_resample_taps.h, tools/gen_resample_taps.py) equals what scipy designs"""
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "supersdr_amd", "csrc", "ssdr_resample_taps.h")
+    text = open(path).read()
+    body = text[text.index("SSDR_RS_TAPS["):]
+    vals = np.array([float.fromhex(v) for v in re.findall(r"-?0x[0-9a-f.]+p[+-]?\d+", body)])
+    tf, n_pre_remove = O.resample_taps_64_27()
+    assert np.array_equal(vals, tf)
+    assert "#define SSDR_RS_PRE_REMOVE %d " % n_pre_remove in text and "#define SSDR_RS_HPP %d\n" % (len(tf) // 64) in text
+
+
 def test_frame_decoders_match_reference():
     g = gold("frames.npz")
     assert np.array_equal(O.decode_wf_frame(g["wf_msg"].tobytes()), g["wf_spectrum"])
