@@ -154,6 +154,34 @@ int ssdr_run_playbuffer(ssdr_ctx *ctx, const ssdr_play_chan *chans, int16_t *out
 int ssdr_set_kiwi_rate(ssdr_ctx *ctx, uint32_t kiwi_rate);
 int ssdr_playbuffer_frame_len(ssdr_ctx *ctx, uint32_t *samples_per_frame);
 
+/* -- display reductions on device-resident state
+ *
+ * ssdr_set_wfdata_rows(rows > 0): every colour line ssdr_run_db2col produces is also kept on the device as the newest
+ * rows of kiwi_waterfall.wf_data (utils_supersdr.py:692-693, 893-897: float64 [WF_HEIGHT][1024] fed through a 3-deep
+ * deque, newest row on top; only the `rows` newest rows are kept).  rows = 0 (default) turns it off and frees it.
+ * ssdr_push_color_lines feeds colour lines float32 [lines][n_ch][1024] that were not produced by ssdr_run_db2col
+ * through the same queue; ssdr_wfdata_white_flag is kiwi_waterfall.set_white_flag (:875-877) for channels
+ * [first, first + count): row 0 becomes 255.
+ *
+ * ssdr_run_trace: display_stuff.plot_spectrum's reduction (utils_supersdr.py:1678-1679) for every channel:
+ *   trace_out double [n_ch][1024] = np.nanmean(wf_data.T[:, :t_avg], axis=1)      (t_avg <= rows; reference: 15)
+ *   y_out     int32  [n_ch][1024] = SPECTRUM_HEIGHT-1-int(v/255 * SPECTRUM_HEIGHT)  (may be NULL)
+ *
+ * ssdr_run_smeter: one display frame of the main loop's S-meter smoothing (supersdr.py:164-168, 190-191, 936-947)
+ * for every channel; chans[] (host memory) is updated in place.  rssi_in double [n_ch] (host) is the frame's
+ * kiwi_snd.rssi reading; NULL takes the last frame's RSSI of the last ssdr_run_audio. */
+typedef struct ssdr_smeter_chan {
+    double rssi_smooth, rssi_smooth_slow;   /* supersdr.py:166-167                                            */
+    double hist[10];                        /* rssi_hist = deque(maxlen=rssi_maxlen=10) (:164-165), ring      */
+    uint32_t hist_pos, run_index;           /* next ring slot; run_index of the main loop (:169, % 20 at :945) */
+    double decay_ms;                        /* kiwi_snd.decay (:941)                                          */
+} ssdr_smeter_chan;                         /* 112 B                                                          */
+int ssdr_set_wfdata_rows(ssdr_ctx *ctx, uint32_t rows);
+int ssdr_push_color_lines(ssdr_ctx *ctx, const float *color, uint32_t lines, int color_is_device);
+int ssdr_wfdata_white_flag(ssdr_ctx *ctx, uint32_t first, uint32_t count);
+int ssdr_run_trace(ssdr_ctx *ctx, uint32_t t_avg, uint32_t spectrum_height, double *trace_out, int32_t *y_out, int out_is_device);
+int ssdr_run_smeter(ssdr_ctx *ctx, ssdr_smeter_chan *chans, const double *rssi_in, double fps);
+
 /* KiwiSDRStream._process_aud, IQ branch (kiwi/client.py:384-389, 443-454): n_frames SND bodies per channel
  * (each 7 B flags/seq/smeter + 10 B GPS + 512 big-endian I,Q pairs = 2065 B, layout [n_ch][n_frames][2065],
  * host memory) become the current input batch, as ssdr_push_iq would; rssi_out (may be NULL) receives
@@ -174,7 +202,7 @@ int ssdr_set_stream(ssdr_ctx *ctx, void *hip_stream);           /* NULL = ctx's 
 int ssdr_set_profiling(ssdr_ctx *ctx, int on);                  /* HIP-event pair around every launch */
 /* run the audio kernel on a second stream beside the waterfall kernel (which then takes one workgroup per CU) */
 int ssdr_set_concurrent(ssdr_ctx *ctx, int on);
-enum { SSDR_K_WF = 0, SSDR_K_AUDIO = 1, SSDR_K_SYNTH = 2, SSDR_K_DB2COL = 3, SSDR_K_PLAY = 4, SSDR_K_WIRE = 5, SSDR_K_COUNT = 6 };
+enum { SSDR_K_WF = 0, SSDR_K_AUDIO = 1, SSDR_K_SYNTH = 2, SSDR_K_DB2COL = 3, SSDR_K_PLAY = 4, SSDR_K_WIRE = 5, SSDR_K_TRACE = 6, SSDR_K_SMETER = 7, SSDR_K_COUNT = 8 };
 int ssdr_kernel_stats(ssdr_ctx *ctx, int which, float *total_ms, uint32_t *launches, int reset);
 int ssdr_elapsed_ms(ssdr_ctx *ctx, float *ms);                  /* last run_* call, device time */
 

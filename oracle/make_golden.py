@@ -17,6 +17,8 @@ Fixtures (all small):
   binning.npz      np.mean time binning of N byte-valued lines               utils_supersdr.py:881-888
   db2col.npz       spectrum_db2col in/out at zoom 0/8/14, autoscale on/off   utils_supersdr.py:787-813
   playbuffer.npz   play_buffer over 4 consecutive frames, volume/pan cases   utils_supersdr.py:1106-1148
+  display.npz      plot_spectrum's trace pixels; S-meter smoothing series             utils_supersdr.py:1669-1691;
+                                                                              supersdr.py:936-947
   frames.npz       W/F, SND and IQ frame bytes and their decoded arrays      utils_supersdr.py:780-785,
                    ADPCM known answer                                        1065-1074; kiwi/client.py:33-87,384-482
   wavreader.npz    decode of a synthetic Kiwi IQ wav                         kiwi/wavreader.py:74-102
@@ -192,6 +194,75 @@ def gold_playbuffer(U):
     return out
 
 
+def gold_display(U):
+    """display reductions: the real display_stuff.plot_spectrum (utils_supersdr.py:1669-1691) drawn into a recording
+    stand-in for pygame's PixelArray, and the S-meter lines of the main loop (supersdr.py:936-947), which are script
+    text rather than a function: they are sliced out of the file between their first and last statement and executed
+    on given inputs."""
+    rng = np.random.default_rng(7)
+    out = {}
+    pygame = sys.modules["pygame"]
+    case = 0
+    for height, spec_h, n_lines, t_avg in ((40, 180, 30, 15), (40, 180, 6, 15), (24, 137, 20, 7)):
+        wf = U.kiwi_waterfall.__new__(U.kiwi_waterfall)
+        wf.wf_data = np.zeros((height, 1024))
+        wf.wf_auto_scaling = True
+        lines = []
+        from collections import deque
+        tmp, run_index = deque([], wf.wf_buffer_len), 0
+        for i in range(n_lines):
+            col = np.clip(rng.normal(90, 60, 1024), 0, 254).astype(np.float32)
+            col[rng.integers(0, 1024, 5)] = np.float32(1e-7) * np.float32(rng.integers(1, 9))
+            lines.append(col)
+            run_index += 1
+            tmp.appendleft(col)                                  # utils_supersdr.py:893-897
+            if len(tmp) > 0 and run_index > wf.wf_buffer_len:
+                wf.wf_data[1:, :] = wf.wf_data[0:-1, :]
+                wf.wf_data[0, :] = tmp.pop()
+        disp = U.display_stuff.__new__(U.display_stuff)
+        disp.SPECTRUM_HEIGHT, disp.DISPLAY_WIDTH, disp.SPECTRUM_Y = spec_h, 1024, 0
+        pix = mock.MagicMock()
+        pygame.PixelArray = mock.MagicMock(return_value=pix)
+        disp.plot_spectrum(mock.MagicMock(), wf, t_avg=t_avg)
+        ys = np.full(1024, -1, np.int64)
+        for call in pix.__setitem__.call_args_list:
+            (x, y), _ = call.args
+            ys[x] = y
+        assert (ys >= 0).all()
+        out["lines_%d" % case] = np.stack(lines)
+        out["cfg_%d" % case] = np.array([height, spec_h, n_lines, t_avg], np.int64)
+        out["y_%d" % case] = ys
+        out["trace_%d" % case] = np.nanmean(wf.wf_data.T[:, :t_avg], axis=1)
+        case += 1
+    out["count"] = np.int64(case)
+
+    src = open(os.path.join(REF, "supersdr.py")).read().split("\n")
+    first = next(i for i, l in enumerate(src) if l.strip() == "rssi_last = rssi_hist[-1]")
+    last = next(i for i, l in enumerate(src) if l.strip() == "rssi_smooth_slow = max(rssi_hist)")
+    code = compile("\n".join(l[4:] if l.startswith("    ") else l for l in src[first:last + 1]), "supersdr.py:smeter", "exec")
+    import math
+    case = 0
+    for decay, fps in ((4000, 30), (1000, 30), (400, 25), (8000, 60)):
+        rssi_in = np.concatenate([np.full(30, -110.0), np.full(40, -53.5), rng.normal(-80, 12, 120), np.full(60, -127.0)])
+        ns = dict(math=math, FPS=fps, kiwi_snd=types.SimpleNamespace(decay=decay),
+                  rssi_hist=deque(10 * [float(rssi_in[0])], 10), rssi_smooth=float(rssi_in[0]),
+                  rssi_smooth_slow=float(rssi_in[0]))
+        sm, sl = [], []
+        for run_index, r in enumerate(rssi_in):
+            ns["rssi_hist"].append(float(r))                     # supersdr.py:190-191
+            ns["run_index"] = run_index
+            exec(code, ns)
+            sm.append(ns["rssi_smooth"])
+            sl.append(ns["rssi_smooth_slow"])
+        out["sm_in_%d" % case] = rssi_in
+        out["sm_cfg_%d" % case] = np.array([decay, fps], np.float64)
+        out["sm_smooth_%d" % case] = np.array(sm)
+        out["sm_slow_%d" % case] = np.array(sl)
+        case += 1
+    out["sm_count"] = np.int64(case)
+    return out
+
+
 def gold_frames(U, KC):
     rng = np.random.default_rng(5)
     out = {}
@@ -300,6 +371,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "binning.npz"), **gold_binning(U))
     np.savez_compressed(os.path.join(OUT, "db2col.npz"), **gold_db2col(U))
     np.savez_compressed(os.path.join(OUT, "playbuffer.npz"), **gold_playbuffer(U))
+    np.savez_compressed(os.path.join(OUT, "display.npz"), **gold_display(U))
     np.savez_compressed(os.path.join(OUT, "frames.npz"), **gold_frames(U, KC))
     np.savez_compressed(os.path.join(OUT, "wavreader.npz"), **gold_wavreader(WR))
     for f in sorted(os.listdir(OUT)):

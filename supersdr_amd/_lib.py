@@ -13,7 +13,7 @@ NFFT, FRAME, RATE, NTAP_MAX, HIST = 1024, 512, 12000, 128, 128
 OK, EINVAL, ENOMEM, EHIP, ENODEV, ESTATE = 0, -1, -2, -3, -4, -5
 MODE_AM, MODE_LSB, MODE_USB, MODE_CW, MODE_NBFM = range(5)
 MODE_BY_NAME = {"am": 0, "lsb": 1, "usb": 2, "cw": 3, "nbfm": 4, "nfm": 4}
-K_WF, K_AUDIO, K_SYNTH, K_DB2COL, K_PLAY, K_WIRE = range(6)
+K_WF, K_AUDIO, K_SYNTH, K_DB2COL, K_PLAY, K_WIRE, K_TRACE, K_SMETER = range(8)
 T_WINDOW, T_TWIDDLE_RE, T_TWIDDLE_IM, T_DB_THRESH = range(4)
 
 
@@ -45,6 +45,16 @@ class PlayChan(C.Structure):
     _fields_ = [("volume", C.c_double), ("balance", C.c_double)]
 
 
+class SmeterChan(C.Structure):          # ssdr_smeter_chan, 112 B
+    _fields_ = [("rssi_smooth", C.c_double), ("rssi_smooth_slow", C.c_double), ("hist", C.c_double * 10),
+                ("hist_pos", C.c_uint32), ("run_index", C.c_uint32), ("decay_ms", C.c_double)]
+
+    @classmethod
+    def start(cls, rssi0, decay_ms=4000.0):
+        """state before the first frame: rssi_hist = deque(10*[rssi0], 10), smooth = slow = rssi0 (supersdr.py:164-167)"""
+        return cls(float(rssi0), float(rssi0), (C.c_double * 10)(*([float(rssi0)] * 10)), 0, 0, float(decay_ms))
+
+
 class ChanState(C.Structure):
     _fields_ = [("phi1", C.c_uint32), ("phi2", C.c_uint32), ("dc", C.c_float), ("agc_d", C.c_float),
                 ("agc_m", C.c_float * 8), ("prev_re", C.c_float), ("prev_im", C.c_float), ("pad", C.c_uint32 * 2)]
@@ -68,6 +78,11 @@ _SIGS = {
     "ssdr_sync": (C.c_int, [_P]),
     "ssdr_run_db2col": (C.c_int, [_P, C.POINTER(Db2colChan), _P, C.c_int]),
     "ssdr_run_playbuffer": (C.c_int, [_P, C.POINTER(PlayChan), _P, C.c_int]),
+    "ssdr_set_wfdata_rows": (C.c_int, [_P, C.c_uint32]),
+    "ssdr_push_color_lines": (C.c_int, [_P, _P, C.c_uint32, C.c_int]),
+    "ssdr_wfdata_white_flag": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "ssdr_run_trace": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P, C.c_int]),
+    "ssdr_run_smeter": (C.c_int, [_P, C.POINTER(SmeterChan), _P, C.c_double]),
     "ssdr_set_kiwi_rate": (C.c_int, [_P, C.c_uint32]),
     "ssdr_playbuffer_frame_len": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "ssdr_push_iq_wire": (C.c_int, [_P, _P, C.c_uint32, _P]),

@@ -70,6 +70,14 @@ struct ssdr_ctx {
     size_t color_lines = 0;
     ssdr_play_chan *d_play = nullptr;
     double *d_play_taps = nullptr, *d_play_hist = nullptr, *d_play_rs_taps = nullptr;
+    float *d_wfdata = nullptr;              // [wfdata_rows][n_ch][1024] newest rows of wf_data, row k at slot (head + k) % rows
+    float *d_wfpend = nullptr;              // [3][n_ch][1024] wf_data_tmp: deque(maxlen = wf_buffer_len = 3) in front of it
+    uint32_t wfdata_rows = 0, wfdata_head = 0, wfpend_n = 0;
+    uint64_t wfdata_seen = 0, wfpend_first = 0;     // run_index of kiwi_waterfall.run; arrival index of the oldest queued line
+    double *d_trace = nullptr;
+    int32_t *d_trace_y = nullptr;
+    ssdr_smeter_chan *d_smeter = nullptr;
+    double *d_smeter_in = nullptr;
     uint32_t kiwi_rate = SSDR_RATE;         // kiwi_sound.KIWI_RATE: 12000, or 20250 (fractional SAMPLE_RATIO path)
     int16_t *d_play_out = nullptr;
     size_t play_frames = 0;
@@ -150,7 +158,8 @@ void ssdr_destroy(ssdr_ctx *c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
-                    c->d_play_taps, c->d_play_hist, c->d_play_rs_taps, c->d_play_out, c->d_wire, c->d_wire_rssi};
+                    c->d_play_taps, c->d_play_hist, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
+                    c->d_smeter_in, c->d_wire, c->d_wire_rssi};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -625,6 +634,30 @@ int ssdr_selftest_quantiser(ssdr_ctx *c, uint64_t *mismatches)
     return SSDR_OK;
 }
 
+// kiwi_waterfall.run's feeding of wf_data (utils_supersdr.py:893-897) for `lines` colour lines [lines][n_ch][1024] on
+// the device: each line joins the 3-deep queue (a full queue drops its oldest entry first); from the 4th line on the
+// oldest queued line becomes row 0 and the rows scroll down by one.
+static int wfdata_feed(ssdr_ctx *c, const float *color, uint32_t lines)
+{
+    const size_t line = (size_t)c->n_ch * SSDR_NFFT;
+    for (uint32_t i = 0; i < lines; i++) {
+        c->wfdata_seen++;                                                        // run_index += 1 (:889)
+        if (c->wfpend_n == 3) { c->wfpend_first++; c->wfpend_n--; }              // deque(maxlen=3).appendleft on a full deque
+        const uint64_t arrival = c->wfpend_first + c->wfpend_n;
+        HIP_TRY(hipMemcpyAsync(c->d_wfpend + (arrival % 3) * line, color + (size_t)i * line, line * sizeof(float),
+                               hipMemcpyDeviceToDevice, c->stream));
+        c->wfpend_n++;
+        if (c->wfdata_seen > 3) {                                                // run_index > wf_buffer_len
+            c->wfdata_head = (c->wfdata_head + c->wfdata_rows - 1) % c->wfdata_rows;   // scroll one row down
+            HIP_TRY(hipMemcpyAsync(c->d_wfdata + (size_t)c->wfdata_head * line, c->d_wfpend + (c->wfpend_first % 3) * line,
+                                   line * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+            c->wfpend_first++;
+            c->wfpend_n--;
+        }
+    }
+    return SSDR_OK;
+}
+
 int ssdr_run_db2col(ssdr_ctx *c, ssdr_db2col_chan *chans, float *color_out, int out_is_device)
 {
     if (!c || !chans) return SSDR_EINVAL;
@@ -650,10 +683,133 @@ int ssdr_run_db2col(ssdr_ctx *c, ssdr_db2col_chan *chans, float *color_out, int 
     if ((rc = timed_begin(c)) != SSDR_OK) return rc;
     HIP_TRY(ssdr_launch_db2col(a, c->stream));
     if ((rc = timed_end(c, SSDR_K_DB2COL)) != SSDR_OK) return rc;
+    if (c->d_wfdata) { int rcw = wfdata_feed(c, c->d_color, lines); if (rcw != SSDR_OK) return rcw; }
     HIP_TRY(hipMemcpyAsync(chans, c->d_db2col, (size_t)c->n_ch * sizeof(ssdr_db2col_chan), hipMemcpyDeviceToHost, c->stream));
     if (color_out)
         HIP_TRY(hipMemcpyAsync(color_out, c->d_color, (size_t)lines * c->n_ch * SSDR_NFFT * sizeof(float),
                                out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_set_wfdata_rows(ssdr_ctx *c, uint32_t rows)
+{
+    if (!c || rows > 4096) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->d_wfdata) { HIP_TRY(hipFree(c->d_wfdata)); c->d_wfdata = nullptr; }
+    if (c->d_wfpend) { HIP_TRY(hipFree(c->d_wfpend)); c->d_wfpend = nullptr; }
+    c->wfdata_rows = rows;
+    c->wfdata_head = 0;
+    c->wfdata_seen = c->wfpend_first = 0;
+    c->wfpend_n = 0;
+    if (rows) {
+        const size_t line = (size_t)c->n_ch * SSDR_NFFT * sizeof(float);
+        if (hipMalloc(&c->d_wfdata, rows * line) != hipSuccess || hipMalloc(&c->d_wfpend, 3 * line) != hipSuccess) {
+            if (c->d_wfdata) (void)hipFree(c->d_wfdata);
+            c->d_wfdata = c->d_wfpend = nullptr;
+            c->wfdata_rows = 0;
+            return SSDR_ENOMEM;
+        }
+        HIP_TRY(hipMemsetAsync(c->d_wfdata, 0, rows * line, c->stream));         // wf_data = np.zeros (:692)
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SSDR_OK;
+}
+
+int ssdr_push_color_lines(ssdr_ctx *c, const float *color, uint32_t lines, int color_is_device)
+{
+    if (!c || (!color && lines)) return SSDR_EINVAL;
+    if (!c->d_wfdata) return SSDR_ESTATE;
+    if (lines == 0) return SSDR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)lines * c->n_ch * SSDR_NFFT;
+    const float *src = color;
+    if (!color_is_device) {
+        if (c->color_lines < lines) {
+            if (c->d_color) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_color)); c->d_color = nullptr; c->color_lines = 0; }
+            HIP_TRY(hipMalloc(&c->d_color, n * sizeof(float)));
+            c->color_lines = lines;
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_color, color, n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        src = c->d_color;
+    }
+    int rc = wfdata_feed(c, src, lines);
+    if (rc != SSDR_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_wfdata_white_flag(ssdr_ctx *c, uint32_t first, uint32_t count)
+{
+    if (!c || first + count > c->n_ch || first + count < first) return SSDR_EINVAL;
+    if (!c->d_wfdata) return SSDR_ESTATE;
+    if (count == 0) return SSDR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const float white = 255.0f;                                                  // np.ones_like(wf_color) * 255 (:876)
+    uint32_t bits;
+    memcpy(&bits, &white, 4);
+    float *row0 = c->d_wfdata + ((size_t)c->wfdata_head * c->n_ch + first) * SSDR_NFFT;
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(row0), (int)bits, (size_t)count * SSDR_NFFT, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_run_trace(ssdr_ctx *c, uint32_t t_avg, uint32_t spectrum_height, double *trace_out, int32_t *y_out, int out_is_device)
+{
+    if (!c || t_avg == 0) return SSDR_EINVAL;
+    if (!c->d_wfdata) return SSDR_ESTATE;
+    if (t_avg > c->wfdata_rows) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)c->n_ch * SSDR_NFFT;
+    if (!c->d_trace) {
+        HIP_TRY(hipMalloc(&c->d_trace, n * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_trace_y, n * sizeof(int32_t)));
+    }
+    SsdrTraceArgs a;
+    a.ring = c->d_wfdata;
+    a.n_ch = c->n_ch;
+    a.rows = c->wfdata_rows;
+    a.head = c->wfdata_head;
+    a.t_avg = t_avg;
+    a.spectrum_height = spectrum_height;
+    a.trace = c->d_trace;
+    a.y = c->d_trace_y;
+    int rc;
+    if ((rc = timed_begin(c)) != SSDR_OK) return rc;
+    HIP_TRY(ssdr_launch_trace(a, c->stream));
+    if ((rc = timed_end(c, SSDR_K_TRACE)) != SSDR_OK) return rc;
+    const hipMemcpyKind kind = out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (trace_out) HIP_TRY(hipMemcpyAsync(trace_out, c->d_trace, n * sizeof(double), kind, c->stream));
+    if (y_out) HIP_TRY(hipMemcpyAsync(y_out, c->d_trace_y, n * sizeof(int32_t), kind, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_run_smeter(ssdr_ctx *c, ssdr_smeter_chan *chans, const double *rssi_in, double fps)
+{
+    if (!c || !chans || !(fps > 0.0)) return SSDR_EINVAL;
+    if (!rssi_in && (!c->d_rssi || c->audio_frames == 0 || c->in_frames == 0)) return SSDR_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
+    if (!c->d_smeter) {
+        HIP_TRY(hipMalloc(&c->d_smeter, (size_t)c->n_ch * sizeof(ssdr_smeter_chan)));
+        HIP_TRY(hipMalloc(&c->d_smeter_in, (size_t)c->n_ch * sizeof(double)));
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_smeter, chans, (size_t)c->n_ch * sizeof(ssdr_smeter_chan), hipMemcpyHostToDevice, c->stream));
+    if (rssi_in) HIP_TRY(hipMemcpyAsync(c->d_smeter_in, rssi_in, (size_t)c->n_ch * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    SsdrSmeterArgs a;
+    a.chans = c->d_smeter;
+    a.rssi = c->d_rssi;
+    a.rssi_in = rssi_in ? c->d_smeter_in : nullptr;
+    a.n_ch = c->n_ch;
+    a.n_frames = c->in_frames;
+    a.fps = fps;
+    int rc;
+    if ((rc = timed_begin(c)) != SSDR_OK) return rc;
+    HIP_TRY(ssdr_launch_smeter(a, c->stream));
+    if ((rc = timed_end(c, SSDR_K_SMETER)) != SSDR_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(chans, c->d_smeter, (size_t)c->n_ch * sizeof(ssdr_smeter_chan), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
 }

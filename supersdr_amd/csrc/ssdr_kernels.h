@@ -82,6 +82,21 @@ struct SsdrPlayArgs {
     const double *rs_taps;                   // resampled path: [64*21] polyphase taps (ssdr_resample_taps.h)
 };
 
+struct SsdrTraceArgs {
+    const float *ring;                       // [rows][n_ch][1024] device copy of wf_data's newest rows; row k at slot (head + k) % rows
+    uint32_t n_ch, rows, head, t_avg, spectrum_height;
+    double *trace;                           // [n_ch][1024]
+    int32_t *y;                              // [n_ch][1024] pixel rows (may be null)
+};
+
+struct SsdrSmeterArgs {
+    ssdr_smeter_chan *chans;                 // [n_ch] in/out
+    const float *rssi;                       // [n_ch][n_frames] of the last audio run (used when rssi_in is null)
+    const double *rssi_in;                   // [n_ch] or null
+    uint32_t n_ch, n_frames;
+    double fps;
+};
+
 struct SsdrWireArgs {
     const uint8_t *bodies;                   // [n_ch][n_frames][SSDR_WIRE_BODY]
     uint32_t n_ch, n_frames;
@@ -94,6 +109,8 @@ hipError_t ssdr_launch_db2col(const SsdrDb2colArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_play(const SsdrPlayArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_play_rs(const SsdrPlayArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_iqwire(const SsdrWireArgs &a, hipStream_t stream);
+hipError_t ssdr_launch_trace(const SsdrTraceArgs &a, hipStream_t stream);
+hipError_t ssdr_launch_smeter(const SsdrSmeterArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_adpcm(const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state, int16_t *out,
                              hipStream_t stream);
 hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream);

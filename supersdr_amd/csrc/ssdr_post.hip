@@ -7,6 +7,9 @@
 //                        interpolation with the reference's 33-tap filter (:999-1005), pan^2, truncating
 //                        int16 stereo pack -- float64 like the reference
 //   ssdr_play_rs_kernel  the same for 20.25 kHz KiwiSDRs (:1125-1126): resample_poly(popped, 64, 27, "line")[:-1]
+//   ssdr_trace_kernel    display_stuff.plot_spectrum's reduction (utils_supersdr.py:1678-1679) over the device copy
+//                        of kiwi_waterfall.wf_data's newest rows; ssdr_smeter_kernel: the S-meter smoothing of the
+//                        main loop (supersdr.py:936-947)
 //   ssdr_iqwire_kernel   KiwiSDRStream._process_aud, IQ branch (kiwi/client.py:443-454): strips the 17-byte
 //                        SND/GPS header of each frame and turns big-endian int16 I,Q into the kernels' layout
 //
@@ -227,6 +230,53 @@ __global__ __launch_bounds__(256) void ssdr_play_rs_kernel(SsdrPlayArgs a)
     }
 }
 
+// Spectrum trace: np.nanmean(wf_data.T[:, :t_avg], axis=1) and y = H-1-int(v/255*H) (utils_supersdr.py:1678-1679)
+// over the device copy of wf_data's newest rows.  NumPy sums the rows left to right in float64 starting with row 0
+// and divides by the number of non-NaN rows.
+__global__ __launch_bounds__(256) void ssdr_trace_kernel(SsdrTraceArgs a)
+{
+    const uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t plane = (uint64_t)a.n_ch * SSDR_NFFT;
+    if (idx >= plane) return;
+    double tot = 0.0;
+    uint32_t cnt = 0;
+    for (uint32_t k = 0; k < a.t_avg; k++) {
+        const double v = (double)a.ring[(uint64_t)((a.head + k) % a.rows) * plane + idx];
+        if (v == v) { tot = tot + v; cnt++; }
+    }
+    const double mean = tot / (double)cnt;                          // 0/0 = NaN, as np.nanmean of an all-NaN column
+    a.trace[idx] = mean;
+    if (a.y) {
+        const double s = mean / 255.0 * (double)a.spectrum_height;
+        a.y[idx] = (s == s) ? (int32_t)a.spectrum_height - 1 - (int32_t)s : INT32_MIN;   // int() of a NaN raises in the reference
+    }
+}
+
+// S-meter smoothing, one display frame per call (supersdr.py:164-168, 190-191, 936-947).
+__global__ __launch_bounds__(256) void ssdr_smeter_kernel(SsdrSmeterArgs a)
+{
+    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= a.n_ch) return;
+    ssdr_smeter_chan st = a.chans[ch];
+    const double rssi = a.rssi_in ? a.rssi_in[ch] : (double)a.rssi[(uint64_t)ch * a.n_frames + (a.n_frames - 1)];
+    st.hist[st.hist_pos] = rssi;                                     // deque(maxlen=10).append
+    st.hist_pos = (st.hist_pos + 1) % 10;
+    if (fabs(rssi) > fabs(st.rssi_smooth)) {
+        const double v0 = -20 + 135;
+        const double t = log(v0 / (st.rssi_smooth + 135));
+        st.rssi_smooth += -v0 / (st.decay_ms / (1000 / (2 * a.fps))) * exp(-t);
+    } else {
+        st.rssi_smooth += fmin((rssi - st.rssi_smooth) / 5, 3.0);
+    }
+    if (st.run_index % 20 == 0) {
+        double m = st.hist[0];
+        for (int i = 1; i < 10; i++) m = fmax(m, st.hist[i]);
+        st.rssi_smooth_slow = m;
+    }
+    st.run_index++;
+    a.chans[ch] = st;
+}
+
 // SND body in IQ mode: 7 bytes (flags, seq, smeter) + 10 bytes GPS + 512 x (I,Q) big-endian int16.
 // One wave per (channel, frame): lane l converts samples 8l .. 8l+7 (32 payload bytes at byte offset 17 + 32 l).
 __global__ __launch_bounds__(64) void ssdr_iqwire_kernel(SsdrWireArgs a)
@@ -315,6 +365,17 @@ hipError_t ssdr_launch_play_rs(const SsdrPlayArgs &a, hipStream_t stream)
 hipError_t ssdr_launch_play(const SsdrPlayArgs &a, hipStream_t stream)
 {
     hipLaunchKernelGGL(ssdr_play_kernel, dim3(a.n_ch), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t ssdr_launch_trace(const SsdrTraceArgs &a, hipStream_t stream)
+{
+    const uint64_t n = (uint64_t)a.n_ch * SSDR_NFFT;
+    hipLaunchKernelGGL(ssdr_trace_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
+hipError_t ssdr_launch_smeter(const SsdrSmeterArgs &a, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ssdr_smeter_kernel, dim3((a.n_ch + 255) / 256), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t ssdr_launch_iqwire(const SsdrWireArgs &a, hipStream_t stream)

@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
-from ._lib import ChanParams, ChanConsts, ChanState, Db2colChan, PlayChan, check, lib
+from ._lib import SmeterChan, ChanParams, ChanConsts, ChanState, Db2colChan, PlayChan, check, lib
 
 CONSTS_DTYPE = np.dtype([("mode", "<u4"), ("ntap8", "<u4"), ("dphi1", "<u4"), ("dphi2", "<u4"),
                          ("wf_cal_lin", "<f4"), ("smeter_cal_db", "<f4"), ("agc_c0", "<f4"), ("agc_c1", "<f4"),
@@ -142,6 +142,40 @@ class SsdrEngine:
         for i in range(self.n_ch):
             chans[i] = arr[i]
         return out
+
+    def set_wfdata_rows(self, rows):
+        """Keep the `rows` newest rows of kiwi_waterfall.wf_data on the device (fed by run_db2col); 0 = off."""
+        check(lib.ssdr_set_wfdata_rows(self._ctx, int(rows)), "ssdr_set_wfdata_rows")
+
+    def push_color_line(self, color):
+        """float32 [lines, n_ch, 1024] colour lines from elsewhere than run_db2col into the device copy of wf_data."""
+        color = np.ascontiguousarray(color, np.float32)
+        assert color.ndim == 3 and color.shape[1:] == (self.n_ch, L.NFFT)
+        check(lib.ssdr_push_color_lines(self._ctx, color.ctypes.data, color.shape[0], 0), "ssdr_push_color_lines")
+
+    def white_flag(self, first=0, count=None):
+        """kiwi_waterfall.set_white_flag (utils_supersdr.py:875-877) on the device copy of wf_data."""
+        check(lib.ssdr_wfdata_white_flag(self._ctx, int(first), self.n_ch - first if count is None else int(count)),
+              "ssdr_wfdata_white_flag")
+
+    def run_trace(self, t_avg=15, spectrum_height=0, want_y=True):
+        """plot_spectrum's reduction (utils_supersdr.py:1678-1679) -> (float64 [n_ch, 1024] nanmean over the t_avg newest
+        wf_data rows, int32 [n_ch, 1024] pixel rows or None)."""
+        trace = np.empty((self.n_ch, L.NFFT), np.float64)
+        y = np.empty((self.n_ch, L.NFFT), np.int32) if want_y else None
+        check(lib.ssdr_run_trace(self._ctx, int(t_avg), int(spectrum_height), trace.ctypes.data,
+                                 y.ctypes.data if want_y else None, 0), "ssdr_run_trace")
+        return trace, y
+
+    def run_smeter(self, chans, fps, rssi=None):
+        """One display frame of the S-meter smoothing (supersdr.py:936-947) per channel; chans (list of SmeterChan) is
+        updated in place.  rssi float64 [n_ch] or None (= last frame of the last run_audio)."""
+        arr = (SmeterChan * self.n_ch)(*chans)
+        r = None if rssi is None else np.ascontiguousarray(rssi, np.float64)
+        check(lib.ssdr_run_smeter(self._ctx, arr, None if r is None else r.ctypes.data, float(fps)), "ssdr_run_smeter")
+        for i in range(self.n_ch):
+            chans[i] = arr[i]
+        return chans
 
     def set_kiwi_rate(self, kiwi_rate):
         """kiwi_sound.KIWI_RATE (utils_supersdr.py:991-994): 12000, or 20250 for play_buffer's resample_poly branch."""

@@ -54,7 +54,7 @@ class IQHub:
         snd_queue[c] : (int16[512] pcm, float rssi) per audio frame
     """
 
-    def __init__(self, n_channels, device=0, engine=None, max_queue=64, gpu_post=True, kiwi_rate=12000):
+    def __init__(self, n_channels, device=0, engine=None, max_queue=64, gpu_post=True, kiwi_rate=12000, trace_rows=0):
         self.n_ch = int(n_channels)
         self.engine = engine if engine is not None else SsdrEngine(self.n_ch, device)
         # spectrum_db2col and play_buffer run on the GPU with every superframe (SURVEY.md 8f-1, 8f-2)
@@ -64,6 +64,11 @@ class IQHub:
         if self.gpu_post:
             self.engine.set_kiwi_rate(self.kiwi_rate)
             self.play_len = self.engine.playbuffer_frame_len()
+        # display reductions: wf_data's newest rows stay on the device, fed by every db2col run
+        self.trace_rows = int(trace_rows) if self.gpu_post else 0
+        if self.trace_rows:
+            self.engine.set_wfdata_rows(self.trace_rows)
+        self._smeter = None
         self.wf_clients = [None] * self.n_ch        # kiwi_waterfall objects: display state for db2col
         self.snd_clients = [None] * self.n_ch       # kiwi_sound objects: volume / balance for play_buffer
         self._buf = [np.zeros((0, 2), np.int16) for _ in range(self.n_ch)]
@@ -124,6 +129,25 @@ class IQHub:
                 for f in range(2):
                     blk = play[c, f * self.play_len:(f + 1) * self.play_len].copy() if play is not None else None
                     _put_drop_oldest(self.snd_queue[c], (pcm[c, f * L.FRAME:(f + 1) * L.FRAME].copy(), float(rssi[c, f]), blk))
+
+    def spectrum_trace(self, t_avg=15, spectrum_height=0):
+        """display_stuff.plot_spectrum's reduction for all channels (utils_supersdr.py:1678-1679): (float64 [n_ch, 1024]
+        np.nanmean over the t_avg newest wf_data rows, int32 [n_ch, 1024] pixel rows).  The device copy of wf_data
+        advances with the lines the hub produces (all channels in step), not with each worker's consumption."""
+        with self._lock:
+            return self.engine.run_trace(t_avg, spectrum_height)
+
+    def smeter_step(self, fps, decay_ms=None):
+        """One display frame of the main loop's S-meter smoothing (supersdr.py:936-947) for all channels, from the last
+        audio frame's RSSI.  Returns (rssi_smooth [n_ch], rssi_smooth_slow [n_ch])."""
+        from ._lib import SmeterChan
+        with self._lock:
+            if self._smeter is None:
+                self._smeter = [SmeterChan.start(-127.0) for _ in range(self.n_ch)]      # kiwi_sound.rssi before any frame
+            for c, s in enumerate(self.snd_clients):
+                self._smeter[c].decay_ms = float(decay_ms if decay_ms is not None else (s.decay if s is not None else 4000))
+            self.engine.run_smeter(self._smeter, fps)
+            return (np.array([s.rssi_smooth for s in self._smeter]), np.array([s.rssi_smooth_slow for s in self._smeter]))
 
     @staticmethod
     def _db2col_chan(w):

@@ -137,6 +137,81 @@ def test_play_buffer_resampled_matches_reference_golden(S):
             assert np.array_equal(out[c, f * 1213:(f + 1) * 1213], ref(pcm[c, f], *cfg[c])), (c, f)
 
 
+def test_spectrum_trace_matches_reference_golden(S):
+    """display_stuff.plot_spectrum (utils_supersdr.py:1669-1691) over the device copy of wf_data: (1) fed by ssdr_run_db2col,
+    white flag included, against the oracle; (2) the reference's own golden lines pushed in, against the pixel rows
+    recorded from the real plot_spectrum and the trace values of the same NumPy expression"""
+    from supersdr_amd._lib import Db2colChan
+    g = np.load(os.path.join(GOLD, "display.npz"))
+    # 1) ring bookkeeping + reduction against the oracle, colours produced by the db2col kernel itself
+    rng = np.random.default_rng(21)
+    n_ch, n_lines, t_avg, H = 3, 9, 5, 150
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_wfdata_rows(8)
+        wds = [O.WfData(8) for _ in range(n_ch)]
+        chans = [Db2colChan(zoom=c, auto_scale=1, low_clip_db=-120.0, high_clip_db=-60.0, dynamic_range=40.0) for c in range(n_ch)]
+        for step in range(n_lines):
+            nl = 1 + (step % 2)                                    # one or two lines per db2col call
+            wf = rng.integers(60, 200, (nl, n_ch, 1024)).astype(np.int16)
+            eng.set_wf_lines(wf)
+            col = eng.run_db2col(chans, nl)
+            for i in range(nl):
+                for c in range(n_ch):
+                    wds[c].push(col[i, c])
+            if step in (1, 5):                                     # set_white_flag (utils_supersdr.py:875-877) on channels 1..2
+                eng.white_flag(1, 2)
+                for c in (1, 2):
+                    wds[c].wf_data[0, :] = 255
+            trace, y = eng.run_trace(t_avg, H)
+            for c in range(n_ch):
+                v = O.spectrum_trace(wds[c].wf_data, t_avg)
+                assert np.array_equal(trace[c], v), (step, c)
+                assert np.array_equal(y[c], O.trace_pixels(v, H)), (step, c)
+        with pytest.raises(S.SsdrError):
+            eng.run_trace(9, H)                                    # more rows than are kept
+    # 2) the reference's own pixels
+    for c in range(int(g["count"])):
+        height, spec_h, n_l, ta = (int(v) for v in g["cfg_%d" % c])
+        with S.SsdrEngine(1) as eng:
+            eng.set_wfdata_rows(ta)
+            for line in g["lines_%d" % c]:
+                eng.push_color_line(line[None, None, :])
+            trace, y = eng.run_trace(ta, spec_h)
+        assert np.array_equal(trace[0], g["trace_%d" % c]), c
+        assert np.array_equal(y[0], g["y_%d" % c]), c
+
+
+def test_smeter_matches_reference_golden(S):
+    """S-meter smoothing of the main loop (supersdr.py:936-947), series produced by executing the reference's own lines.
+    float64 log/exp come from different libraries (glibc on the host, ocml on the device): tolerance 1e-9 dB."""
+    from supersdr_amd._lib import SmeterChan
+    g = np.load(os.path.join(GOLD, "display.npz"))
+    n = int(g["sm_count"])
+    rssi = np.stack([g["sm_in_%d" % c] for c in range(n)])                 # [n_ch, T]
+    fps = [float(g["sm_cfg_%d" % c][1]) for c in range(n)]
+    for c in range(n):                                                       # fps is per call: one engine per case
+        with S.SsdrEngine(1) as eng:
+            st = [SmeterChan.start(rssi[c, 0], g["sm_cfg_%d" % c][0])]
+            sm, sl = [], []
+            for i in range(rssi.shape[1]):
+                eng.run_smeter(st, fps[c], rssi[c, i:i + 1])
+                sm.append(st[0].rssi_smooth)
+                sl.append(st[0].rssi_smooth_slow)
+        assert np.allclose(sm, g["sm_smooth_%d" % c], rtol=0, atol=1e-9), c
+        assert np.array_equal(sl, g["sm_slow_%d" % c]), c
+    # RSSI taken from the last audio frame on the device
+    with S.SsdrEngine(2) as eng:
+        eng.synth_iq(2, seed=5)
+        _, r = eng.run_audio()
+        st = [SmeterChan.start(-127.0), SmeterChan.start(-127.0)]
+        eng.run_smeter(st, 30.0)
+        ref = [O.SMeter(-127.0) for _ in range(2)]
+        for c in range(2):
+            want = ref[c].step(float(r[c, -1]), 4000.0, 30.0, 0)
+            assert abs(st[c].rssi_smooth - want[0]) < 1e-9 and st[c].rssi_smooth_slow == want[1]
+            assert st[c].run_index == 1
+
+
 def test_iq_wire_decode_matches_reference_golden(S):
     g = np.load(os.path.join(GOLD, "frames.npz"))
     body = g["iq_body"]

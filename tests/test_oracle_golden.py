@@ -100,6 +100,25 @@ def test_resample_tap_table_is_scipys():
     assert "#define SSDR_RS_PRE_REMOVE %d " % n_pre_remove in text and "#define SSDR_RS_HPP %d\n" % (len(tf) // 64) in text
 
 
+def test_display_reductions_match_reference():
+    """plot_spectrum's trace (real reference drawing into a recording PixelArray) and the S-meter lines of the main loop"""
+    g = gold("display.npz")
+    for c in range(int(g["count"])):
+        height, spec_h, n_lines, t_avg = (int(v) for v in g["cfg_%d" % c])
+        wd = O.WfData(height)
+        for line in g["lines_%d" % c]:
+            wd.push(line)
+        v = O.spectrum_trace(wd.wf_data, t_avg)
+        assert np.array_equal(v, g["trace_%d" % c]), c
+        assert np.array_equal(O.trace_pixels(v, spec_h), g["y_%d" % c]), c
+    for c in range(int(g["sm_count"])):
+        decay, fps = g["sm_cfg_%d" % c]
+        rssi = g["sm_in_%d" % c]
+        sm = O.SMeter(float(rssi[0]))
+        got = np.array([sm.step(float(r), decay, fps, i) for i, r in enumerate(rssi)])
+        assert np.array_equal(got[:, 0], g["sm_smooth_%d" % c]) and np.array_equal(got[:, 1], g["sm_slow_%d" % c]), c
+
+
 def test_frame_decoders_match_reference():
     g = gold("frames.npz")
     assert np.array_equal(O.decode_wf_frame(g["wf_msg"].tobytes()), g["wf_spectrum"])
