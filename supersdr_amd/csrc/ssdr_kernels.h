@@ -14,12 +14,10 @@
 #define SSDR_WF_ABLATE 0                     // profiling ablations only (1 memory-only, 2 no loads, 3 no stores)
 #endif
 #define SSDR_TW_STAGE_N 992                  // per-stage twiddle table entries: 32*(1+2+4+8+16)
-// dB quantiser table: one entry per 2^-SSDR_LUT_BITS octave segment of [2^-37, 2^50], indexed by
-// bits(p) >> (23 - SSDR_LUT_BITS).  4 bits: 0.19 dB segments, index from one SDWA op, 11 KB;
-// 2 bits: 0.75 dB segments (still < 1 dB: at most one threshold inside), shift + and, 2.8 KB.
-#ifndef SSDR_LUT_BITS
+// dB quantiser table: one entry per quarter-octave segment of [2^-37, 2^50] (0.75 dB < 1 dB: at most one threshold
+// inside a segment), indexed by bits(p) >> (23 - SSDR_LUT_BITS): shift + and, 2.8 KB.  (A 16-segment-per-octave table
+// indexed by one SDWA op was measured slower: 9x LDS bank conflicts, profiles/README.md.)
 #define SSDR_LUT_BITS 2
-#endif
 #define SSDR_LUT_PLO 0x1p-37f
 #define SSDR_LUT_PHI 0x1p50f
 #define SSDR_LUT_SHIFT (23 - SSDR_LUT_BITS)

@@ -42,17 +42,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 //   6..10 (992 float2), quantiser table, then the per-wave transpose / staging buffers (2 x 4224 B).
 constexpr int LDS_LUT0 = SSDR_LUT_IDX0 * 8;                     // address of the first stored entry
 constexpr int LDS_LUT_END = LDS_LUT0 + SSDR_LUT_N * 8;
-#if SSDR_LUT_BITS == 4
-constexpr int LDS_WIN = 0;                                      // [0, 2064)
-constexpr int LDS_TW = 2064;                                    // [2064, 10000)   table at [11520, 22664)
-constexpr int LDS_XCH = (LDS_LUT_END + 15) & ~15;
-static_assert(LDS_TW + SSDR_TW_STAGE_N * 8 <= LDS_LUT0, "tables overlap");
-#else
 constexpr int LDS_WIN = 0;                                      // [0, 2064)       table at [2880, 5672)
 constexpr int LDS_TW = (LDS_LUT_END + 15) & ~15;                // [5680, 13616)
 constexpr int LDS_XCH = LDS_TW + SSDR_TW_STAGE_N * 8;
 static_assert(LDS_WIN + 2064 <= LDS_LUT0, "tables overlap");
-#endif
 constexpr int LDS_TOTAL = LDS_XCH + WAVES * 2 * XCH_FLOATS * 4;
 static_assert(LDS_XCH % 16 == 0 && LDS_TW % 8 == 0, "alignment");
 static_assert(LDS_TOTAL <= 163840, "LDS budget");
@@ -169,14 +162,7 @@ SSDR_DEV void wave_lds_sync()
 SSDR_DEV float quant_clamp(float p) { return __builtin_amdgcn_fmed3f(p, SSDR_LUT_PLO, SSDR_LUT_PHI); }
 SSDR_DEV uint32_t quant_addr(float pc, uint32_t mask)
 {
-#if SSDR_LUT_BITS == 4
-    uint32_t off;      // one full-rate op: SDWA picks the upper half-word, the mask (0xFFF8) drops the low mantissa bits
-    asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
-        : "=v"(off) : "v"(__float_as_uint(pc)), "v"(mask));
-    return off;
-#else
     return (__float_as_uint(pc) >> (SSDR_LUT_SHIFT - 3)) & mask;            // mask = ~7
-#endif
 }
 SSDR_DEV uint32_t quant_result(float pc, uint2 e) { return e.x + ((pc >= __uint_as_float(e.y)) ? 1u : 0u); }
 SSDR_DEV uint32_t quantise(float p, const unsigned char *lut0, uint32_t mask)
@@ -346,7 +332,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, l = lane & 31;
     float *xch_wave = reinterpret_cast<float *>(smem + LDS_XCH) + wave * 2 * XCH_FLOATS;      // wave-uniform
-    const uint32_t mask_fff8 = (SSDR_LUT_BITS == 4) ? 0xFFF8u : ~7u;
+    const uint32_t lut_mask = ~7u;
     const unsigned char *lut0 = smem;
     const uint32_t n_pairs = (a.n_ch + 1) >> 1;
     const uint32_t n_items = n_pairs * a.n_groups;
@@ -380,10 +366,10 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
 
             // |X|^2 -> 1-dB byte; bin k = 32 j + l lands at fftshifted position 32 ((j+16)&31) + l
             if (AVG) {
-                quantise32(z, cal, lut0, mask_fff8, [&](int j, uint32_t q0, uint32_t q1) { acc[j] += q0 + (q1 << 16); });
+                quantise32(z, cal, lut0, lut_mask, [&](int j, uint32_t q0, uint32_t q1) { acc[j] += q0 + (q1 << 16); });
             } else {
                 uint32_t q[16];                                     // bins j | j+16, written out after the last look-up
-                quantise32(z, cal, lut0, mask_fff8, [&](int j, uint32_t q0, uint32_t q1) { q[j] = q0 | (q1 << 16); });
+                quantise32(z, cal, lut0, lut_mask, [&](int j, uint32_t q0, uint32_t q1) { q[j] = q0 | (q1 << 16); });
                 int16_t *x16 = reinterpret_cast<int16_t *>(xch_wave + opaque(h) * XCH_FLOATS) + opaque(l);
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
@@ -430,7 +416,7 @@ __global__ __launch_bounds__(256) void ssdr_quant_selftest_kernel(const float *t
     for (int i = threadIdx.x; i < SSDR_LUT_N; i += blockDim.x) s_lut[i] = lut[i];
     __syncthreads();
     unsigned long long bad = 0;
-    const uint32_t mask_fff8 = (SSDR_LUT_BITS == 4) ? 0xFFF8u : ~7u;
+    const uint32_t lut_mask = ~7u;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < 0x7F800000ull; u += stride) {
         const float p = __uint_as_float((uint32_t)u);
@@ -439,7 +425,7 @@ __global__ __launch_bounds__(256) void ssdr_quant_selftest_kernel(const float *t
             const int mid = (lo + hi + 1) >> 1;
             if (s_thr[mid] <= p) lo = mid; else hi = mid - 1;
         }
-        bad += (quantise(p, smem, mask_fff8) != (uint32_t)lo);
+        bad += (quantise(p, smem, lut_mask) != (uint32_t)lo);
     }
     if (bad) atomicAdd(mismatch, bad);
 }
