@@ -198,6 +198,7 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
     const uint32_t *src = a.iq + (uint64_t)ch * a.ch_stride + 8 * l;
     int16_t *dst = a.pcm + (uint64_t)ch * a.n_frames * SSDR_FRAME + 8 * l;
     u32x4 raw0, raw1;
+    float rssi_sum = 0.0f;
 
     for (uint32_t f = 0; f < a.n_frames; f++, src += SSDR_FRAME, dst += SSDR_FRAME) {
         raw0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src));
@@ -321,11 +322,16 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
         }
         __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(dst));
 
-        // 6. RSSI: sum over the frame = last lane of the inclusive sum scan
+        // 6. RSSI: sum over the frame = last lane of the inclusive sum scan.  Lane (f mod 64) keeps the sum; the
+        //    conversion to dBm runs once per 64 frames (or at the end of the call) for all kept sums together,
+        //    instead of one log2 per frame on a single lane.
         const float tot = lane63(scan_sum(ps));
-        if (l == 0)
-            a.rssi[(uint64_t)ch * a.n_frames + f] =
-                fmaf(ssdr_log2p(fmaxf(tot, 1e-20f)) - 39.0f, SSDR_DB_PER_LOG2, cal);
+        if ((f & 63u) == (uint32_t)l) rssi_sum = tot;
+        if ((f & 63u) == 63u || f + 1 == a.n_frames) {
+            if ((uint32_t)l <= (f & 63u))
+                a.rssi[(uint64_t)ch * a.n_frames + (f & ~63u) + l] =
+                    fmaf(ssdr_log2p(fmaxf(rssi_sum, 1e-20f)) - 39.0f, SSDR_DB_PER_LOG2, cal);
+        }
 
         // 7. carry: phases advance one frame; the frame tail becomes the FIR history
         phi1 += (uint32_t)SSDR_FRAME * dphi1;

@@ -141,7 +141,7 @@ def test_wf_calibration_and_edges(S, twin):
     assert not ((wf[:, 3] != o3) & ~g3).any()
 
 
-@pytest.mark.parametrize("n_ch,n_frames", [(1, 1), (4, 2), (16, 5), (67, 3)])
+@pytest.mark.parametrize("n_ch,n_frames", [(1, 1), (4, 2), (16, 5), (67, 3), (2, 64), (3, 130)])   # > 64 frames: RSSI is converted in batches of 64
 def test_audio_bit_exact_vs_twin_and_oracle(S, twin, n_ch, n_frames):
     iq = O.synth_iq(n_ch, n_frames * 512, seed=21 + n_ch)
     ps, ops = mixed_params(S, n_ch)
