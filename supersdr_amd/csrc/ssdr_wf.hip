@@ -356,8 +356,8 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
             load_line(src, raw);
 #endif
 #if SSDR_WF_ABLATE == 1      // ablation: memory traffic only
-#pragma unroll
             int16_t *x16 = reinterpret_cast<int16_t *>(xch_wave + opaque(h) * XCH_FLOATS) + opaque(l);
+#pragma unroll
             for (int j = 0; j < 32; j++) x16[32 * ((j + 16) & 31)] = (int16_t)(raw[j] & 0xFF);
 #else
             window_line(raw, smem, l, z);
