@@ -232,6 +232,7 @@ SSDR_DEV void window_line(const uint32_t (&raw)[32], const unsigned char *smem, 
 }
 
 // 1024-pt FFT of the windowed line held by this 32-lane half; on return z[j] = X[32 j + l]
+template <bool TIGHT>
 SSDR_DEV void fft_line(f32x2 (&z)[32], const unsigned char *smem, float *xch_wave, int h, int l)
 {
     stage_const<1>(z);
@@ -270,23 +271,54 @@ SSDR_DEV void fft_line(f32x2 (&z)[32], const unsigned char *smem, float *xch_wav
     SCHED_FENCE();
     stage_lane<0, 0, 1>(z, w0);
     stage_lane<1, 0, 2>(z, w1);
-    f32x2 w3[8];
-    load_tw<3, 0, 8>(w3, s_tw_lane);
-    SCHED_FENCE();
-    stage_lane<2, 0, 4>(z, w2);
-    SCHED_FENCE();
-    f32x2 w4a[8];
-    load_tw<4, 0, 8>(w4a, s_tw_lane);
-    SCHED_FENCE();
-    stage_lane<3, 0, 8>(z, w3);
-    SCHED_FENCE();
-    f32x2 w4b[8];
-    load_tw<4, 8, 8>(w4b, s_tw_lane);
-    SCHED_FENCE();
-    stage_lane<4, 0, 8>(z, w4a);
-    SCHED_FENCE();
-    stage_lane<4, 8, 8>(z, w4b);
-    SCHED_FENCE();
+    if (!TIGHT) {
+        f32x2 w3[8];
+        load_tw<3, 0, 8>(w3, s_tw_lane);
+        SCHED_FENCE();
+        stage_lane<2, 0, 4>(z, w2);
+        SCHED_FENCE();
+        f32x2 w4a[8];
+        load_tw<4, 0, 8>(w4a, s_tw_lane);
+        SCHED_FENCE();
+        stage_lane<3, 0, 8>(z, w3);
+        SCHED_FENCE();
+        f32x2 w4b[8];
+        load_tw<4, 8, 8>(w4b, s_tw_lane);
+        SCHED_FENCE();
+        stage_lane<4, 0, 8>(z, w4a);
+        SCHED_FENCE();
+        stage_lane<4, 8, 8>(z, w4b);
+        SCHED_FENCE();
+    } else {
+        // the averaging kernel also carries 16 accumulator registers: twiddles arrive in groups of four, one group ahead
+        f32x2 wa[4], wb[4];
+        load_tw<3, 0, 4>(wa, s_tw_lane);
+        SCHED_FENCE();
+        stage_lane<2, 0, 4>(z, w2);
+        SCHED_FENCE();
+        load_tw<3, 4, 4>(wb, s_tw_lane);
+        SCHED_FENCE();
+        stage_lane<3, 0, 4>(z, wa);
+        SCHED_FENCE();
+        load_tw<4, 0, 4>(wa, s_tw_lane);
+        SCHED_FENCE();
+        stage_lane<3, 4, 4>(z, wb);
+        SCHED_FENCE();
+        load_tw<4, 4, 4>(wb, s_tw_lane);
+        SCHED_FENCE();
+        stage_lane<4, 0, 4>(z, wa);
+        SCHED_FENCE();
+        load_tw<4, 8, 4>(wa, s_tw_lane);
+        SCHED_FENCE();
+        stage_lane<4, 4, 4>(z, wb);
+        SCHED_FENCE();
+        load_tw<4, 12, 4>(wb, s_tw_lane);
+        SCHED_FENCE();
+        stage_lane<4, 8, 4>(z, wa);
+        SCHED_FENCE();
+        stage_lane<4, 12, 4>(z, wb);
+        SCHED_FENCE();
+    }
 }
 
 struct WfItem {                 // one (channel pair, averaging group) work item, wave-uniform except ch/ch_ok
@@ -362,7 +394,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
 #else
             window_line(raw, smem, l, z);
             SCHED_FENCE();
-            fft_line(z, smem, xch_wave, h, l);
+            fft_line<AVG>(z, smem, xch_wave, h, l);
 
             // |X|^2 -> 1-dB byte; bin k = 32 j + l lands at fftshifted position 32 ((j+16)&31) + l
             if (AVG) {
