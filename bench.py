@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--channels", type=int, default=0, help="override channels per GPU")
     ap.add_argument("--superframes", type=int, default=0, help="override superframes per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-feed", type=int, default=0,
+                    help="1: inputs come from (pinned) host memory and results go back to it through the pipelined feed "
+                         "(ssdr_feed_*): the PCIe-inclusive rate of DESIGN.md, never the headline value")
     ap.add_argument("--concurrent", type=int, default=0, help="1: audio kernel on a second stream beside the waterfall kernel")
     args = ap.parse_args()
 
@@ -141,6 +144,25 @@ def main():
         if do_audio:
             eng.run_audio(fetch=False)
 
+    if args.host_feed:
+        depth = 3
+        host_batch = eng.read_input()                     # one synthetic batch, replayed from pinned host memory
+        eng.feed_open(n_frames, depth)
+        for _ in range(depth):                            # fill every slot once: the timed loop measures transport + kernels
+            eng.feed_slot()[:] = host_batch.reshape(channels, -1, 2)
+            eng.feed_submit()
+        for _ in range(depth):
+            eng.feed_collect()
+        inflight = [0]
+
+        def step():                                       # noqa: F811  (steady state: one submit, one collect)
+            eng.feed_slot()
+            eng.feed_submit()
+            inflight[0] += 1
+            if inflight[0] == depth:
+                eng.feed_collect()
+                inflight[0] -= 1
+
     barrier = rdv.barrier
 
     t_spin = time.perf_counter()            # clock spin-up from the idle state, then the W warmup steps proper
@@ -159,6 +181,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if args.host_feed:
+        while inflight[0]:
+            eng.feed_collect()
+            inflight[0] -= 1
     eng.sync()
     torch.cuda.synchronize()
     barrier()
@@ -210,6 +236,7 @@ def main():
                                 "mixed": "65536 channels mixed AM/USB/LSB/NBFM + 10x time binning, BASELINE configs[3]"}[args.workload],
                    "channels_per_gpu": channels, "superframes_per_step": sframes, "averaging_n": n_avg,
                    "clock_spinup_s": args.spinup,
+                   "input": "pinned host memory, pipelined H2D / kernels / D2H (PCIe-inclusive)" if args.host_feed else "resident in HBM",
                    "sharding": "channel blocks per GPU, no collectives", "rendezvous": rdv.backend if world > 1 else "none"},
         "roofline": roof(dom),
     }

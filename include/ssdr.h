@@ -193,6 +193,27 @@ int ssdr_push_iq_wire(ssdr_ctx *ctx, const uint8_t *bodies, uint32_t n_frames, f
  * {index, prev} in/out (zero it per W/F line, keep it across SND frames); out int16 [n_streams][2*n_bytes]. */
 int ssdr_adpcm_decode(ssdr_ctx *ctx, const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state, int16_t *out);
 
+/* -- pipelined host feed: the path a live ingest takes (KiwiSDRStream._process_iq_samples -> batches, kiwi/client.py:493)
+ *
+ * ssdr_push_iq + ssdr_run_* from pageable host memory serialise copy-in, kernels and copy-out.  The feed keeps `depth`
+ * slots of pinned host memory with their own device buffers and runs three HIP streams: while the kernels work on
+ * batch k, batch k+1 is copied in and the results of batch k-1 are copied out.  Results are those of ssdr_push_iq /
+ * ssdr_run_wf / ssdr_run_audio on the same batches in the same order (state and partial waterfall sums carry over).
+ *
+ *   ssdr_feed_open(ctx, n_frames, depth)   n_frames (even) 512-sample frames per channel and batch, 2 <= depth <= 16
+ *   ssdr_feed_slot(ctx, &iq)               pinned int16 [n_ch][n_frames*512][2] to fill; SSDR_ESTATE if all slots are in flight
+ *   ssdr_feed_submit(ctx)                  queue the slot: copy-in, both kernels, copy-out; returns at once
+ *   ssdr_feed_collect(ctx, &wf, &lines, &pcm, &rssi)
+ *                                          wait for the OLDEST submitted batch; pinned int16 [lines][n_ch][1024], int16
+ *                                          [n_ch][n_frames*512], float [n_ch][n_frames]; valid until that slot is handed out again
+ *   ssdr_feed_close(ctx)
+ * The post-processing entry points (db2col, playbuffer, trace) keep referring to the last ssdr_run_* batch, not to fed ones. */
+int ssdr_feed_open(ssdr_ctx *ctx, uint32_t n_frames, uint32_t depth);
+int ssdr_feed_slot(ssdr_ctx *ctx, int16_t **host_iq);
+int ssdr_feed_submit(ssdr_ctx *ctx);
+int ssdr_feed_collect(ssdr_ctx *ctx, int16_t **wf_sum, uint32_t *lines, int16_t **pcm, float **rssi);
+int ssdr_feed_close(ssdr_ctx *ctx);
+
 /* -- device-resident results of the last run_* (for zero-copy consumers and bench) */
 int ssdr_wf_device(ssdr_ctx *ctx, int16_t **ptr, uint32_t *lines);
 int ssdr_audio_device(ssdr_ctx *ctx, int16_t **pcm, float **rssi);

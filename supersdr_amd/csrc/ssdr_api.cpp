@@ -53,6 +53,20 @@ struct ssdr_ctx {
     int16_t *d_pcm = nullptr;
     float *d_rssi = nullptr;
     size_t audio_frames = 0;
+    // pipelined host feed (ssdr_feed_*): slots of pinned host memory + their own device buffers
+    struct FeedSlot {
+        int16_t *h_in = nullptr, *h_wf = nullptr, *h_pcm = nullptr;
+        float *h_rssi = nullptr;
+        uint32_t *d_in = nullptr;
+        int16_t *d_wf = nullptr, *d_pcm = nullptr;
+        float *d_rssi = nullptr;
+        hipEvent_t ev_in = nullptr, ev_run = nullptr, ev_out = nullptr;
+        uint32_t lines = 0;
+    };
+    std::vector<FeedSlot> feed;
+    uint32_t feed_frames = 0, feed_head = 0, feed_tail = 0, feed_inflight = 0;
+    bool feed_taken = false;                             // slot at feed_head handed to the caller, not yet submitted
+    hipStream_t feed_s_in = nullptr, feed_s_out = nullptr;
     // measurement
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;            // last launch (ssdr_elapsed_ms)
@@ -155,6 +169,7 @@ void ssdr_destroy(ssdr_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)ssdr_feed_close(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
@@ -572,6 +587,126 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         HIP_TRY(hipEventRecord(c->ev_a, s));
         c->audio_pending = true;
     }
+    return SSDR_OK;
+}
+
+// ---- pipelined host feed ------------------------------------------------------------------------------------
+// Three streams: host->device copy of batch k+1, the two kernels of batch k, device->host copy of batch k-1.
+// The kernels stay on the ctx stream, in batch order, so the per-channel state and the waterfall's partial sums
+// carry from batch to batch exactly as with ssdr_push_iq / ssdr_run_*.
+int ssdr_feed_close(ssdr_ctx *c)
+{
+    if (!c) return SSDR_EINVAL;
+    if (c->feed.empty()) return SSDR_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->feed_s_in) (void)hipStreamSynchronize(c->feed_s_in);
+    if (c->feed_s_out) (void)hipStreamSynchronize(c->feed_s_out);
+    for (auto &s : c->feed) {
+        void *hp[] = {s.h_in, s.h_wf, s.h_pcm, s.h_rssi};
+        for (void *p : hp) if (p) (void)hipHostFree(p);
+        void *dp[] = {s.d_in, s.d_wf, s.d_pcm, s.d_rssi};
+        for (void *p : dp) if (p) (void)hipFree(p);
+        hipEvent_t ev[] = {s.ev_in, s.ev_run, s.ev_out};
+        for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
+    }
+    c->feed.clear();
+    if (c->feed_s_in) { (void)hipStreamDestroy(c->feed_s_in); c->feed_s_in = nullptr; }
+    if (c->feed_s_out) { (void)hipStreamDestroy(c->feed_s_out); c->feed_s_out = nullptr; }
+    c->feed_frames = c->feed_head = c->feed_tail = c->feed_inflight = 0;
+    c->feed_taken = false;
+    return SSDR_OK;
+}
+
+int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth)
+{
+    if (!c || n_frames == 0 || (n_frames & 1u) || depth < 2 || depth > 16) return SSDR_EINVAL;
+    if (!c->feed.empty() || c->concurrent) return SSDR_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t in_b = (size_t)c->n_ch * n_frames * SSDR_FRAME * 4;
+    const size_t wf_b = (size_t)(n_frames / 2) * c->n_ch * SSDR_NFFT * 2;
+    const size_t pcm_b = (size_t)c->n_ch * n_frames * SSDR_FRAME * 2;
+    const size_t rssi_b = (size_t)c->n_ch * n_frames * sizeof(float);
+    c->feed.resize(depth);
+    bool ok = hipStreamCreateWithFlags(&c->feed_s_in, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->feed_s_out, hipStreamNonBlocking) == hipSuccess;
+    for (auto &s : c->feed) {
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_in), in_b, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_wf), wf_b, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_pcm), pcm_b, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_rssi), rssi_b, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipMalloc(&s.d_in, in_b) == hipSuccess && hipMalloc(&s.d_wf, wf_b) == hipSuccess;
+        ok = ok && hipMalloc(&s.d_pcm, pcm_b) == hipSuccess && hipMalloc(&s.d_rssi, rssi_b) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&s.ev_run, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming) == hipSuccess;
+    }
+    c->feed_frames = n_frames;
+    if (!ok) { (void)hipGetLastError(); (void)ssdr_feed_close(c); return SSDR_ENOMEM; }
+    return SSDR_OK;
+}
+
+int ssdr_feed_slot(ssdr_ctx *c, int16_t **host_iq)
+{
+    if (!c || !host_iq) return SSDR_EINVAL;
+    if (c->feed.empty() || c->feed_taken) return SSDR_ESTATE;
+    if (c->feed_inflight == c->feed.size()) return SSDR_ESTATE;      // collect first: every slot is in flight
+    *host_iq = c->feed[c->feed_head].h_in;
+    c->feed_taken = true;
+    return SSDR_OK;
+}
+
+int ssdr_feed_submit(ssdr_ctx *c)
+{
+    if (!c) return SSDR_EINVAL;
+    if (c->feed.empty() || !c->feed_taken) return SSDR_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    auto &s = c->feed[c->feed_head];
+    const uint32_t nf = c->feed_frames;
+    HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, (size_t)c->n_ch * nf * SSDR_FRAME * 4, hipMemcpyHostToDevice, c->feed_s_in));
+    HIP_TRY(hipEventRecord(s.ev_in, c->feed_s_in));
+    HIP_TRY(hipStreamWaitEvent(c->stream, s.ev_in, 0));
+    // run the two kernels on this slot's buffers: the ctx's own batch pointers are parked meanwhile
+    const uint32_t *k_iq = c->d_iq; const uint32_t k_frames = c->in_frames; const bool k_have = c->have_input;
+    int16_t *k_wf = c->d_wf_out; const size_t k_wf_lines = c->wf_out_lines; const uint32_t k_ready = c->wf_lines_ready;
+    int16_t *k_pcm = c->d_pcm; float *k_rssi = c->d_rssi; const size_t k_af = c->audio_frames;
+    c->d_iq = s.d_in; c->in_frames = nf; c->have_input = true;
+    c->d_wf_out = s.d_wf; c->wf_out_lines = nf / 2;
+    c->d_pcm = s.d_pcm; c->d_rssi = s.d_rssi; c->audio_frames = nf;
+    uint32_t lines = 0;
+    int rc = ssdr_run_wf(c, nullptr, &lines, 0);
+    if (rc == SSDR_OK) rc = ssdr_run_audio(c, nullptr, nullptr, 0);
+    c->d_iq = k_iq; c->in_frames = k_frames; c->have_input = k_have;
+    c->d_wf_out = k_wf; c->wf_out_lines = k_wf_lines; c->wf_lines_ready = k_ready;
+    c->d_pcm = k_pcm; c->d_rssi = k_rssi; c->audio_frames = k_af;
+    if (rc != SSDR_OK) return rc;
+    s.lines = lines;
+    HIP_TRY(hipEventRecord(s.ev_run, c->stream));
+    HIP_TRY(hipStreamWaitEvent(c->feed_s_out, s.ev_run, 0));
+    if (lines)
+        HIP_TRY(hipMemcpyAsync(s.h_wf, s.d_wf, (size_t)lines * c->n_ch * SSDR_NFFT * 2, hipMemcpyDeviceToHost, c->feed_s_out));
+    HIP_TRY(hipMemcpyAsync(s.h_pcm, s.d_pcm, (size_t)c->n_ch * nf * SSDR_FRAME * 2, hipMemcpyDeviceToHost, c->feed_s_out));
+    HIP_TRY(hipMemcpyAsync(s.h_rssi, s.d_rssi, (size_t)c->n_ch * nf * sizeof(float), hipMemcpyDeviceToHost, c->feed_s_out));
+    HIP_TRY(hipEventRecord(s.ev_out, c->feed_s_out));
+    c->feed_head = (c->feed_head + 1) % (uint32_t)c->feed.size();
+    c->feed_inflight++;
+    c->feed_taken = false;
+    return SSDR_OK;
+}
+
+int ssdr_feed_collect(ssdr_ctx *c, int16_t **wf_sum, uint32_t *lines, int16_t **pcm, float **rssi)
+{
+    if (!c) return SSDR_EINVAL;
+    if (c->feed.empty() || c->feed_inflight == 0) return SSDR_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    auto &s = c->feed[c->feed_tail];
+    HIP_TRY(hipEventSynchronize(s.ev_out));
+    if (wf_sum) *wf_sum = s.h_wf;
+    if (lines) *lines = s.lines;
+    if (pcm) *pcm = s.h_pcm;
+    if (rssi) *rssi = s.h_rssi;
+    c->feed_tail = (c->feed_tail + 1) % (uint32_t)c->feed.size();
+    c->feed_inflight--;
     return SSDR_OK;
 }
 

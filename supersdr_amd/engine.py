@@ -143,6 +143,36 @@ class SsdrEngine:
             chans[i] = arr[i]
         return out
 
+    # ---- pipelined host feed (copy-in / kernels / copy-out of consecutive batches overlap)
+    def feed_open(self, n_frames, depth=3):
+        check(lib.ssdr_feed_open(self._ctx, int(n_frames), int(depth)), "ssdr_feed_open")
+        self._feed_frames = int(n_frames)
+
+    def feed_slot(self):
+        """-> int16 [n_ch, n_frames*512, 2] view of the next pinned slot (fill it, then feed_submit())."""
+        p = C.c_void_p()
+        check(lib.ssdr_feed_slot(self._ctx, C.byref(p)), "ssdr_feed_slot")
+        n = self.n_ch * self._feed_frames * L.FRAME * 2
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), shape=(n,)).reshape(self.n_ch, -1, 2)
+
+    def feed_submit(self):
+        check(lib.ssdr_feed_submit(self._ctx), "ssdr_feed_submit")
+
+    def feed_collect(self):
+        """Oldest submitted batch -> (wf int16 [lines, n_ch, 1024], pcm int16 [n_ch, n_frames*512], rssi float32
+        [n_ch, n_frames]) as views of pinned memory, valid until that slot is handed out again."""
+        wf, pcm, rssi, lines = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
+        check(lib.ssdr_feed_collect(self._ctx, C.byref(wf), C.byref(lines), C.byref(pcm), C.byref(rssi)), "ssdr_feed_collect")
+        nf, nl = self._feed_frames, int(lines.value)
+        w = (np.ctypeslib.as_array(C.cast(wf, C.POINTER(C.c_int16)), shape=(nl * self.n_ch * L.NFFT,)).reshape(nl, self.n_ch, L.NFFT)
+             if nl else np.zeros((0, self.n_ch, L.NFFT), np.int16))
+        p = np.ctypeslib.as_array(C.cast(pcm, C.POINTER(C.c_int16)), shape=(self.n_ch * nf * L.FRAME,)).reshape(self.n_ch, -1)
+        r = np.ctypeslib.as_array(C.cast(rssi, C.POINTER(C.c_float)), shape=(self.n_ch * nf,)).reshape(self.n_ch, nf)
+        return w, p, r
+
+    def feed_close(self):
+        check(lib.ssdr_feed_close(self._ctx), "ssdr_feed_close")
+
     def set_wfdata_rows(self, rows):
         """Keep the `rows` newest rows of kiwi_waterfall.wf_data on the device (fed by run_db2col); 0 = off."""
         check(lib.ssdr_set_wfdata_rows(self._ctx, int(rows)), "ssdr_set_wfdata_rows")

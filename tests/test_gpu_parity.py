@@ -244,6 +244,46 @@ def test_synth_input_roundtrip_and_parity(S, twin):
     assert np.array_equal(pcm, pcm_t) and np.array_equal(rssi, rssi_t)
 
 
+def test_pipelined_feed_equals_push_and_run(S):
+    """ssdr_feed_*: batches in flight on three streams give the results of push_iq + run_wf + run_audio in order
+    (state, FIR history and partial waterfall sums carried), also when slots are reused and N does not divide a batch"""
+    n_ch, nf, n_batches = 6, 4, 7
+    iq = O.synth_iq(n_ch, n_batches * nf * 512, seed=91)
+    ps, _ = mixed_params(S, n_ch)
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.set_averaging(3)
+        want = []
+        for b in range(n_batches):
+            eng.push_iq(iq[:, b * nf * 512:(b + 1) * nf * 512])
+            wf = eng.run_wf()
+            pcm, rssi = eng.run_audio()
+            want.append((wf.copy(), pcm.copy(), rssi.copy()))
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.set_averaging(3)
+        eng.feed_open(nf, depth=3)
+        got, sub = [], 0
+        for b in range(n_batches):
+            if sub - len(got) == 3:                              # every slot in flight: the next slot must be refused
+                with pytest.raises(S.SsdrError):
+                    eng.feed_slot()
+                got.append(tuple(x.copy() for x in eng.feed_collect()))
+            eng.feed_slot()[:] = iq[:, b * nf * 512:(b + 1) * nf * 512]
+            eng.feed_submit()
+            sub += 1
+        while len(got) < n_batches:
+            got.append(tuple(x.copy() for x in eng.feed_collect()))
+        with pytest.raises(S.SsdrError):
+            eng.feed_collect()
+        eng.feed_close()
+        eng.push_iq(iq[:, :nf * 512])                            # the ordinary path still works afterwards
+        eng.run_audio()
+    for b in range(n_batches):
+        for k in range(3):
+            assert np.array_equal(got[b][k], want[b][k]), (b, k)
+
+
 def test_error_codes(S):
     from supersdr_amd import _lib as L
     import ctypes as C
