@@ -22,6 +22,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -104,7 +106,7 @@ def main():
     ap.add_argument("--superframes", type=int, default=0, help="override superframes per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-feed", type=int, default=0,
-                    help="1: inputs come from (pinned) host memory and results go back to it through the pipelined feed "
+                    help="1: inputs come from (pinned) host memory (2: as SND wire bodies, unpacked on the device) and results go back to it through the pipelined feed "
                          "(ssdr_feed_*): the PCIe-inclusive rate of DESIGN.md, never the headline value")
     ap.add_argument("--concurrent", type=int, default=0, help="1: audio kernel on a second stream beside the waterfall kernel")
     args = ap.parse_args()
@@ -147,9 +149,15 @@ def main():
     if args.host_feed:
         depth = 3
         host_batch = eng.read_input()                     # one synthetic batch, replayed from pinned host memory
-        eng.feed_open(n_frames, depth)
+        eng.feed_open(n_frames, depth, wire=(args.host_feed == 2))
+        if args.host_feed == 2:                           # SND bodies as they come off the socket: 17-byte header + big-endian I,Q
+            bodies = np.zeros((channels, n_frames, 2065), np.uint8)
+            bodies[:, :, 17:] = host_batch.reshape(channels, n_frames, 512, 2).astype(">i2").view(np.uint8).reshape(channels, n_frames, 2048)
+            host_batch = bodies
+        else:
+            host_batch = host_batch.reshape(channels, -1, 2)
         for _ in range(depth):                            # fill every slot once: the timed loop measures transport + kernels
-            eng.feed_slot()[:] = host_batch.reshape(channels, -1, 2)
+            eng.feed_slot()[:] = host_batch
             eng.feed_submit()
         for _ in range(depth):
             eng.feed_collect()

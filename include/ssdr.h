@@ -200,18 +200,25 @@ int ssdr_adpcm_decode(ssdr_ctx *ctx, const uint8_t *data, uint32_t n_streams, ui
  * batch k, batch k+1 is copied in and the results of batch k-1 are copied out.  Results are those of ssdr_push_iq /
  * ssdr_run_wf / ssdr_run_audio on the same batches in the same order (state and partial waterfall sums carry over).
  *
- *   ssdr_feed_open(ctx, n_frames, depth)   n_frames (even) 512-sample frames per channel and batch, 2 <= depth <= 16
- *   ssdr_feed_slot(ctx, &iq)               pinned int16 [n_ch][n_frames*512][2] to fill; SSDR_ESTATE if all slots are in flight
+ *   ssdr_feed_open(ctx, n_frames, depth, flags)
+ *                                          n_frames (even) 512-sample frames per channel and batch, 2 <= depth <= 16;
+ *                                          flags = SSDR_FEED_WIRE: the slots take the SND bodies as they come off the
+ *                                          socket (uint8 [n_ch][n_frames][2065], layout of ssdr_push_iq_wire) and the
+ *                                          header strip / byte swap runs on the device
+ *   ssdr_feed_slot(ctx, &in)               pinned int16 [n_ch][n_frames*512][2] (or bodies) to fill; SSDR_ESTATE if all slots are in flight
  *   ssdr_feed_submit(ctx)                  queue the slot: copy-in, both kernels, copy-out; returns at once
- *   ssdr_feed_collect(ctx, &wf, &lines, &pcm, &rssi)
+ *   ssdr_feed_collect(ctx, &wf, &lines, &pcm, &rssi, &wire_rssi)
  *                                          wait for the OLDEST submitted batch; pinned int16 [lines][n_ch][1024], int16
- *                                          [n_ch][n_frames*512], float [n_ch][n_frames]; valid until that slot is handed out again
+ *                                          [n_ch][n_frames*512], float [n_ch][n_frames]; wire_rssi float [n_ch][n_frames] =
+ *                                          0.1*smeter - 127 of the SND headers (NULL without SSDR_FEED_WIRE); valid until
+ *                                          that slot is handed out again
  *   ssdr_feed_close(ctx)
  * The post-processing entry points (db2col, playbuffer, trace) keep referring to the last ssdr_run_* batch, not to fed ones. */
-int ssdr_feed_open(ssdr_ctx *ctx, uint32_t n_frames, uint32_t depth);
-int ssdr_feed_slot(ssdr_ctx *ctx, int16_t **host_iq);
+#define SSDR_FEED_WIRE 1u
+int ssdr_feed_open(ssdr_ctx *ctx, uint32_t n_frames, uint32_t depth, uint32_t flags);
+int ssdr_feed_slot(ssdr_ctx *ctx, void **host_in);
 int ssdr_feed_submit(ssdr_ctx *ctx);
-int ssdr_feed_collect(ssdr_ctx *ctx, int16_t **wf_sum, uint32_t *lines, int16_t **pcm, float **rssi);
+int ssdr_feed_collect(ssdr_ctx *ctx, int16_t **wf_sum, uint32_t *lines, int16_t **pcm, float **rssi, float **wire_rssi);
 int ssdr_feed_close(ssdr_ctx *ctx);
 
 /* -- device-resident results of the last run_* (for zero-copy consumers and bench) */

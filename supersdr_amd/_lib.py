@@ -87,10 +87,10 @@ _SIGS = {
     "ssdr_playbuffer_frame_len": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
     "ssdr_push_iq_wire": (C.c_int, [_P, _P, C.c_uint32, _P]),
     "ssdr_adpcm_decode": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P]),
-    "ssdr_feed_open": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "ssdr_feed_open": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "ssdr_feed_slot": (C.c_int, [_P, C.POINTER(_P)]),
     "ssdr_feed_submit": (C.c_int, [_P]),
-    "ssdr_feed_collect": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(_P), C.POINTER(_P)]),
+    "ssdr_feed_collect": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "ssdr_feed_close": (C.c_int, [_P]),
     "ssdr_wf_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32)]),
     "ssdr_audio_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),

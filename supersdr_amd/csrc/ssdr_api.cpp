@@ -55,8 +55,11 @@ struct ssdr_ctx {
     size_t audio_frames = 0;
     // pipelined host feed (ssdr_feed_*): slots of pinned host memory + their own device buffers
     struct FeedSlot {
-        int16_t *h_in = nullptr, *h_wf = nullptr, *h_pcm = nullptr;
-        float *h_rssi = nullptr;
+        void *h_in = nullptr;                            // int16 IQ, or SND bodies in wire mode
+        int16_t *h_wf = nullptr, *h_pcm = nullptr;
+        float *h_rssi = nullptr, *h_wire_rssi = nullptr;
+        uint8_t *d_wire = nullptr;
+        float *d_wire_rssi = nullptr;
         uint32_t *d_in = nullptr;
         int16_t *d_wf = nullptr, *d_pcm = nullptr;
         float *d_rssi = nullptr;
@@ -66,6 +69,7 @@ struct ssdr_ctx {
     std::vector<FeedSlot> feed;
     uint32_t feed_frames = 0, feed_head = 0, feed_tail = 0, feed_inflight = 0;
     bool feed_taken = false;                             // slot at feed_head handed to the caller, not yet submitted
+    bool feed_wire = false;                              // slots hold SND bodies (kiwi/client.py:443-454), unpacked on the device
     hipStream_t feed_s_in = nullptr, feed_s_out = nullptr;
     // measurement
     bool profiling = false;
@@ -603,9 +607,9 @@ int ssdr_feed_close(ssdr_ctx *c)
     if (c->feed_s_in) (void)hipStreamSynchronize(c->feed_s_in);
     if (c->feed_s_out) (void)hipStreamSynchronize(c->feed_s_out);
     for (auto &s : c->feed) {
-        void *hp[] = {s.h_in, s.h_wf, s.h_pcm, s.h_rssi};
+        void *hp[] = {s.h_in, s.h_wf, s.h_pcm, s.h_rssi, s.h_wire_rssi};
         for (void *p : hp) if (p) (void)hipHostFree(p);
-        void *dp[] = {s.d_in, s.d_wf, s.d_pcm, s.d_rssi};
+        void *dp[] = {s.d_in, s.d_wf, s.d_pcm, s.d_rssi, s.d_wire, s.d_wire_rssi};
         for (void *p : dp) if (p) (void)hipFree(p);
         hipEvent_t ev[] = {s.ev_in, s.ev_run, s.ev_out};
         for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
@@ -618,12 +622,15 @@ int ssdr_feed_close(ssdr_ctx *c)
     return SSDR_OK;
 }
 
-int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth)
+int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth, uint32_t flags)
 {
-    if (!c || n_frames == 0 || (n_frames & 1u) || depth < 2 || depth > 16) return SSDR_EINVAL;
+    if (!c || n_frames == 0 || (n_frames & 1u) || depth < 2 || depth > 16 || (flags & ~(uint32_t)SSDR_FEED_WIRE)) return SSDR_EINVAL;
     if (!c->feed.empty() || c->concurrent) return SSDR_ESTATE;
     HIP_TRY(hipSetDevice(c->device));
     const size_t in_b = (size_t)c->n_ch * n_frames * SSDR_FRAME * 4;
+    const size_t wire_b = (size_t)c->n_ch * n_frames * SSDR_WIRE_BODY;
+    const bool wire = (flags & SSDR_FEED_WIRE) != 0;
+    c->feed_wire = wire;
     const size_t wf_b = (size_t)(n_frames / 2) * c->n_ch * SSDR_NFFT * 2;
     const size_t pcm_b = (size_t)c->n_ch * n_frames * SSDR_FRAME * 2;
     const size_t rssi_b = (size_t)c->n_ch * n_frames * sizeof(float);
@@ -631,7 +638,11 @@ int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth)
     bool ok = hipStreamCreateWithFlags(&c->feed_s_in, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->feed_s_out, hipStreamNonBlocking) == hipSuccess;
     for (auto &s : c->feed) {
-        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_in), in_b, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(&s.h_in, wire ? wire_b : in_b, hipHostMallocDefault) == hipSuccess;
+        if (wire) {
+            ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_wire_rssi), rssi_b, hipHostMallocDefault) == hipSuccess;
+            ok = ok && hipMalloc(&s.d_wire, wire_b) == hipSuccess && hipMalloc(&s.d_wire_rssi, rssi_b) == hipSuccess;
+        }
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_wf), wf_b, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_pcm), pcm_b, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_rssi), rssi_b, hipHostMallocDefault) == hipSuccess;
@@ -646,7 +657,7 @@ int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth)
     return SSDR_OK;
 }
 
-int ssdr_feed_slot(ssdr_ctx *c, int16_t **host_iq)
+int ssdr_feed_slot(ssdr_ctx *c, void **host_iq)
 {
     if (!c || !host_iq) return SSDR_EINVAL;
     if (c->feed.empty() || c->feed_taken) return SSDR_ESTATE;
@@ -663,9 +674,25 @@ int ssdr_feed_submit(ssdr_ctx *c)
     HIP_TRY(hipSetDevice(c->device));
     auto &s = c->feed[c->feed_head];
     const uint32_t nf = c->feed_frames;
-    HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, (size_t)c->n_ch * nf * SSDR_FRAME * 4, hipMemcpyHostToDevice, c->feed_s_in));
+    if (c->feed_wire)
+        HIP_TRY(hipMemcpyAsync(s.d_wire, s.h_in, (size_t)c->n_ch * nf * SSDR_WIRE_BODY, hipMemcpyHostToDevice, c->feed_s_in));
+    else
+        HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, (size_t)c->n_ch * nf * SSDR_FRAME * 4, hipMemcpyHostToDevice, c->feed_s_in));
     HIP_TRY(hipEventRecord(s.ev_in, c->feed_s_in));
     HIP_TRY(hipStreamWaitEvent(c->stream, s.ev_in, 0));
+    if (c->feed_wire) {                                  // header strip + big-endian -> little-endian on the device
+        SsdrWireArgs w;
+        w.bodies = s.d_wire;
+        w.n_ch = c->n_ch;
+        w.n_frames = nf;
+        w.iq = s.d_in;
+        w.ch_stride = (uint64_t)nf * SSDR_FRAME;
+        w.rssi = s.d_wire_rssi;
+        int rcw;
+        if ((rcw = timed_begin(c)) != SSDR_OK) return rcw;
+        HIP_TRY(ssdr_launch_iqwire(w, c->stream));
+        if ((rcw = timed_end(c, SSDR_K_WIRE)) != SSDR_OK) return rcw;
+    }
     // run the two kernels on this slot's buffers: the ctx's own batch pointers are parked meanwhile
     const uint32_t *k_iq = c->d_iq; const uint32_t k_frames = c->in_frames; const bool k_have = c->have_input;
     int16_t *k_wf = c->d_wf_out; const size_t k_wf_lines = c->wf_out_lines; const uint32_t k_ready = c->wf_lines_ready;
@@ -687,6 +714,8 @@ int ssdr_feed_submit(ssdr_ctx *c)
         HIP_TRY(hipMemcpyAsync(s.h_wf, s.d_wf, (size_t)lines * c->n_ch * SSDR_NFFT * 2, hipMemcpyDeviceToHost, c->feed_s_out));
     HIP_TRY(hipMemcpyAsync(s.h_pcm, s.d_pcm, (size_t)c->n_ch * nf * SSDR_FRAME * 2, hipMemcpyDeviceToHost, c->feed_s_out));
     HIP_TRY(hipMemcpyAsync(s.h_rssi, s.d_rssi, (size_t)c->n_ch * nf * sizeof(float), hipMemcpyDeviceToHost, c->feed_s_out));
+    if (c->feed_wire)
+        HIP_TRY(hipMemcpyAsync(s.h_wire_rssi, s.d_wire_rssi, (size_t)c->n_ch * nf * sizeof(float), hipMemcpyDeviceToHost, c->feed_s_out));
     HIP_TRY(hipEventRecord(s.ev_out, c->feed_s_out));
     c->feed_head = (c->feed_head + 1) % (uint32_t)c->feed.size();
     c->feed_inflight++;
@@ -694,7 +723,7 @@ int ssdr_feed_submit(ssdr_ctx *c)
     return SSDR_OK;
 }
 
-int ssdr_feed_collect(ssdr_ctx *c, int16_t **wf_sum, uint32_t *lines, int16_t **pcm, float **rssi)
+int ssdr_feed_collect(ssdr_ctx *c, int16_t **wf_sum, uint32_t *lines, int16_t **pcm, float **rssi, float **wire_rssi)
 {
     if (!c) return SSDR_EINVAL;
     if (c->feed.empty() || c->feed_inflight == 0) return SSDR_ESTATE;
@@ -705,6 +734,7 @@ int ssdr_feed_collect(ssdr_ctx *c, int16_t **wf_sum, uint32_t *lines, int16_t **
     if (lines) *lines = s.lines;
     if (pcm) *pcm = s.h_pcm;
     if (rssi) *rssi = s.h_rssi;
+    if (wire_rssi) *wire_rssi = s.h_wire_rssi;            // NULL unless the feed was opened with SSDR_FEED_WIRE
     c->feed_tail = (c->feed_tail + 1) % (uint32_t)c->feed.size();
     c->feed_inflight--;
     return SSDR_OK;

@@ -144,14 +144,19 @@ class SsdrEngine:
         return out
 
     # ---- pipelined host feed (copy-in / kernels / copy-out of consecutive batches overlap)
-    def feed_open(self, n_frames, depth=3):
-        check(lib.ssdr_feed_open(self._ctx, int(n_frames), int(depth)), "ssdr_feed_open")
-        self._feed_frames = int(n_frames)
+    def feed_open(self, n_frames, depth=3, wire=False):
+        """wire=True: slots take SND bodies uint8 [n_ch, n_frames, 2065] (kiwi/client.py:443-454), unpacked on the device."""
+        check(lib.ssdr_feed_open(self._ctx, int(n_frames), int(depth), 1 if wire else 0), "ssdr_feed_open")
+        self._feed_frames, self._feed_wire = int(n_frames), bool(wire)
 
     def feed_slot(self):
-        """-> int16 [n_ch, n_frames*512, 2] view of the next pinned slot (fill it, then feed_submit())."""
+        """-> int16 [n_ch, n_frames*512, 2] (or uint8 [n_ch, n_frames, 2065]) view of the next pinned slot (fill it, then
+        feed_submit())."""
         p = C.c_void_p()
         check(lib.ssdr_feed_slot(self._ctx, C.byref(p)), "ssdr_feed_slot")
+        if self._feed_wire:
+            n = self.n_ch * self._feed_frames * 2065
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).reshape(self.n_ch, self._feed_frames, 2065)
         n = self.n_ch * self._feed_frames * L.FRAME * 2
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_int16)), shape=(n,)).reshape(self.n_ch, -1, 2)
 
@@ -160,14 +165,18 @@ class SsdrEngine:
 
     def feed_collect(self):
         """Oldest submitted batch -> (wf int16 [lines, n_ch, 1024], pcm int16 [n_ch, n_frames*512], rssi float32
-        [n_ch, n_frames]) as views of pinned memory, valid until that slot is handed out again."""
-        wf, pcm, rssi, lines = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
-        check(lib.ssdr_feed_collect(self._ctx, C.byref(wf), C.byref(lines), C.byref(pcm), C.byref(rssi)), "ssdr_feed_collect")
+        [n_ch, n_frames]) as views of pinned memory, valid until that slot is handed out again; in wire mode a fourth
+        item: the SND headers' rssi float32 [n_ch, n_frames]."""
+        wf, pcm, rssi, wr, lines = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
+        check(lib.ssdr_feed_collect(self._ctx, C.byref(wf), C.byref(lines), C.byref(pcm), C.byref(rssi), C.byref(wr)),
+              "ssdr_feed_collect")
         nf, nl = self._feed_frames, int(lines.value)
         w = (np.ctypeslib.as_array(C.cast(wf, C.POINTER(C.c_int16)), shape=(nl * self.n_ch * L.NFFT,)).reshape(nl, self.n_ch, L.NFFT)
              if nl else np.zeros((0, self.n_ch, L.NFFT), np.int16))
         p = np.ctypeslib.as_array(C.cast(pcm, C.POINTER(C.c_int16)), shape=(self.n_ch * nf * L.FRAME,)).reshape(self.n_ch, -1)
         r = np.ctypeslib.as_array(C.cast(rssi, C.POINTER(C.c_float)), shape=(self.n_ch * nf,)).reshape(self.n_ch, nf)
+        if self._feed_wire:
+            return w, p, r, np.ctypeslib.as_array(C.cast(wr, C.POINTER(C.c_float)), shape=(self.n_ch * nf,)).reshape(self.n_ch, nf)
         return w, p, r
 
     def feed_close(self):

@@ -284,6 +284,40 @@ def test_pipelined_feed_equals_push_and_run(S):
             assert np.array_equal(got[b][k], want[b][k]), (b, k)
 
 
+def test_pipelined_feed_wire_mode(S):
+    """SSDR_FEED_WIRE: SND bodies (big-endian, 17-byte header) in, same results as the int16 path, header rssi out"""
+    import struct
+    n_ch, nf, n_batches = 3, 2, 4
+    iq = O.synth_iq(n_ch, n_batches * nf * 512, seed=17)
+    ps, _ = mixed_params(S, n_ch)
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        want = []
+        for b in range(n_batches):
+            eng.push_iq(iq[:, b * nf * 512:(b + 1) * nf * 512])
+            want.append((eng.run_wf().copy(), *(x.copy() for x in eng.run_audio())))
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.feed_open(nf, depth=2, wire=True)
+        got = []
+        for b in range(n_batches):
+            slot = eng.feed_slot()
+            for c in range(n_ch):
+                for f in range(nf):
+                    x = iq[c, (b * nf + f) * 512:(b * nf + f + 1) * 512]
+                    hdr = struct.pack("<BI", 0, b * nf + f) + struct.pack(">H", 500 + 10 * c + f) + struct.pack("<BBII", 1, 0, 2, 3)
+                    slot[c, f] = np.frombuffer(hdr + x.astype(">i2").tobytes(), np.uint8)
+            eng.feed_submit()
+            got.append(tuple(x.copy() for x in eng.feed_collect()))
+        eng.feed_close()
+    for b in range(n_batches):
+        for k in range(3):
+            assert np.array_equal(got[b][k], want[b][k]), (b, k)
+        for c in range(n_ch):
+            for f in range(nf):
+                assert abs(got[b][3][c, f] - (0.1 * (500 + 10 * c + f) - 127)) < 1e-4
+
+
 def test_error_codes(S):
     from supersdr_amd import _lib as L
     import ctypes as C
