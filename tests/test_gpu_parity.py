@@ -411,3 +411,28 @@ def test_full_size_batch_properties(S, twin):
         p3, r3 = eng.run_audio()
         assert np.array_equal(p3, pcm[sub]) and np.array_equal(r3, rssi[sub])
     assert len(np.unique(k["mode"])) == 4 and pcm.std() > 1000
+
+
+def test_million_channel_batch(S, twin):
+    """BASELINE's largest configuration: 2^20 channels in one context (one superframe): sampled channels from the
+    whole range bit-exact vs the twin, nothing left unwritten, last channel included"""
+    n_ch, n_frames = 1 << 20, 2
+    sub = np.concatenate([np.arange(0, n_ch, 32749)[:30], [n_ch - 1]])
+    with S.SsdrEngine(n_ch) as eng:
+        ps, _ = mixed_params(S, 388)
+        big = ps * (4096 // 388 + 1)
+        for first in range(0, n_ch, 3880):
+            eng.set_params(first, big[: min(3880, n_ch - first)])
+        eng.synth_iq(n_frames, seed=7)
+        iq_sub = np.stack([eng.read_input(int(c), 1)[0] for c in sub])
+        wf = eng.run_wf()
+        pcm, rssi = eng.run_audio()
+        consts, taps = eng.get_consts()
+    assert wf.shape == (1, n_ch, 1024) and pcm.shape == (n_ch, 1024) and rssi.shape == (n_ch, 2)
+    k, t = consts[sub], taps[sub]
+    assert np.array_equal(wf[:, sub], twin.wf(iq_sub, 1, k["wf_cal_lin"]))
+    st, hist = twinlib.fresh_state(k)
+    pcm_t, rssi_t = twin.audio(iq_sub, k, t, st, hist)
+    assert np.array_equal(pcm[sub], pcm_t) and np.array_equal(rssi[sub], rssi_t)
+    assert (wf.max(axis=2) > 0).all()                       # every channel's line was written (a carrier is in every channel)
+    assert (np.abs(pcm).max(axis=1) > 0).all() and np.isfinite(rssi).all()
