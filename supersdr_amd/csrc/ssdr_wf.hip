@@ -20,11 +20,11 @@
 //   The butterflies are exactly those of a textbook radix-2 DIT FFT (same operand
 //   pairs, same six fused multiply-adds), only regrouped -- results are bit-identical.
 //
-// What bounds it (profiles/): VALU issue, not HBM.  On gfx950 only v_fma/add/mul/mov_f32
-// and simple integer add/and issue at ~2.5 cycles per wave; shifts, conversions, med3,
-// compares and all packed-fp32 ops take ~4.5.  Hence: scalar (unpacked) 6-FMA butterflies,
-// a quantiser with a single slow op chain, and one 1024-thread workgroup per CU (16 waves,
-// 4 per SIMD, <= 128 VGPRs) that owns the whole 160 KB of LDS.
+// What bounds it (profiles/): VALU lane-operations and, at steady state, the board's power cap -- not HBM.  On gfx950
+// a wave64 v_fma/add/mul/mov_f32 or simple integer add/and takes 2 cycles of its SIMD; shifts, conversions, med3,
+// compares and packed-fp32 ops (two lane-operations) take 4.  Hence: 6-FMA butterflies (packing them buys nothing),
+// a quantiser with a single slow op chain, and two 512-thread workgroups per CU (16 waves, 4 per SIMD, <= 128 VGPRs)
+// that share the 160 KB of LDS.
 #include "ssdr_math.h"
 #include "ssdr_kernels.h"
 
