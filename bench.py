@@ -35,6 +35,8 @@ WORKLOADS = {
     "full":  (65536,     4,           1,     ("am",),               True, True),
     "wf":    (4096,      256,         1,     ("am",),               True, False),
     "mixed": (65536,     10,          10,    ("am", "usb", "lsb", "nbfm"), True, True),
+    # configs[4]: 2^20 channels in total, 2^20 / N per GPU (strong scaling; 16 GiB of input on one GPU at N = 1)
+    "million": (1 << 20, 4,           1,     ("am",),               True, True),
 }
 
 
@@ -125,6 +127,8 @@ def main():
     from supersdr_amd import _lib as L
 
     channels, sframes, n_avg, modes, do_wf, do_audio = WORKLOADS[args.workload]
+    if args.workload == "million":
+        channels //= world
     channels = args.channels or channels
     sframes = args.superframes or sframes
     n_frames = 2 * sframes
@@ -238,10 +242,11 @@ def main():
     out = {
         "metric": "real-time IQ channels sustained (WF+demod)", "value": value, "unit": "rt_channels",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if args.workload == "million" else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": {"full": "65536 channels full chain (WF + AM demod + AGC), BASELINE configs[2]",
                                 "wf": "4096 channels batched 1024-pt FFT + log-mag waterfall only, BASELINE configs[1]",
-                                "mixed": "65536 channels mixed AM/USB/LSB/NBFM + 10x time binning, BASELINE configs[3]"}[args.workload],
+                                "mixed": "65536 channels mixed AM/USB/LSB/NBFM + 10x time binning, BASELINE configs[3]",
+                                "million": "2^20 channels full chain in total, channel-sharded, BASELINE configs[4]"}[args.workload],
                    "channels_per_gpu": channels, "superframes_per_step": sframes, "averaging_n": n_avg,
                    "clock_spinup_s": args.spinup,
                    "input": "pinned host memory, pipelined H2D / kernels / D2H (PCIe-inclusive)" if args.host_feed else "resident in HBM",
