@@ -99,7 +99,10 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
 void ssdr_destroy(ssdr_ctx *ctx);
 
 /* -- control plane: the SET commands listed above.  Changing parameters keeps the
- *    carried state (NCO phase, FIR history, AGC envelope), as a Kiwi server does. */
+ *    carried state (NCO phase, FIR history, AGC envelope), as a Kiwi server does.  Until the
+ *    first ssdr_run_audio after ssdr_create / a full ssdr_reset_state there is no stream yet:
+ *    ssdr_set_params then also puts the channel's AGC envelope at its new knee (the initial
+ *    state of ssdr_reset_state: full gain, no pop). */
 int ssdr_set_params(ssdr_ctx *ctx, uint32_t first, uint32_t count, const ssdr_chan_params *p);
 int ssdr_default_params(int mode, ssdr_chan_params *out);      /* reference defaults, utils:42-50,936-944 */
 int ssdr_reset_state(ssdr_ctx *ctx, uint32_t first, uint32_t count);

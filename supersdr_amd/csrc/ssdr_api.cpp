@@ -45,6 +45,7 @@ struct ssdr_ctx {
     const uint32_t *d_iq = nullptr;
     uint32_t in_frames = 0;
     bool have_input = false;
+    bool audio_started = false;              // an audio kernel has run since create / full reset: set_params leaves the state alone
     uint64_t synth_sample0 = 0;
     // outputs
     int16_t *d_wf_out = nullptr;
@@ -262,7 +263,7 @@ int ssdr_reset_state(ssdr_ctx *c, uint32_t first, uint32_t count)
     for (int i = 0; i < 2; i++)
         HIP_TRY(hipMemsetAsync(c->d_wf_acc[i] + (size_t)first * SSDR_NFFT, 0, (size_t)count * SSDR_NFFT * 2, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (first == 0 && count == c->n_ch) { c->wf_phase = 0; c->synth_sample0 = 0; }
+    if (first == 0 && count == c->n_ch) { c->wf_phase = 0; c->synth_sample0 = 0; c->audio_started = false; }
     return SSDR_OK;
 }
 
@@ -280,6 +281,16 @@ int ssdr_set_params(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan
     HIP_TRY(hipMemcpyAsync(c->d_consts + first, k.data(), count * sizeof(ssdr_chan_consts), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_taps + (size_t)first * SSDR_NTAP_MAX, taps.data(), taps.size() * sizeof(float),
                            hipMemcpyHostToDevice, c->stream));
+    std::vector<ssdr_chan_state> st;
+    if (!c->audio_started) {                 // a channel that has not produced audio yet starts at ITS knee (full gain, no pop)
+        st.resize(count);
+        for (uint32_t i = 0; i < count; i++) {
+            memset(&st[i], 0, sizeof st[i]);
+            st[i].agc_d = k[i].agc_knee;
+            for (int j = 0; j < 8; j++) st[i].agc_m[j] = -1000.0f;
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_state + first, st.data(), count * sizeof(ssdr_chan_state), hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
 }
@@ -580,6 +591,7 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         HIP_TRY(hipEventRecord(c->ev_in, c->stream));          // everything queued so far, incl. the input copy/synth
         HIP_TRY(hipStreamWaitEvent(s, c->ev_in, 0));
     }
+    c->audio_started = true;
     if ((rc = timed_begin(c, s)) != SSDR_OK) return rc;
     HIP_TRY(ssdr_launch_audio(a, s));
     if ((rc = timed_end(c, SSDR_K_AUDIO, s)) != SSDR_OK) return rc;

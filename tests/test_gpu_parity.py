@@ -244,6 +244,43 @@ def test_synth_input_roundtrip_and_parity(S, twin):
     assert np.array_equal(pcm, pcm_t) and np.array_equal(rssi, rssi_t)
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_parameter_surface_bit_exact_vs_twin(S, twin, seed):
+    """seeded random modes / passbands (down to 50 Hz CW: 127 taps) / AGC laws / calibrations / levels incl. silence and
+    bursts at the rails, 96 channels x 6 frames: PCM, RSSI, carried state, FIR history and waterfall bit-exact vs the twin"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import random_params as RP
+    rng = np.random.default_rng(seed)
+    n_ch, n_frames = 96, 6
+    kw = [RP.draw(rng) for _ in range(n_ch)]
+    iq = RP.signal(rng, n_ch, n_frames * 512)
+    ps = [S.default_params(k["mode"], f_shift_hz=k["f_shift_hz"], low_cut=k["low_cut"], high_cut=k["high_cut"],
+                           agc_on=k["agc_on"], agc_hang=k["hang"], agc_thresh=k["thresh"], agc_slope=k["slope"],
+                           agc_decay=k["decay"], agc_man_gain=k["man_gain"], wf_cal_db=k["wf_cal_db"],
+                           smeter_cal_db=k["smeter_cal_db"]) for k in kw]
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.push_iq(iq[:, : 4 * 512])                            # two calls: state crosses a call boundary
+        wf1 = eng.run_wf()
+        p1, r1 = eng.run_audio()
+        eng.push_iq(iq[:, 4 * 512:])
+        wf2 = eng.run_wf()
+        p2, r2 = eng.run_audio()
+        consts, taps = eng.get_consts()
+        st_g, hist_g = eng.get_state()
+    st, hist = twinlib.fresh_state(consts)
+    pcm_t, rssi_t = twin.audio(iq, consts, taps, st, hist)
+    assert np.array_equal(np.concatenate([p1, p2], axis=1), pcm_t)
+    assert np.array_equal(np.concatenate([r1, r2], axis=1), rssi_t)
+    assert st_g.tobytes() == st.tobytes() and np.array_equal(hist_g, hist)
+    assert np.array_equal(np.concatenate([wf1, wf2]), twin.wf(iq, 1, consts["wf_cal_lin"]))
+    # the host-compiled constants are the oracle's
+    for c in (0, 17, 95):
+        k = O.compile_params(O.ChanParams(**kw[c]))
+        assert int(consts["dphi1"][c]) == int(k["dphi1"]) and int(consts["ntap"][c]) == int(k["ntap"])
+        assert np.array_equal(taps[c], k["taps"]) and consts["agc_knee"][c] == np.float32(k["agc_knee"])
+
+
 def test_pipelined_feed_equals_push_and_run(S):
     """ssdr_feed_*: batches in flight on three streams give the results of push_iq + run_wf + run_audio in order
     (state, FIR history and partial waterfall sums carried), also when slots are reused and N does not divide a batch"""
