@@ -244,6 +244,31 @@ def test_synth_input_roundtrip_and_parity(S, twin):
     assert np.array_equal(pcm, pcm_t) and np.array_equal(rssi, rssi_t)
 
 
+@pytest.mark.parametrize("seed", [31, 32, 33, 34])
+def test_wf_random_batching_and_averaging(S, twin, seed):
+    """random N in 1..100 and random ragged pushes (1..9 lines each): the lines that come out, in order, are the twin's
+    N-line sums of the whole stream; nothing is lost or duplicated at call boundaries"""
+    rng = np.random.default_rng(seed)
+    n_ch = int(rng.integers(1, 12))
+    n_avg = int(rng.choice([1, 2, 3, 5, 10, 37, 100]))
+    total = int(rng.integers(n_avg, n_avg * 3 + 20))
+    iq = O.synth_iq(n_ch, total * 1024, seed=seed)
+    cal = rng.integers(-10, 11, n_ch).astype(np.float64)
+    outs, pos = [], 0
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, [S.default_params("am", wf_cal_db=float(cal[c])) for c in range(n_ch)])
+        eng.set_averaging(n_avg)
+        while pos < total:
+            k = int(min(total - pos, rng.integers(1, 10)))
+            eng.push_iq(iq[:, pos * 1024:(pos + k) * 1024])
+            outs.append(eng.run_wf())
+            pos += k
+        consts, _ = eng.get_consts()
+    got = np.concatenate(outs, axis=0)
+    ref = twin.wf(iq, n_avg, consts["wf_cal_lin"])
+    assert got.shape == ref.shape == (total // n_avg, n_ch, 1024) and np.array_equal(got, ref)
+
+
 @pytest.mark.parametrize("seed", [11, 12, 13])
 def test_random_parameter_surface_bit_exact_vs_twin(S, twin, seed):
     """seeded random modes / passbands (down to 50 Hz CW: 127 taps) / AGC laws / calibrations / levels incl. silence and

@@ -76,6 +76,51 @@ def test_db2col_on_real_waterfall_lines_vs_oracle(S):
         assert chans[c].low_clip_db == np.float32(ref[1]) and chans[c].dynamic_range == np.float32(ref[3])
 
 
+@pytest.mark.parametrize("seed,n_avg", [(1, 1), (2, 7), (3, 10), (4, 100), (5, 33)])
+def test_db2col_random_lines_vs_oracle(S, seed, n_avg):
+    """random summed lines (flat, sparse peaks, heavy ties around the 40th percentile, all-equal, ramps), zoom 0..14,
+    autoscale on and off (clip state carried from line to line), clip deltas: == the oracle restatement, which the
+    golden tests pin to the real reference"""
+    from supersdr_amd._lib import Db2colChan
+    rng = np.random.default_rng(seed)
+    n_ch, n_lines = 16, 4
+    wf = np.empty((n_lines, n_ch, 1024), np.int16)
+    for c in range(n_ch):
+        for i in range(n_lines):
+            kind = (c + i) % 5
+            if kind == 0:
+                b = rng.integers(100, 140, 1024)
+            elif kind == 1:
+                b = np.full(1024, int(rng.integers(0, 256)))
+            elif kind == 2:
+                b = np.where(rng.random(1024) < 0.4, 120, 121)                 # ties straddling the 40th percentile
+            elif kind == 3:
+                b = (np.arange(1024) // 4) % 256
+            else:
+                b = rng.integers(0, 256, 1024)
+            wf[i, c] = (b * n_avg - rng.integers(0, n_avg, 1024) * (b > 0)).clip(0, 255 * n_avg)
+    cfg = [(int(rng.integers(0, 15)), int(rng.random() < 0.6), int(rng.integers(-10, 11)), int(rng.integers(-10, 11)))
+           for _ in range(n_ch)]
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_averaging(n_avg)
+        eng.set_wf_lines(wf)
+        chans = [Db2colChan(zoom=z, auto_scale=a, delta_low_db=dl, delta_high_db=dh, low_clip_db=-110.0 - c, high_clip_db=-50.0,
+                            dynamic_range=55.0 + c) for c, (z, a, dl, dh) in enumerate(cfg)]
+        col = eng.run_db2col(chans, n_lines)
+    for c, (z, a, dl, dh) in enumerate(cfg):
+        lo, hi, dyn = -110.0 - c, -50.0, 55.0 + c
+        for i in range(n_lines):
+            spec = O.wf_mean_from_sum(wf[i, c], n_avg)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                ref = O.spectrum_db2col(spec.copy(), z, bool(a), low_clip_db=lo, high_clip_db=hi, dynamic_range=dyn,
+                                        delta_low_db=dl, delta_high_db=dh)
+            lo, hi, dyn = ref[1], ref[2], ref[3]
+            assert np.array_equal(col[i, c], ref[0], equal_nan=True), (c, i, cfg[c])
+        assert chans[c].wf_min_db == np.float32(ref[4]) and chans[c].wf_max_db == np.float32(ref[5]), (c, cfg[c])
+        if a:
+            assert (chans[c].low_clip_db, chans[c].dynamic_range) == (np.float32(lo), np.float32(dyn)), c
+
+
 def test_play_buffer_matches_reference_golden(S):
     """kiwi_sound.play_buffer: 4 consecutive frames per case (history carry), volume 150 (int16 wrap), pan"""
     from supersdr_amd._lib import PlayChan
@@ -96,6 +141,29 @@ def test_play_buffer_matches_reference_golden(S):
         out = eng.run_playbuffer([PlayChan(*g["cfg_%d" % c]) for c in range(n)])
     for c in range(n):
         assert np.array_equal(out[c].reshape(4, 2048, 2), g["out_%d" % c])
+
+
+def test_play_buffer_random_vs_oracle(S):
+    """x4 branch: random PCM incl. rails and silence, volumes 0..200 %, any balance, frames split over several calls
+    (history carried in the ctx) == the oracle restatement that the golden tests pin to the real reference"""
+    from supersdr_amd._lib import PlayChan
+    rng = np.random.default_rng(8)
+    n_ch, nf = 7, 6
+    pcm = rng.integers(-32768, 32768, (n_ch, nf, 512)).astype(np.int16)
+    pcm[0] = 0
+    pcm[1, 2] = 32767
+    pcm[1, 3] = -32768
+    cfg = [(float(rng.integers(0, 201)), float(rng.integers(-100, 101)) / 100.0) for _ in range(n_ch)]
+    outs = []
+    with S.SsdrEngine(n_ch) as eng:
+        for a, b in ((0, 1), (1, 4), (4, 6)):
+            eng.set_pcm(pcm[:, a:b].reshape(n_ch, -1))
+            outs.append(eng.run_playbuffer([PlayChan(*k) for k in cfg]))
+    got = np.concatenate(outs, axis=1)
+    for c in range(n_ch):
+        pb = O.PlayBuffer()
+        ref = np.concatenate([pb(pcm[c, f], *cfg[c]) for f in range(nf)])
+        assert np.array_equal(got[c], ref), (c, cfg[c])
 
 
 def test_play_buffer_resampled_matches_reference_golden(S):
