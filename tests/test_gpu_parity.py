@@ -269,14 +269,14 @@ def test_wf_random_batching_and_averaging(S, twin, seed):
     assert got.shape == ref.shape == (total // n_avg, n_ch, 1024) and np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13])
-def test_random_parameter_surface_bit_exact_vs_twin(S, twin, seed):
+@pytest.mark.parametrize("seed,n_frames", [(11, 6), (12, 6), (13, 6), (14, 48)])
+def test_random_parameter_surface_bit_exact_vs_twin(S, twin, seed, n_frames):
     """seeded random modes / passbands (down to 50 Hz CW: 127 taps) / AGC laws / calibrations / levels incl. silence and
     bursts at the rails, 96 channels x 6 frames: PCM, RSSI, carried state, FIR history and waterfall bit-exact vs the twin"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import random_params as RP
     rng = np.random.default_rng(seed)
-    n_ch, n_frames = 96, 6
+    n_ch = 96
     kw = [RP.draw(rng) for _ in range(n_ch)]
     iq = RP.signal(rng, n_ch, n_frames * 512)
     ps = [S.default_params(k["mode"], f_shift_hz=k["f_shift_hz"], low_cut=k["low_cut"], high_cut=k["high_cut"],
@@ -285,20 +285,23 @@ def test_random_parameter_surface_bit_exact_vs_twin(S, twin, seed):
                            smeter_cal_db=k["smeter_cal_db"]) for k in kw]
     with S.SsdrEngine(n_ch) as eng:
         eng.set_params(0, ps)
-        eng.push_iq(iq[:, : 4 * 512])                            # two calls: state crosses a call boundary
-        wf1 = eng.run_wf()
-        p1, r1 = eng.run_audio()
-        eng.push_iq(iq[:, 4 * 512:])
-        wf2 = eng.run_wf()
-        p2, r2 = eng.run_audio()
+        wfs, ps_, rs, pos = [], [], [], 0
+        while pos < n_frames:                                    # several calls: state crosses call boundaries
+            k = min(n_frames - pos, 2 * int(rng.integers(1, 6)))
+            eng.push_iq(iq[:, pos * 512:(pos + k) * 512])
+            wfs.append(eng.run_wf())
+            p, r = eng.run_audio()
+            ps_.append(p)
+            rs.append(r)
+            pos += k
         consts, taps = eng.get_consts()
         st_g, hist_g = eng.get_state()
     st, hist = twinlib.fresh_state(consts)
     pcm_t, rssi_t = twin.audio(iq, consts, taps, st, hist)
-    assert np.array_equal(np.concatenate([p1, p2], axis=1), pcm_t)
-    assert np.array_equal(np.concatenate([r1, r2], axis=1), rssi_t)
+    assert np.array_equal(np.concatenate(ps_, axis=1), pcm_t)
+    assert np.array_equal(np.concatenate(rs, axis=1), rssi_t)
     assert st_g.tobytes() == st.tobytes() and np.array_equal(hist_g, hist)
-    assert np.array_equal(np.concatenate([wf1, wf2]), twin.wf(iq, 1, consts["wf_cal_lin"]))
+    assert np.array_equal(np.concatenate(wfs), twin.wf(iq, 1, consts["wf_cal_lin"]))
     # the host-compiled constants are the oracle's
     for c in (0, 17, 95):
         k = O.compile_params(O.ChanParams(**kw[c]))
