@@ -84,6 +84,27 @@ def test_param_compile_equals_oracle(S, mode, over):
     assert np.array_equal(taps, ok["taps"])
 
 
+def test_param_compile_equals_oracle_on_random_parameters(S):
+    """400 seeded random parameter sets: the library's host code and the oracle compile to the same constants and the
+    same float32 taps (two libms, one rounding to float32)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import random_params as RP
+    rng = np.random.default_rng(5)
+    for i in range(400):
+        kw = RP.draw(rng)
+        p = S.default_params(kw["mode"], f_shift_hz=kw["f_shift_hz"], low_cut=kw["low_cut"], high_cut=kw["high_cut"],
+                             agc_on=kw["agc_on"], agc_hang=kw["hang"], agc_thresh=kw["thresh"], agc_slope=kw["slope"],
+                             agc_decay=kw["decay"], agc_man_gain=kw["man_gain"], wf_cal_db=kw["wf_cal_db"],
+                             smeter_cal_db=kw["smeter_cal_db"])
+        k, taps = S.compile_params(p)
+        ok = O.compile_params(O.ChanParams(**kw))
+        for f in ("mode", "ntap", "dphi1", "dphi2", "hang_frames", "tap_groups"):
+            assert int(k[f]) == int(ok[f]), (i, f, kw)
+        for f in ("wf_cal_lin", "smeter_cal_db", "agc_c0", "agc_c1", "agc_knee", "agc_delta8"):
+            assert np.float32(k[f]) == np.float32(ok[f]), (i, f, kw)
+        assert np.array_equal(taps, ok["taps"]), (i, kw, np.nonzero(taps != ok["taps"])[0][:5])
+
+
 def test_device_entry_points_fail_cleanly_without_gpu(S):
     import torch
     if torch.cuda.is_available():
