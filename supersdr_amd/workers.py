@@ -24,8 +24,10 @@ arithmetic steps -- spectrum_db2col (utils_supersdr.py:787-813) and the play_buf
 ssdr_run_playbuffer, bit-exact against golden vectors of the real reference): the hub runs them with every
 superframe and the workers hand out their results.  There is no host implementation of either step:
 `IQHub(gpu_post=False)` skips the two kernels for consumers that only want raw lines and PCM, and
-spectrum_db2col() / play_buffer() then raise.
+spectrum_db2col() then raises and play_buffer() (a PortAudio callback, which must not raise) plays silence, stops
+the worker and leaves the error in `kiwi_sound.error`.
 """
+import logging
 import queue
 import threading
 import time
@@ -432,6 +434,7 @@ class kiwi_sound:
         self._timeout = timeout
         self.center_khz = float(kiwi_wf.freq)            # the IQ band's centre: tuning is relative to it
         self._play_blocks = {}
+        self.error = None                                # set by play_buffer when it has to give up
         if hasattr(self.hub, "snd_clients"):
             self.hub.snd_clients[self.channel] = self
         self.set_mode_freq_pb()
@@ -516,8 +519,14 @@ class kiwi_sound:
             outdata[:] = np.concatenate(blocks)
             self._mute_logic(outdata)
             return
-        raise RuntimeError("play_buffer runs on the GPU (ssdr_run_playbuffer): frames without a 48 kHz block -- "
-                           "the hub was built with gpu_post=False")
+        # No host implementation exists.  This is the PortAudio callback, which must not raise: as the
+        # reference does for its own stream errors (utils_supersdr.py:1031-1036), play silence, stop the worker and keep
+        # the error where the owner finds it.
+        outdata[:] = 0
+        self.error = RuntimeError("play_buffer runs on the GPU (ssdr_run_playbuffer): a frame came without its 48 kHz "
+                                  "block -- the hub was built with gpu_post=False")
+        logging.error("%s", self.error)
+        self.terminate = True
 
     def _mute_logic(self, outdata):                      # utils_supersdr.py:1142-1147
         if self.rssi > self.max_rssi_before_mute:

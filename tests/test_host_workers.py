@@ -217,9 +217,11 @@ def test_play_buffer_hands_out_gpu_blocks():
         out = np.zeros((2048, 2), np.int16)
         snd.play_buffer(out, 2048, None, None)
         assert np.array_equal(out, ref(s, volume=snd.volume, balance=snd.audio_balance)), f
-    snd.audio_buffer.put(np.zeros(512, np.int16))              # a frame that did not come from the hub: no host path
-    with pytest.raises(RuntimeError):
-        snd.play_buffer(np.zeros((2048, 2), np.int16), 2048, None, None)
+    snd.audio_buffer.put(np.zeros(512, np.int16))              # a frame that did not come from the hub: no host path,
+    out = np.ones((2048, 2), np.int16)                         # and the PortAudio callback must not raise: silence + stop
+    snd.play_buffer(out, 2048, None, None)
+    assert (out == 0).all() and snd.terminate and isinstance(snd.error, RuntimeError)
+    snd.terminate, snd.error = False, None
     snd.late_flag = True
     out = np.ones((2048, 2), np.int16)
     snd.play_buffer(out, 2048, None, None)
