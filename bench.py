@@ -90,9 +90,27 @@ def cpu_baseline(workload, budget_s=12.0):
         list(ex.map(work, blocks))
     wall = time.perf_counter() - t0
     units = nch_core * cores * sf
-    return {"value": units / wall / RT_SUPERFRAMES_PER_S, "unit": "rt_channels", "cores": cores, "kind": "port",
-            "sample": "%d ch x %d superframes per core on %d threads, oracle/ssdr_twin.c (fp32 C port), %.1f s"
-                      % (nch_core, sf, cores, wall)}
+    out = {"value": units / wall / RT_SUPERFRAMES_PER_S, "unit": "rt_channels", "cores": cores, "kind": "port",
+           "sample": "%d ch x %d superframes per core on %d threads, oracle/ssdr_twin.c (fp32 C port), %.1f s"
+                     % (nch_core, sf, cores, wall)}
+    # north_star also asks for the NumPy path: the float64 oracle (vectorised NumPy, one process) on a few channels
+    nn = 16
+    iq = O.synth_iq(nn, sf * 1024, seed=7)
+    prm = [O.ChanParams(mode=modes[c % len(modes)], f_shift_hz=((c * 37) % 97 - 48) * 100.0) for c in range(nn)]
+    t0 = time.perf_counter()
+    reps = 0
+    while time.perf_counter() - t0 < 3.0:
+        if do_wf:
+            for c in range(nn):
+                O.wf_sum_lines(iq[c].reshape(-1, 1024, 2), 1, 0.0)
+        if do_audio:
+            O.audio_chain(iq, prm)
+        reps += 1
+    wall_np = time.perf_counter() - t0
+    out["numpy_oracle"] = {"value": nn * sf * reps / wall_np / RT_SUPERFRAMES_PER_S, "unit": "rt_channels", "cores": 1,
+                           "sample": "%d ch x %d superframes x %d passes, oracle/ssdr_oracle.py (NumPy float64), %.1f s"
+                                     % (nn, sf, reps, wall_np)}
+    return out
 
 
 def main():
