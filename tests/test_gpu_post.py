@@ -363,3 +363,39 @@ def test_adpcm_matches_reference_golden(S):
         wfc = g["wfc_body"][12:]
         out = eng.adpcm_decode(wfc[None])                    # fresh state per W/F line
         assert np.array_equal(out[0][:-10], g["wfc_samples"])
+
+
+def test_replay_tool_end_to_end(S, tmp_path):
+    """tools/replay_iq_wav.py: Kiwi IQ wav -> IQHub -> kiwi_waterfall / kiwi_sound -> 48 kHz stereo + waterfall rows;
+    the audio is the twin's PCM through the reference's play_buffer, the rows are db2col of the twin's lines"""
+    import struct
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import replay_iq_wav as R
+    import twinlib
+    iq = O.synth_iq(1, 8 * 512, seed=3, modes=[1])[0]                       # a USB tone, 8 blocks of 512
+    body = b"WAVE" + b"fmt " + struct.pack("<IHHIIHH", 16, 1, 2, 12000, 48000, 4, 16)
+    for i in range(8):
+        body += b"kiwi" + struct.pack("<IBBII", 10, 3, 0, 1000, 42666667 * i)
+        body += b"data" + struct.pack("<I", 2048) + iq[i * 512:(i + 1) * 512].astype("<i2").tobytes()
+    path = tmp_path / "rec.wav"
+    path.write_bytes(b"RIFF" + struct.pack("<I", len(body)) + body)
+    probe = {}
+    audio, rows, rssi = R.replay(str(path), "usb", tune_khz=((1 * 37) % 97 - 48) * 0.1, probe=probe)
+    assert audio.shape == (8 * 2048, 2) and rows.shape == (4, 1024) and rssi.shape == (8,)
+    twin = twinlib.load()
+    st, hist = twinlib.fresh_state(probe["consts"])
+    pcm_t, rssi_t = twin.audio(iq[None], probe["consts"], probe["taps"], st, hist)
+    pb = O.PlayBuffer()
+    want = np.concatenate([pb(pcm_t[0, f * 512:(f + 1) * 512], 100, 0.0) for f in range(8)])
+    assert np.array_equal(audio, want) and np.array_equal(rssi.astype(np.float32), rssi_t[0])
+    lines = twin.wf(iq[None], 1, probe["consts"]["wf_cal_lin"])[:, 0]
+    lo, hi, dyn = -120.0, -60.0, 40.0
+    for i in range(4):
+        ref = O.spectrum_db2col(lines[i].astype(np.float32), 10, True, low_clip_db=lo, high_clip_db=hi, dynamic_range=dyn)
+        lo, hi, dyn = ref[1], ref[2], ref[3]
+        assert np.array_equal(rows[i], ref[0].astype(np.float64)), i
+    out = tmp_path / "a.wav"
+    R.write_wav(str(out), audio)
+    raw = out.read_bytes()
+    assert raw[:4] == b"RIFF" and len(raw) == 44 + audio.size * 2 and pcm_t.std() > 100
