@@ -32,7 +32,7 @@ HBM_PEAK_GBPS = 8000.0                           # MI355X_MICROARCH.md: HBM3E 8.
 
 WORKLOADS = {
     #          channels  superframes  n_avg  modes                  wf    audio
-    "full":  (65536,     4,           1,     ("am",),               True, True),
+    "full":  (65536,     16,          1,     ("am",),               True, True),      # >= 16 superframes
     "wf":    (4096,      256,         1,     ("am",),               True, False),
     "mixed": (65536,     10,          10,    ("am", "usb", "lsb", "nbfm"), True, True),
     # configs[4]: 2^20 channels in total, 2^20 / N per GPU (strong scaling; 16 GiB of input on one GPU at N = 1)
