@@ -62,6 +62,17 @@ static void sincos20(uint32_t phase, float *c_out, float *s_out)
     }
 }
 
+/* 1/d for d in [1, 2.42]: cubic seed + two Newton steps, seven fused multiply-adds (no divide). */
+static float rcp_1to2p42(float d)
+{
+    float r = fmaf(fmaf(fmaf(-0.1340303272008896f, d, 0.9271132946014404f), d, -2.337818145751953f), d, 2.539294958114624f);
+    float e = fmaf(-d, r, 1.0f);
+    r = fmaf(r, e, r);
+    e = fmaf(-d, r, 1.0f);
+    r = fmaf(r, e, r);
+    return r;
+}
+
 /* log2(x), x > 0 normal.  atanh series in s=(m-1)/(m+1), m in [0.707,1.414]. */
 static float log2p(float x)
 {
@@ -71,7 +82,7 @@ static float log2p(float x)
     int32_t e = (int32_t)(I >> 23) - 127;
     float m = u2f((I & 0x007FFFFFu) | 0x3F800000u);
     if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
-    float s = (m - 1.0f) / (m + 1.0f);
+    float s = (m - 1.0f) * rcp_1to2p42(m + 1.0f);
     float z = s * s;
     float t = fmaf(z, L4, L3);
     t = fmaf(z, t, L2);
@@ -100,7 +111,7 @@ static float exp2p(float y)
     return u2f(f2u(r) + ((uint32_t)(int32_t)n << 23));
 }
 
-/* atan2(y, x), cephes atanf reduction; IEEE divides only. */
+/* atan2(y, x), cephes atanf reduction; the two quotients through rcp_1to2p42. */
 static float atan2p(float y, float x)
 {
     const float A0 = -3.33329491539e-1f, A1 = 1.99777106478e-1f,
@@ -109,9 +120,11 @@ static float atan2p(float y, float x)
     float ax = fabsf(x), ay = fabsf(y);
     float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
     if (mx == 0.0f) return 0.0f;
-    float t = mn / fmaxf(mx, 1e-30f);
+    const float mxc = fmaxf(mx, 1e-30f);
+    const float sc = u2f(0x7F000000u - (f2u(mxc) & 0x7F800000u));       /* 2^-exponent(mx): mx*sc in [1, 2) */
+    float t = (mn * sc) * rcp_1to2p42(mxc * sc);
     float u = t, off = 0.0f;
-    if (t > 0.41421356237f) { u = (t - 1.0f) / (t + 1.0f); off = PI_4; }
+    if (t > 0.41421356237f) { u = (t - 1.0f) * rcp_1to2p42(t + 1.0f); off = PI_4; }
     float z = u * u;
     float q = fmaf(A3, z, A2);
     q = fmaf(q, z, A1);

@@ -2,7 +2,7 @@
 //
 // No libm transcendentals and no implicit contraction (-ffp-contract=off): every
 // rounding step is explicit, so results are reproducible op-for-op on any IEEE-754
-// machine.  v_fma_f32 / v_rndne_f32 / IEEE divide and sqrt are the only primitives.
+// machine.  v_fma_f32 / v_rndne_f32 / IEEE sqrt and integer bit operations are the only primitives.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "ssdr_consts.h"
@@ -33,6 +33,18 @@ SSDR_DEV void ssdr_sincos20(uint32_t phase, float &c_out, float &s_out)
     s_out = (k & 2u) ? -ss : ss;              // k=2,3 -> negative sin side
 }
 
+// 1/d for d in [1, 2.42]: cubic seed (|rel err| < 5.5e-3) + two Newton steps (-> 1e-9, i.e. fp32 rounding is what is left).
+// Seven full-rate ops; an IEEE divide is ~15 instructions, several of them quarter-rate.  The twin states the same ops.
+SSDR_DEV float ssdr_rcp_1to2p42(float d)
+{
+    float r = fmaf(fmaf(fmaf(-0.1340303272008896f, d, 0.9271132946014404f), d, -2.337818145751953f), d, 2.539294958114624f);
+    float e = fmaf(-d, r, 1.0f);
+    r = fmaf(r, e, r);
+    e = fmaf(-d, r, 1.0f);
+    r = fmaf(r, e, r);
+    return r;
+}
+
 // log2(x) for normal x > 0: exponent split + atanh series in s = (m-1)/(m+1).
 SSDR_DEV float ssdr_log2p(float x)
 {
@@ -41,7 +53,7 @@ SSDR_DEV float ssdr_log2p(float x)
     int32_t e = (int32_t)(I >> 23) - 127;
     float m = __uint_as_float((I & 0x007FFFFFu) | 0x3F800000u);
     if (m > 1.41421356f) { m = m * 0.5f; e += 1; }
-    float s = (m - 1.0f) / (m + 1.0f);
+    float s = (m - 1.0f) * ssdr_rcp_1to2p42(m + 1.0f);      // m + 1 in [1.707, 2.414]
     float z = s * s;
     float t = fmaf(z, L4, L3);
     t = fmaf(z, t, L2);
@@ -70,7 +82,7 @@ SSDR_DEV float ssdr_exp2p(float y)
     return __uint_as_float(__float_as_uint(r) + ((uint32_t)(int32_t)n << 23));
 }
 
-// atan2(y, x): cephes atanf reduction, IEEE divides
+// atan2(y, x): cephes atanf reduction
 SSDR_DEV float ssdr_atan2p(float y, float x)
 {
     const float A0 = -3.33329491539e-1f, A1 = 1.99777106478e-1f,
@@ -78,9 +90,12 @@ SSDR_DEV float ssdr_atan2p(float y, float x)
     const float PI_4 = 0.78539816339744831f, PI_2 = 1.5707963267948966f, PI_1 = 3.14159265358979323f;
     float ax = fabsf(x), ay = fabsf(y);
     float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    float t = mn / fmaxf(mx, 1e-30f);            // no 0/0: mx == 0 returns 0 below
+    // t = mn / mx without a divide: both scaled by the power of two that brings mx into [1, 2) (exact), then 1/mx
+    const float mxc = fmaxf(mx, 1e-30f);         // no 0/0: mx == 0 returns 0 below
+    const float sc = __uint_as_float(0x7F000000u - (__float_as_uint(mxc) & 0x7F800000u));
+    float t = (mn * sc) * ssdr_rcp_1to2p42(mxc * sc);
     float u = t, off = 0.0f;
-    if (t > 0.41421356237f) { u = (t - 1.0f) / (t + 1.0f); off = PI_4; }
+    if (t > 0.41421356237f) { u = (t - 1.0f) * ssdr_rcp_1to2p42(t + 1.0f); off = PI_4; }     // t + 1 in (1.41, 2]
     float z = u * u;
     float q = fmaf(A3, z, A2);
     q = fmaf(q, z, A1);
