@@ -52,6 +52,12 @@ SSDR_DEV float vmax(float a, float b)
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+SSDR_DEV float vmax3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 SSDR_DEV float lane63(float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63)); }
 SSDR_DEV float from_prev_lane(float lane0_value, float x) { return dpp<0x138, 0xF>(lane0_value, x); }   // wave_shr:1
 
@@ -288,10 +294,12 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
         prev_im = lane63(yi[7]);
 
         // 4. AGC: block peak -> log2 -> (max,+) follower across lanes -> gain
-        float pm = p[0], ps = p[0];
+        float ps = p[0];
 #pragma unroll
-        for (int j = 1; j < 8; j++) { pm = vmax(pm, p[j]); ps = ps + p[j]; }
-        const float al = ssdr_log2p(vmax(pm, SSDR_P_FLOOR));
+        for (int j = 1; j < 8; j++) ps = ps + p[j];
+        // max of the eight powers and the floor in four three-input maxima (max is exact: any grouping gives the same value)
+        const float pm = vmax3(vmax3(vmax3(p[0], p[1], p[2]), p[3], p[4]), vmax3(p[5], p[6], p[7]), SSDR_P_FLOOR);
+        const float al = ssdr_log2p(pm);
         const float fl = (float)l;
         float e;
         if (K == 0) {
