@@ -69,7 +69,7 @@ SSDR_DEV float ssdr_exp2p(float y)
     const float E1 = 0.69314718056f, E2 = 0.24022650696f, E3 = 0.055504108665f,
                 E4 = 0.0096181291076f, E5 = 0.0013333558146f, E6 = 0.00015403530393f,
                 E7 = 0.000015252733805f;
-    y = fminf(fmaxf(y, -126.0f), 126.0f);
+    y = __builtin_amdgcn_fmed3f(y, -126.0f, 126.0f);       // clamp in one instruction (same value as min(max()))
     float n = rintf(y);
     float f = y - n;
     float r = fmaf(E7, f, E6);
