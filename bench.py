@@ -63,7 +63,7 @@ def cpu_baseline(workload, budget_s=12.0):
             lc, hc = {"am": (-6000, 6000), "usb": (30, 3000), "lsb": (-3000, -30), "nbfm": (-6000, 6000)}[m]
             k = O.compile_params(O.ChanParams(mode=m, f_shift_hz=((c * 37) % 97 - 48) * 100.0, low_cut=lc, high_cut=hc))
             for f in ("mode", "ntap", "dphi1", "dphi2", "wf_cal_lin", "smeter_cal_db", "agc_c0", "agc_c1",
-                      "agc_knee", "agc_delta8", "hang_frames"):
+                      "agc_knee", "agc_delta8", "hang_frames", "fir_flags"):
                 consts[f][c] = k[f]
             consts["ntap8"][c] = (k["ntap"] + 7) // 8 * 8
             taps[c] = k["taps"]
@@ -128,7 +128,7 @@ def main():
     ap.add_argument("--host-feed", type=int, default=0,
                     help="1: inputs come from (pinned) host memory (2: as SND wire bodies, unpacked on the device) and results go back to it through the pipelined feed "
                          "(ssdr_feed_*): the PCIe-inclusive rate of DESIGN.md, never the headline value")
-    ap.add_argument("--concurrent", type=int, default=0, help="1: audio kernel on a second stream beside the waterfall kernel")
+    ap.add_argument("--concurrent", type=int, default=0, help="bit 0: audio stage on a second stream beside the waterfall kernel; bit 1: the audio stage's per-path kernels one after the other")
     args = ap.parse_args()
 
     import torch

@@ -78,8 +78,13 @@ typedef struct ssdr_chan_consts {
     float agc_c0, agc_c1, agc_knee, agc_delta8;
     uint32_t hang_frames, ntap;
     uint32_t tap_groups;            /* bit g set: taps 4g..4g+3 are not all zero (the FIR skips the others) */
-    uint32_t pad[3];
+    uint32_t fir_flags;             /* SSDR_FIR_*                                                            */
+    uint32_t pad[2];
 } ssdr_chan_consts;
+/* the channel filter is exactly a 4-sample delay (one unit tap at index 4: the full-band passband +-6 kHz at 12 kHz,
+ * the reference's AM default, utils_supersdr.py:46).  The kernel then shifts samples across lanes instead of filtering,
+ * and in AM -- where |x e^{j phi}| = |x| -- skips the NCO as well. */
+#define SSDR_FIR_DELAY4 1u
 
 /* Per-channel carried state (read back / restored for tests and checkpointing). 64 B. */
 typedef struct ssdr_chan_state {
@@ -121,6 +126,9 @@ int ssdr_run_wf(ssdr_ctx *ctx, int16_t *wf_sum_out, uint32_t *lines_ready, int o
 /* Fills what kiwi_sound.process_audio_stream returns (utils:1044-1076): int16 PCM and
  * rssi per 512-sample frame.  Either output may be NULL. */
 int ssdr_run_audio(ssdr_ctx *ctx, int16_t *pcm_out, float *rssi_out, int out_is_device);
+/* SND header flags, bit 1 "ADC overflow" (kiwi_sound.adc_overflow_flag, utils_supersdr.py:1066-1067) for every frame of the
+ * last ssdr_run_audio: flags_out uint8 [n_ch][n_frames], 1 where a sample of that frame has |I| or |Q| >= 32767. */
+int ssdr_audio_flags(ssdr_ctx *ctx, uint8_t *flags_out, int out_is_device);
 int ssdr_sync(ssdr_ctx *ctx);
 
 /* -- the reference's own post-processing of the two streams, on the GPU.
@@ -231,7 +239,8 @@ int ssdr_audio_device(ssdr_ctx *ctx, int16_t **pcm, float **rssi);
 /* -- measurement */
 int ssdr_set_stream(ssdr_ctx *ctx, void *hip_stream);           /* NULL = ctx's own stream */
 int ssdr_set_profiling(ssdr_ctx *ctx, int on);                  /* HIP-event pair around every launch */
-/* run the audio kernel on a second stream beside the waterfall kernel (which then takes one workgroup per CU) */
+/* bit 0: run the audio stage on a second stream beside the waterfall kernel (which then takes one workgroup per CU);
+ * bit 1: run the audio stage's per-path kernels one after the other instead of side by side (measurement only) */
 int ssdr_set_concurrent(ssdr_ctx *ctx, int on);
 enum { SSDR_K_WF = 0, SSDR_K_AUDIO = 1, SSDR_K_SYNTH = 2, SSDR_K_DB2COL = 3, SSDR_K_PLAY = 4, SSDR_K_WIRE = 5, SSDR_K_TRACE = 6, SSDR_K_SMETER = 7, SSDR_K_COUNT = 8 };
 int ssdr_kernel_stats(ssdr_ctx *ctx, int which, float *total_ms, uint32_t *launches, int reset);

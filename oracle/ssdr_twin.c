@@ -272,8 +272,10 @@ typedef struct {            /* per-channel kernel constants; same layout as the 
     float agc_c0, agc_c1, agc_knee, agc_delta8;
     uint32_t hang_frames, ntap;
     uint32_t tap_groups;    /* unused here: zero taps are exact no-ops in the fma chain */
-    uint32_t pad[3];
+    uint32_t fir_flags;     /* bit 0: the filter is a pure 4-sample delay (one unit tap at index 4) */
+    uint32_t pad[2];
 } twin_consts;              /* 64 bytes */
+#define FIR_DELAY4 1u
 
 typedef struct {
     uint32_t phi1, phi2;
@@ -327,7 +329,7 @@ static const float KFM = 0x1.8723a2p+12f;   /* float32(16384*12000/(2*pi*5000)) 
 static const float P_FLOOR = 9.5367431640625e-07f;   /* 2^-20 */
 
 static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, const float *taps,
-                        twin_state *st, int16_t *hist /*[HIST][2]*/, int16_t *pcm, float *rssi)
+                        twin_state *st, int16_t *hist /*[HIST][2]*/, int16_t *pcm, float *rssi, uint8_t *flag)
 {
     static _Thread_local float z1r[HIST + FRAME], z1i[HIST + FRAME];
     float z2r[FRAME], z2i[FRAME], p[FRAME], aud[FRAME];
@@ -348,6 +350,23 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
         }
         z2r[n] = ar; z2i[n] = ai;
         p[n] = fmaf(ar, ar, ai * ai);
+    }
+    /* AM behind a filter that is a pure delay: |x e^{j phi}| = |x|, so envelope, AGC level and RSSI do not depend on
+     * the NCO.  The power of a sample is then taken exactly in integers, I*I + Q*Q (< 2^32), and rounded once.
+     * (z2 keeps its mixed value: its last sample is the discriminator memory carried in the state.) */
+    const int am_raw = (c->mode == 0) && (c->fir_flags & FIR_DELAY4);
+    if (am_raw) {
+        for (int n = 0; n < FRAME; n++) {
+            const int16_t *x = (n < 4) ? hist + 2 * (HIST + n - 4) : iq + 2 * (n - 4);
+            const uint32_t q = (uint32_t)((int32_t)x[0] * x[0]) + (uint32_t)((int32_t)x[1] * x[1]);
+            p[n] = (float)q;
+        }
+    }
+    /* ADC overflow (SND header flags bit 1, utils_supersdr.py:1066-1067): a sample of this frame at the rails */
+    {
+        int ovf = 0;
+        for (int n = 0; n < 2 * FRAME; n++) ovf |= (iq[n] >= 32767) || (iq[n] <= -32767);
+        *flag = (uint8_t)ovf;
     }
     /* 3. demod */
     if (c->mode == 0) {
@@ -453,12 +472,20 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
 
 /* batch: iq[n_ch][n_frames*512][2]; consts[n_ch]; taps[n_ch][128]; state[n_ch]; hist[n_ch][128][2]
  * -> pcm[n_ch][n_frames*512], rssi[n_ch][n_frames]; state and hist updated in place. */
-void twin_audio(const int16_t *iq, uint32_t n_ch, uint32_t n_frames, const twin_consts *consts,
-                const float *taps, twin_state *state, int16_t *hist, int16_t *pcm, float *rssi)
+void twin_audio2(const int16_t *iq, uint32_t n_ch, uint32_t n_frames, const twin_consts *consts,
+                 const float *taps, twin_state *state, int16_t *hist, int16_t *pcm, float *rssi, uint8_t *flags)
 {
+    uint8_t dummy;
     for (uint32_t c = 0; c < n_ch; c++)
         for (uint32_t f = 0; f < n_frames; f++)
             audio_frame(iq + ((size_t)c * n_frames + f) * FRAME * 2, consts + c,
                         taps + (size_t)c * NTAP_MAX, state + c, hist + (size_t)c * HIST * 2,
-                        pcm + ((size_t)c * n_frames + f) * FRAME, rssi + (size_t)c * n_frames + f);
+                        pcm + ((size_t)c * n_frames + f) * FRAME, rssi + (size_t)c * n_frames + f,
+                        flags ? flags + (size_t)c * n_frames + f : &dummy);
+}
+
+void twin_audio(const int16_t *iq, uint32_t n_ch, uint32_t n_frames, const twin_consts *consts,
+                const float *taps, twin_state *state, int16_t *hist, int16_t *pcm, float *rssi)
+{
+    twin_audio2(iq, n_ch, n_frames, consts, taps, state, hist, pcm, rssi, NULL);
 }

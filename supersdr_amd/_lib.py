@@ -30,7 +30,8 @@ class ChanConsts(C.Structure):
     _fields_ = [("mode", C.c_uint32), ("ntap8", C.c_uint32), ("dphi1", C.c_uint32), ("dphi2", C.c_uint32),
                 ("wf_cal_lin", C.c_float), ("smeter_cal_db", C.c_float),
                 ("agc_c0", C.c_float), ("agc_c1", C.c_float), ("agc_knee", C.c_float), ("agc_delta8", C.c_float),
-                ("hang_frames", C.c_uint32), ("ntap", C.c_uint32), ("tap_groups", C.c_uint32), ("pad", C.c_uint32 * 3)]
+                ("hang_frames", C.c_uint32), ("ntap", C.c_uint32), ("tap_groups", C.c_uint32), ("fir_flags", C.c_uint32),
+                ("pad", C.c_uint32 * 2)]
 
 
 class Db2colChan(C.Structure):
@@ -75,6 +76,7 @@ _SIGS = {
     "ssdr_push_iq": (C.c_int, [_P, _P, C.c_uint32, C.c_int]),
     "ssdr_run_wf": (C.c_int, [_P, _P, C.POINTER(C.c_uint32), C.c_int]),
     "ssdr_run_audio": (C.c_int, [_P, _P, _P, C.c_int]),
+    "ssdr_audio_flags": (C.c_int, [_P, _P, C.c_int]),
     "ssdr_sync": (C.c_int, [_P]),
     "ssdr_run_db2col": (C.c_int, [_P, C.POINTER(Db2colChan), _P, C.c_int]),
     "ssdr_run_playbuffer": (C.c_int, [_P, C.POINTER(PlayChan), _P, C.c_int]),

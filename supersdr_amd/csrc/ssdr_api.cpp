@@ -37,6 +37,13 @@ struct ssdr_ctx {
     float *d_taps = nullptr;
     ssdr_chan_state *d_state = nullptr;
     uint32_t *d_hist = nullptr;
+    std::vector<ssdr_chan_consts> h_consts;             // host mirror of d_consts
+    uint32_t *d_chan_list = nullptr;                    // channels sorted by audio frame path (ssdr_audio_path)
+    uint32_t path_off[SSDR_PATH_COUNT] = {}, path_n[SSDR_PATH_COUNT] = {};
+    bool chan_list_dirty = true;
+    hipStream_t path_stream[SSDR_PATH_COUNT - 1] = {};  // the audio kernels of different paths run side by side
+    hipEvent_t ev_fork = nullptr, ev_path[SSDR_PATH_COUNT - 1] = {};
+    bool audio_serial = false;                          // measurement: one path kernel after the other on one stream
     int16_t *d_wf_acc[2] = {nullptr, nullptr};          // ping-pong: carry-in / carry-out of partial groups
     int wf_acc_cur = 0;
     // input batch
@@ -54,6 +61,9 @@ struct ssdr_ctx {
     int16_t *d_pcm = nullptr;
     float *d_rssi = nullptr;
     size_t audio_frames = 0;
+    uint8_t *d_flags = nullptr;               // ADC-overflow flag per frame of the last audio run
+    size_t flags_frames = 0;
+    uint32_t audio_run_frames = 0;            // frames the last audio run (or ssdr_set_pcm) produced: extent and stride of d_pcm / d_rssi
     // pipelined host feed (ssdr_feed_*): slots of pinned host memory + their own device buffers
     struct FeedSlot {
         void *h_in = nullptr;                            // int16 IQ, or SND bodies in wire mode
@@ -176,8 +186,8 @@ void ssdr_destroy(ssdr_ctx *c)
     (void)hipSetDevice(c->device);
     (void)ssdr_feed_close(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_wf_acc[0], c->d_wf_acc[1],
-                    c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
+    void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_wf_acc[0], c->d_wf_acc[1],
+                    c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_flags, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
                     c->d_play_taps, c->d_play_hist, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
                     c->d_smeter_in, c->d_wire, c->d_wire_rssi};
     for (void *p : ptrs)
@@ -189,6 +199,11 @@ void ssdr_destroy(ssdr_ctx *c)
     if (c->stream2) { (void)hipStreamSynchronize(c->stream2); (void)hipStreamDestroy(c->stream2); }
     if (c->ev_in) (void)hipEventDestroy(c->ev_in);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int i = 0; i < SSDR_PATH_COUNT - 1; i++) {
+        if (c->path_stream[i]) { (void)hipStreamSynchronize(c->path_stream[i]); (void)hipStreamDestroy(c->path_stream[i]); }
+        if (c->ev_path[i]) (void)hipEventDestroy(c->ev_path[i]);
+    }
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -278,6 +293,8 @@ int ssdr_set_params(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan
         const int rc = ssdr_compile_params_host(p + i, &k[i], taps.data() + (size_t)i * SSDR_NTAP_MAX);
         if (rc != SSDR_OK) return rc;
     }
+    for (uint32_t i = 0; i < count; i++) c->h_consts[first + i] = k[i];
+    c->chan_list_dirty = true;
     HIP_TRY(hipMemcpyAsync(c->d_consts + first, k.data(), count * sizeof(ssdr_chan_consts), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_taps + (size_t)first * SSDR_NTAP_MAX, taps.data(), taps.size() * sizeof(float),
                            hipMemcpyHostToDevice, c->stream));
@@ -325,6 +342,13 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         HIP_TRY(hipMalloc(&c->d_consts, (size_t)n_channels * sizeof(ssdr_chan_consts)));
         HIP_TRY(hipMalloc(&c->d_taps, (size_t)n_channels * SSDR_NTAP_MAX * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_state, (size_t)n_channels * sizeof(ssdr_chan_state)));
+        HIP_TRY(hipMalloc(&c->d_chan_list, (size_t)n_channels * sizeof(uint32_t)));
+        c->h_consts.resize(n_channels);
+        HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (int i = 0; i < SSDR_PATH_COUNT - 1; i++) {
+            HIP_TRY(hipStreamCreateWithFlags(&c->path_stream[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&c->ev_path[i], hipEventDisableTiming));
+        }
         HIP_TRY(hipMalloc(&c->d_hist, (size_t)n_channels * SSDR_HIST * 4));
         HIP_TRY(hipMalloc(&c->d_wf_acc[0], (size_t)n_channels * SSDR_NFFT * 2));
         HIP_TRY(hipMalloc(&c->d_wf_acc[1], (size_t)n_channels * SSDR_NFFT * 2));
@@ -389,7 +413,8 @@ int ssdr_set_concurrent(ssdr_ctx *c, int on)
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream2));
-    c->concurrent = on != 0;
+    c->concurrent = (on & 1) != 0;
+    c->audio_serial = (on & 2) != 0;
     c->audio_pending = false;
     return SSDR_OK;
 }
@@ -571,6 +596,13 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         HIP_TRY(hipMalloc(&c->d_rssi, (size_t)c->n_ch * c->in_frames * sizeof(float)));
         c->audio_frames = c->in_frames;
     }
+    if (c->flags_frames < c->in_frames) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_flags) { HIP_TRY(hipFree(c->d_flags)); c->d_flags = nullptr; }
+        c->flags_frames = 0;
+        HIP_TRY(hipMalloc(&c->d_flags, (size_t)c->n_ch * c->in_frames));
+        c->flags_frames = c->in_frames;
+    }
     SsdrAudioArgs a;
     a.iq = c->d_iq;
     a.ch_stride = (uint64_t)c->in_frames * SSDR_FRAME;
@@ -582,6 +614,7 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
     a.hist = c->d_hist;
     a.pcm = c->d_pcm;
     a.rssi = c->d_rssi;
+    a.flags = c->d_flags;
     int rc;
     hipStream_t s = c->stream;
     if (c->concurrent) {
@@ -592,8 +625,46 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         HIP_TRY(hipStreamWaitEvent(s, c->ev_in, 0));
     }
     c->audio_started = true;
+    c->audio_run_frames = c->in_frames;
+    if (c->chan_list_dirty) {                // channels sorted by frame path; rebuilt after ssdr_set_params
+        std::vector<uint32_t> list(c->n_ch);
+        uint32_t pos = 0;
+        for (int p = 0; p < SSDR_PATH_COUNT; p++) {
+            c->path_off[p] = pos;
+            for (uint32_t ch = 0; ch < c->n_ch; ch++)
+                if (ssdr_audio_path(c->h_consts[ch]) == p) list[pos++] = ch;
+            c->path_n[p] = pos - c->path_off[p];
+        }
+        HIP_TRY(hipMemcpyAsync(c->d_chan_list, list.data(), (size_t)c->n_ch * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        HIP_TRY(hipStreamSynchronize(s));    // `list` goes out of scope
+        c->chan_list_dirty = false;
+    }
+    // one kernel per non-empty path: the first on the stream itself, the others beside it on their own streams
+    // (fork and join by events); the stage is timed between two events on `s`
     if ((rc = timed_begin(c, s)) != SSDR_OK) return rc;
-    HIP_TRY(ssdr_launch_audio(a, s));
+    {
+        int n_paths = 0, n_side = 0;
+        for (int p = 0; p < SSDR_PATH_COUNT; p++) n_paths += c->path_n[p] != 0;
+        const bool side = n_paths > 1 && !c->audio_serial;
+        if (side) HIP_TRY(hipEventRecord(c->ev_fork, s));
+        bool first = true;
+        for (int p = 0; p < SSDR_PATH_COUNT; p++) {
+            if (!c->path_n[p]) continue;
+            a.chan_list = c->d_chan_list + c->path_off[p];
+            a.list_n = c->path_n[p];
+            if (first || !side) {
+                HIP_TRY(ssdr_launch_audio(a, p, s));
+            } else {
+                hipStream_t ps = c->path_stream[n_side];
+                HIP_TRY(hipStreamWaitEvent(ps, c->ev_fork, 0));
+                HIP_TRY(ssdr_launch_audio(a, p, ps));
+                HIP_TRY(hipEventRecord(c->ev_path[n_side], ps));
+                n_side++;
+            }
+            first = false;
+        }
+        for (int i = 0; i < n_side; i++) HIP_TRY(hipStreamWaitEvent(s, c->ev_path[i], 0));
+    }
     if ((rc = timed_end(c, SSDR_K_AUDIO, s)) != SSDR_OK) return rc;
     const hipMemcpyKind kind = out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (pcm_out) HIP_TRY(hipMemcpyAsync(pcm_out, c->d_pcm, (size_t)c->n_ch * c->in_frames * SSDR_FRAME * 2, kind, s));
@@ -603,6 +674,18 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         HIP_TRY(hipEventRecord(c->ev_a, s));
         c->audio_pending = true;
     }
+    return SSDR_OK;
+}
+
+int ssdr_audio_flags(ssdr_ctx *c, uint8_t *flags_out, int out_is_device)
+{
+    if (!c || !flags_out) return SSDR_EINVAL;
+    if (!c->d_flags || c->audio_run_frames == 0 || c->flags_frames < c->audio_run_frames) return SSDR_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
+    HIP_TRY(hipMemcpyAsync(flags_out, c->d_flags, (size_t)c->n_ch * c->audio_run_frames,
+                           out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    if (!out_is_device) HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
 }
 
@@ -708,7 +791,7 @@ int ssdr_feed_submit(ssdr_ctx *c)
     // run the two kernels on this slot's buffers: the ctx's own batch pointers are parked meanwhile
     const uint32_t *k_iq = c->d_iq; const uint32_t k_frames = c->in_frames; const bool k_have = c->have_input;
     int16_t *k_wf = c->d_wf_out; const size_t k_wf_lines = c->wf_out_lines; const uint32_t k_ready = c->wf_lines_ready;
-    int16_t *k_pcm = c->d_pcm; float *k_rssi = c->d_rssi; const size_t k_af = c->audio_frames;
+    int16_t *k_pcm = c->d_pcm; float *k_rssi = c->d_rssi; const size_t k_af = c->audio_frames; const uint32_t k_arf = c->audio_run_frames;
     c->d_iq = s.d_in; c->in_frames = nf; c->have_input = true;
     c->d_wf_out = s.d_wf; c->wf_out_lines = nf / 2;
     c->d_pcm = s.d_pcm; c->d_rssi = s.d_rssi; c->audio_frames = nf;
@@ -717,7 +800,7 @@ int ssdr_feed_submit(ssdr_ctx *c)
     if (rc == SSDR_OK) rc = ssdr_run_audio(c, nullptr, nullptr, 0);
     c->d_iq = k_iq; c->in_frames = k_frames; c->have_input = k_have;
     c->d_wf_out = k_wf; c->wf_out_lines = k_wf_lines; c->wf_lines_ready = k_ready;
-    c->d_pcm = k_pcm; c->d_rssi = k_rssi; c->audio_frames = k_af;
+    c->d_pcm = k_pcm; c->d_rssi = k_rssi; c->audio_frames = k_af; c->audio_run_frames = k_arf;
     if (rc != SSDR_OK) return rc;
     s.lines = lines;
     HIP_TRY(hipEventRecord(s.ev_run, c->stream));
@@ -792,7 +875,10 @@ int ssdr_set_state(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan_
 {
     if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
-    if (state) HIP_TRY(hipMemcpyAsync(c->d_state + first, state, count * sizeof(ssdr_chan_state), hipMemcpyHostToDevice, c->stream));
+    if (state) {
+        HIP_TRY(hipMemcpyAsync(c->d_state + first, state, count * sizeof(ssdr_chan_state), hipMemcpyHostToDevice, c->stream));
+        c->audio_started = true;             // a restored stream is live: ssdr_set_params must not re-seed its state
+    }
     if (hist) HIP_TRY(hipMemcpyAsync(c->d_hist + (size_t)first * SSDR_HIST, hist, (size_t)count * SSDR_HIST * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
@@ -966,7 +1052,7 @@ int ssdr_run_trace(ssdr_ctx *c, uint32_t t_avg, uint32_t spectrum_height, double
 int ssdr_run_smeter(ssdr_ctx *c, ssdr_smeter_chan *chans, const double *rssi_in, double fps)
 {
     if (!c || !chans || !(fps > 0.0)) return SSDR_EINVAL;
-    if (!rssi_in && (!c->d_rssi || c->audio_frames == 0 || c->in_frames == 0)) return SSDR_ESTATE;
+    if (!rssi_in && (!c->d_rssi || c->audio_frames == 0 || c->audio_run_frames == 0)) return SSDR_ESTATE;
     HIP_TRY(hipSetDevice(c->device));
     { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     if (!c->d_smeter) {
@@ -980,7 +1066,7 @@ int ssdr_run_smeter(ssdr_ctx *c, ssdr_smeter_chan *chans, const double *rssi_in,
     a.rssi = c->d_rssi;
     a.rssi_in = rssi_in ? c->d_smeter_in : nullptr;
     a.n_ch = c->n_ch;
-    a.n_frames = c->in_frames;
+    a.n_frames = c->audio_run_frames;
     a.fps = fps;
     int rc;
     if ((rc = timed_begin(c)) != SSDR_OK) return rc;
@@ -1008,10 +1094,10 @@ int ssdr_playbuffer_frame_len(ssdr_ctx *c, uint32_t *samples_per_frame)
 int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, int out_is_device)
 {
     if (!c || !chans) return SSDR_EINVAL;
-    if (!c->d_pcm || c->in_frames == 0 || c->audio_frames < c->in_frames) return SSDR_ESTATE;
+    if (!c->d_pcm || c->audio_run_frames == 0 || c->audio_frames < c->audio_run_frames) return SSDR_ESTATE;
     HIP_TRY(hipSetDevice(c->device));
     { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
-    const uint32_t nf = c->in_frames;
+    const uint32_t nf = c->audio_run_frames;
     const bool wide = c->kiwi_rate != SSDR_RATE;                  // SAMPLE_RATIO % 1 != 0 (:1125)
     const size_t per_frame = wide ? (size_t)SSDR_RS_OUT_PER_FRAME : 2048;
     if (!c->d_play) {
@@ -1143,7 +1229,7 @@ int ssdr_set_pcm(ssdr_ctx *c, const int16_t *pcm, uint32_t n_frames)
     }
     HIP_TRY(hipMemcpyAsync(c->d_pcm, pcm, (size_t)c->n_ch * n_frames * SSDR_FRAME * 2, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->in_frames = n_frames;
+    c->audio_run_frames = n_frames;          // the input batch (d_iq / in_frames / have_input) is not touched
     return SSDR_OK;
 }
 

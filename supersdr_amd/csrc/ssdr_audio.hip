@@ -58,6 +58,25 @@ SSDR_DEV float vmax3(float a, float b, float c)
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// max(a, |b|, |c|): the absolute values are source modifiers, no extra instruction
+SSDR_DEV float vmax3_abs(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+SSDR_DEV uint32_t lane63_u(uint32_t x) { return (uint32_t)__builtin_amdgcn_readlane((int)x, 63); }
+SSDR_DEV uint32_t from_prev_lane_u(uint32_t lane0_value, uint32_t x)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)x, 0x138, 0xF, 0xF, false);     // wave_shr:1
+}
+// I*I + Q*Q of one raw sample, exactly, in one instruction (v_dot2_i32_i16; both components -32768 give 2^31, read unsigned)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+SSDR_DEV uint32_t iq_power(uint32_t raw)
+{
+    const s16x2 v = __builtin_bit_cast(s16x2, raw);
+    return (uint32_t)__builtin_amdgcn_sdot2(v, v, 0, false);
+}
 SSDR_DEV float lane63(float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63)); }
 SSDR_DEV float from_prev_lane(float lane0_value, float x) { return dpp<0x138, 0xF>(lane0_value, x); }   // wave_shr:1
 
@@ -108,7 +127,9 @@ SSDR_DEV void step_phasor(uint32_t dphi, float &c, float &s)
 
 // Block NCO: the phasor of sample j of an 8-sample block is P20(phase of the block start) * S^j.
 // One polynomial sincos per 8 samples, a complex rotation (4 full-rate ops) for each of the others.
-SSDR_DEV void mix8(const uint32_t (&rw)[8], uint32_t phase0, float cs, float ss, float2 (&z)[8])
+// CLIP: amax = max(amax, |I|, |Q|) over the block (ADC-overflow detection on the samples as they arrive).
+template <bool CLIP>
+SSDR_DEV void mix8(const uint32_t (&rw)[8], uint32_t phase0, float cs, float ss, float2 (&z)[8], float &amax)
 {
     float c, s;
     ssdr_sincos20(phase0, c, s);
@@ -116,6 +137,7 @@ SSDR_DEV void mix8(const uint32_t (&rw)[8], uint32_t phase0, float cs, float ss,
     for (int j = 0; j < 8; j++) {
         const float xr = (float)(int16_t)(rw[j] & 0xFFFFu);
         const float xi = (float)((int32_t)rw[j] >> 16);
+        if (CLIP) amax = vmax3_abs(amax, xr, xi);
         z[j] = make_float2(fmaf(xr, c, xi * s), fmaf(xi, c, -(xr * s)));          // x * (c - j s)
         const float cn = fmaf(c, cs, -(s * ss)), sn = fmaf(s, cs, c * ss);
         c = cn; s = sn;
@@ -155,30 +177,152 @@ SSDR_DEV void fir_taps(const float *h, const float2 (&A)[8], const float2 (&B)[8
     }
 }
 
-__global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioArgs a)
+// ---- per-frame pieces shared by the three frame paths of the kernel ----------------------------------
+
+struct AgcK { float c0, c1, knee, d8; uint32_t K; };
+
+// AM: envelope minus a one-pole DC estimate.  The envelope is the correctly rounded sqrt of the power; the
+// recurrence along time is an affine scan across lanes in a defined order (the twin walks the same six steps).
+template <bool INTEGER_POWER>
+SSDR_DEV void demod_am(const float (&p)[8], float &dc, float (&aud)[8])
 {
-    __shared__ __attribute__((aligned(16))) float2 s_z[NOCT * OCT];      // 6400 B
-    __shared__ __attribute__((aligned(16))) float s_taps[SSDR_NTAP_MAX + 8];   // + one block of padding for odd block counts
     constexpr float DC_APOW[8] = SSDR_DC_APOW_INIT;
+    float env[8], loc[8];
+    float s = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        env[j] = INTEGER_POWER ? ssdr_sqrt_rn_int(p[j]) : ssdr_sqrt_rn(p[j]);
+        s = fmaf(SSDR_DC_A, s, SSDR_DC_AL * env[j]);
+        loc[j] = s;
+    }
+    float Asc = DC_APOW[7], Bsc = s;                 // this lane's 8 samples as the map m -> A m + B
+    scan_affine(Asc, Bsc);
+    const float Ae = from_prev_lane(1.0f, Asc), Be = from_prev_lane(0.0f, Bsc);
+    const float carry = fmaf(Ae, dc, Be);            // lane 0: identity map -> dc
+    float m = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        m = fmaf(DC_APOW[j], carry, loc[j]);
+        aud[j] = env[j] - m;
+    }
+    dc = lane63(m);
+}
 
-    const int l = threadIdx.x;
-    const uint32_t ch = blockIdx.x;
-    if (ch >= a.n_ch) return;
+// SSB / CW product detector: Re{y * e^{+j phi2}}, block NCO as in mix8
+SSDR_DEV void demod_ssb(const float (&yr)[8], const float (&yi)[8], uint32_t phase0, float cs2, float ss2, float (&aud)[8])
+{
+    float c, s;
+    ssdr_sincos20(phase0, c, s);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        aud[j] = fmaf(yr[j], c, -(yi[j] * s));       // Re{y * (c + j s)}
+        const float cn = fmaf(c, cs2, -(s * ss2)), sn = fmaf(s, cs2, c * ss2);
+        c = cn; s = sn;
+    }
+}
 
-    const ssdr_chan_consts &kc = a.consts[ch];
+// NBFM discriminator: angle of y[n] * conj(y[n-1])
+SSDR_DEV void demod_fm(const float (&yr)[8], const float (&yi)[8], float prev_re, float prev_im, float (&aud)[8])
+{
+    float pr = from_prev_lane(prev_re, yr[7]), pi = from_prev_lane(prev_im, yi[7]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float dr = fmaf(yr[j], pr, yi[j] * pi);
+        const float di = fmaf(yi[j], pr, -(yr[j] * pi));
+        aud[j] = ssdr_atan2p(di, dr) * SSDR_KFM;
+        pr = yr[j]; pi = yi[j];
+    }
+}
+
+// AGC (block peak -> log2 -> (max,+) follower across lanes -> gain), round-half-even, saturate, pack, store
+SSDR_DEV void agc_pack_store(const float (&p)[8], const float (&aud)[8], int l, const AgcK &k, float &agc_d,
+                             float (&agc_m)[8], int16_t *dst)
+{
+    // max of the eight powers and the floor in four three-input maxima (max is exact: any grouping gives the same value)
+    const float pm = vmax3(vmax3(vmax3(p[0], p[1], p[2]), p[3], p[4]), vmax3(p[5], p[6], p[7]), SSDR_P_FLOOR);
+    const float al = ssdr_log2p(pm);
+    const float fl = (float)l;
+    const float d8 = k.d8;
+    float e;
+    if (k.K == 0) {
+        const float P = scan_max(fmaf(fl, d8, al));
+        e = vmax(fmaf(-fl, d8, P), fmaf(-(fl + 1.0f), d8, agc_d));
+        agc_d = lane63(e);
+    } else {
+        const float P = scan_max(al);
+        float maxM = agc_m[0], mK = agc_m[0];
+#pragma unroll
+        for (int i = 1; i < 8; i++)
+            if ((uint32_t)i < k.K) { maxM = fmaxf(maxM, agc_m[i]); mK = agc_m[i]; }
+        e = vmax(vmax(P, maxM), fmaf(-(fl + 1.0f), d8, agc_d));
+        agc_d = fmaxf(fmaf(-64.0f, d8, agc_d), mK);
+#pragma unroll
+        for (int i = 7; i > 0; i--) agc_m[i] = agc_m[i - 1];
+        agc_m[0] = lane63(P);
+    }
+    const float g = ssdr_exp2p(fmaf(k.c1, vmax(e, k.knee), k.c0));
+    u32x4 w;
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        // v_cvt_i32_f32 saturates, v_cvt_pk_i16_i32 saturates again to int16: same as clamp(rint(y))
+        const int i0 = __float2int_rn(aud[j] * g), i1 = __float2int_rn(aud[j + 1] * g);
+        w[j >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(i0, i1));
+    }
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(dst));
+}
+
+// Per-frame RSSI (sum over the frame = last lane of the inclusive sum scan) and ADC-overflow flag.  Lane (f mod 64)
+// keeps both; the conversion to dBm (one log2) and the stores run once per 64 frames (or at the end of the call) for
+// all kept frames together, instead of once per frame on a single lane.
+SSDR_DEV void rssi_flag_step(const float (&p)[8], bool clip, uint32_t f, uint32_t n_frames, int l, float cal,
+                             float &rssi_sum, uint32_t &flag_keep, float *rssi_row, uint8_t *flag_row)
+{
+    float ps = p[0];
+#pragma unroll
+    for (int j = 1; j < 8; j++) ps = ps + p[j];
+    const float tot = lane63(scan_sum(ps));
+    if ((f & 63u) == (uint32_t)l) { rssi_sum = tot; flag_keep = clip ? 1u : 0u; }
+    if ((f & 63u) == 63u || f + 1 == n_frames) {
+        if ((uint32_t)l <= (f & 63u)) {
+            rssi_row[(f & ~63u) + l] = fmaf(ssdr_log2p(fmaxf(rssi_sum, 1e-20f)) - 39.0f, SSDR_DB_PER_LOG2, cal);
+            flag_row[(f & ~63u) + l] = (uint8_t)flag_keep;
+        }
+    }
+}
+
+SSDR_DEV bool wave_any(bool x) { return __builtin_amdgcn_ballot_w64(x) != 0ull; }
+
+// |component| >= 32767 for any of a lane's eight raw samples (the rare exact check behind the cheap triggers)
+SSDR_DEV bool raw_clipped(const uint32_t (&rw)[8])
+{
+    bool c = false;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int lo = (int16_t)(rw[j] & 0xFFFFu), hi = (int32_t)rw[j] >> 16;
+        c = c || lo >= 32767 || lo <= -32767 || hi >= 32767 || hi <= -32767;
+    }
+    return c;
+}
+
+enum { PATH_GENERAL = SSDR_PATH_GENERAL, PATH_DELAY4 = SSDR_PATH_DELAY4, PATH_AM_RAW = SSDR_PATH_AM_RAW };
+
+// One receiver channel, all frames of the call.
+//   PATH_GENERAL  NCO -> LDS -> FIR (any tap set)
+//   PATH_DELAY4   the channel filter is a pure 4-sample delay (the reference's full-band +-6 kHz passband at 12 kHz:
+//                 one unit tap): the "FIR" is a lane shift by DPP, no LDS
+//   PATH_AM_RAW   PATH_DELAY4 and mode AM: |x e^{j phi}| = |x|, so the envelope, the AGC level and the RSSI do not
+//                 depend on the NCO at all; the power of a sample is taken exactly in integers (I*I + Q*Q, one
+//                 v_dot2) and rounded once
+template <int PATH>
+SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const int l, const ssdr_chan_consts &kc,
+                             float2 *s_z, float *s_taps)
+{
     const uint32_t mode = kc.mode;
     const uint32_t tap_groups = kc.tap_groups;           // fma(0, z, acc) == acc exactly: all-zero 4-tap groups are skipped
     const uint32_t nblk = (kc.ntap + 7) >> 3;
     const uint32_t dphi1 = kc.dphi1, dphi2 = kc.dphi2;
-    const float c0 = kc.agc_c0, c1 = kc.agc_c1, knee = kc.agc_knee, d8 = kc.agc_delta8;
-    const uint32_t K = kc.hang_frames;
+    const AgcK agc = {kc.agc_c0, kc.agc_c1, kc.agc_knee, kc.agc_delta8, kc.hang_frames};
     const float cal = kc.smeter_cal_db;
-    {   // the channel's taps go to LDS once; the FIR reads them back as broadcasts
-        const float2 t = reinterpret_cast<const float2 *>(a.taps + (size_t)ch * SSDR_NTAP_MAX)[l];
-        s_taps[2 * l] = t.x;
-        s_taps[2 * l + 1] = t.y;
-        if (l < 8) s_taps[SSDR_NTAP_MAX + l] = 0.0f;
-    }
     float cs1, ss1, cs2, ss2;
     step_phasor(dphi1, cs1, ss1);
     step_phasor(dphi2, cs2, ss2);
@@ -190,170 +334,166 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
 #pragma unroll
     for (int i = 0; i < 8; i++) agc_m[i] = st.agc_m[i];
 
-    // history z1[-128..-1]: re-mix the raw tail kept in HBM exactly as the previous frame mixed it
-    // (block t of the tail was block 48+t of that frame): lanes 0..15, one octet each
-    if (l < HOCT) {
-        const uint4 *hp = reinterpret_cast<const uint4 *>(a.hist + (size_t)ch * SSDR_HIST + 8 * l);
+    const uint32_t *hist = a.hist + (size_t)ch * SSDR_HIST;
+    float2 tail_z[4];                                   // PATH_DELAY4: mixed samples -4..-1 (wave-uniform)
+    uint32_t tail_q[4];                                 // PATH_AM_RAW: I*I + Q*Q of samples -4..-1 (wave-uniform)
+    if constexpr (PATH == PATH_GENERAL) {
+        {   // the channel's taps go to LDS once; the FIR reads them back as broadcasts
+            const float2 t = reinterpret_cast<const float2 *>(a.taps + (size_t)ch * SSDR_NTAP_MAX)[l];
+            s_taps[2 * l] = t.x;
+            s_taps[2 * l + 1] = t.y;
+            if (l < 8) s_taps[SSDR_NTAP_MAX + l] = 0.0f;
+        }
+        // history z1[-128..-1]: re-mix the raw tail kept in HBM exactly as the previous frame mixed it
+        // (block t of the tail was block 48+t of that frame): lanes 0..15, one octet each
+        if (l < HOCT) {
+            const uint4 *hp = reinterpret_cast<const uint4 *>(hist + 8 * l);
+            const uint4 h0 = hp[0], h1 = hp[1];
+            const uint32_t rw[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+            float2 H[8];
+            float unused = 0.0f;
+            mix8<false>(rw, phi1 - (uint32_t)(SSDR_HIST - 8 * l) * dphi1, cs1, ss1, H, unused);
+            store_oct(s_z, l, H);
+        }
+    } else {
+        // the last block of the raw tail (samples -8..-1), the same bytes in every lane
+        const uint4 *hp = reinterpret_cast<const uint4 *>(hist + SSDR_HIST - 8);
         const uint4 h0 = hp[0], h1 = hp[1];
         const uint32_t rw[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-        float2 H[8];
-        mix8(rw, phi1 - (uint32_t)(SSDR_HIST - 8 * l) * dphi1, cs1, ss1, H);
-        store_oct(s_z, l, H);
+        if constexpr (PATH == PATH_DELAY4) {
+            float2 H[8];
+            float unused = 0.0f;
+            mix8<false>(rw, phi1 - 8u * dphi1, cs1, ss1, H, unused);
+#pragma unroll
+            for (int j = 0; j < 4; j++) tail_z[j] = H[4 + j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) tail_q[j] = iq_power(rw[4 + j]);
+        }
     }
 
     const uint32_t *src = a.iq + (uint64_t)ch * a.ch_stride + 8 * l;
     int16_t *dst = a.pcm + (uint64_t)ch * a.n_frames * SSDR_FRAME + 8 * l;
+    float *rssi_row = a.rssi + (uint64_t)ch * a.n_frames;
+    uint8_t *flag_row = a.flags + (uint64_t)ch * a.n_frames;
     u32x4 raw0, raw1;
     float rssi_sum = 0.0f;
+    uint32_t flag_keep = 0;
 
     for (uint32_t f = 0; f < a.n_frames; f++, src += SSDR_FRAME, dst += SSDR_FRAME) {
         raw0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src));
         raw1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src) + 1);
         const uint32_t rw[8] = {raw0.x, raw0.y, raw0.z, raw0.w, raw1.x, raw1.y, raw1.z, raw1.w};
-
-        // 1. NCO mix of this lane's 8 samples -> LDS
-        float2 A[8], B[8];
-        mix8(rw, phi1 + (uint32_t)(8 * l) * dphi1, cs1, ss1, A);
-        store_oct(s_z, HOCT + l, A);
-        lds_sync();
-
-        // 2. FIR: y[n] = sum_k h[k] z1[n-k], k ascending, fma chain from zero.  Blocks of 8 taps go in pairs with the
-        //    two register octets swapping roles (newer, older) -> (older, newer), so no window is ever copied.
-        float yr[8], yi[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) { yr[j] = 0.0f; yi[j] = 0.0f; }
-        uint32_t a_oct = 0;                                      // A currently holds octet (l - a_oct)
-        for (uint32_t b = 0; b < nblk; b += 2) {
-            const uint32_t m4 = (tap_groups >> (2 * b)) & 15u;   // wave-uniform
-            if (m4 == 0) continue;
-            const float4 *hq = reinterpret_cast<const float4 *>(s_taps + 8 * b);
-            if (m4 & 3u) {
-                if (a_oct != b) load_oct(s_z, HOCT + l - (int)b, A);
-                load_oct(s_z, HOCT + l - 1 - (int)b, B);
-                const float4 h0 = hq[0], h1 = hq[1];             // same address in all lanes: LDS broadcast
-                const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-                if (m4 & 1u) fir_taps<0, 4>(h, A, B, yr, yi);
-                if (m4 & 2u) fir_taps<4, 4>(h, A, B, yr, yi);
-            }
-            if (m4 & 12u) {
-                if (!(m4 & 3u)) load_oct(s_z, HOCT + l - 1 - (int)b, B);
-                load_oct(s_z, HOCT + l - 2 - (int)b, A);
-                const float4 h0 = hq[2], h1 = hq[3];
-                const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-                if (m4 & 4u) fir_taps<0, 4>(h, B, A, yr, yi);
-                if (m4 & 8u) fir_taps<4, 4>(h, B, A, yr, yi);
-                a_oct = b + 2;
-            }
-        }
-
-        // 3. power, demodulation
         float p[8], aud[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) p[j] = fmaf(yr[j], yr[j], yi[j] * yi[j]);
+        bool clip;
 
-        if (mode == SSDR_MODE_AM) {
-            float env[8], loc[8];
-            float s = 0.0f;
+        if constexpr (PATH == PATH_AM_RAW) {
+            uint32_t q[8], d[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                env[j] = ssdr_sqrt_rn(p[j]);
-                s = fmaf(SSDR_DC_A, s, SSDR_DC_AL * env[j]);
-                loc[j] = s;
-            }
-            float Asc = DC_APOW[7], Bsc = s;                 // this lane's 8 samples as the map m -> A m + B
-            scan_affine(Asc, Bsc);
-            const float Ae = from_prev_lane(1.0f, Asc), Be = from_prev_lane(0.0f, Bsc);
-            const float carry = fmaf(Ae, dc, Be);            // lane 0: identity map -> dc
-            float m = 0.0f;
+            for (int j = 0; j < 8; j++) q[j] = iq_power(rw[j]);
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                m = fmaf(DC_APOW[j], carry, loc[j]);
-                aud[j] = env[j] - m;
-            }
-            dc = lane63(m);
-        } else if (mode <= SSDR_MODE_CW) {
-            float c, s;
-            ssdr_sincos20(phi2 + (uint32_t)(8 * l) * dphi2, c, s);
+            for (int j = 0; j < 4; j++) { d[j] = from_prev_lane_u(tail_q[j], q[4 + j]); d[4 + j] = q[j]; }
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                aud[j] = fmaf(yr[j], c, -(yi[j] * s));       // Re{y * (c + j s)}
-                const float cn = fmaf(c, cs2, -(s * ss2)), sn = fmaf(s, cs2, c * ss2);
-                c = cn; s = sn;
-            }
+            for (int j = 0; j < 4; j++) tail_q[j] = lane63_u(q[4 + j]);
+#pragma unroll
+            for (int j = 0; j < 8; j++) p[j] = (float)d[j];
+            // ADC overflow: a component at the rails makes I*I + Q*Q >= 32767^2; the exact check runs only then
+            // (the delayed window of the lanes misses this frame's last four samples: those are in tail_q, scalar)
+            const float pmx = vmax3(vmax3(vmax3(p[0], p[1], p[2]), p[3], p[4]), vmax3(p[5], p[6], p[7]), 0.0f);
+            const bool trig = wave_any(pmx >= 1073676160.0f) || tail_q[0] >= 0x3FFF0001u || tail_q[1] >= 0x3FFF0001u ||
+                              tail_q[2] >= 0x3FFF0001u || tail_q[3] >= 0x3FFF0001u;
+            clip = trig ? wave_any(raw_clipped(rw)) : false;
+            demod_am<true>(p, dc, aud);
         } else {
-            float pr = from_prev_lane(prev_re, yr[7]), pi = from_prev_lane(prev_im, yi[7]);
+            float yr[8], yi[8];
+            float amax = 0.0f;
+            float2 A[8], B[8];
+            mix8<true>(rw, phi1 + (uint32_t)(8 * l) * dphi1, cs1, ss1, A, amax);
+            clip = wave_any(amax >= 32767.0f);
+            if constexpr (PATH == PATH_DELAY4) {
+                // y[n] = z1[n - 4]: the previous lane's last four samples, then this lane's first four
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const float dr = fmaf(yr[j], pr, yi[j] * pi);
-                const float di = fmaf(yi[j], pr, -(yr[j] * pi));
-                aud[j] = ssdr_atan2p(di, dr) * SSDR_KFM;
-                pr = yr[j]; pi = yi[j];
+                for (int j = 0; j < 4; j++) {
+                    yr[j] = from_prev_lane(tail_z[j].x, A[4 + j].x);
+                    yi[j] = from_prev_lane(tail_z[j].y, A[4 + j].y);
+                    yr[4 + j] = A[j].x;
+                    yi[4 + j] = A[j].y;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; j++) tail_z[j] = make_float2(lane63(A[4 + j].x), lane63(A[4 + j].y));
+            } else {
+                // 1. NCO mix of this lane's 8 samples -> LDS
+                store_oct(s_z, HOCT + l, A);
+                lds_sync();
+                // 2. FIR: y[n] = sum_k h[k] z1[n-k], k ascending, fma chain from zero.  Blocks of 8 taps go in pairs with
+                //    the two register octets swapping roles (newer, older) -> (older, newer), so no window is ever copied.
+#pragma unroll
+                for (int j = 0; j < 8; j++) { yr[j] = 0.0f; yi[j] = 0.0f; }
+                uint32_t a_oct = 0;                                      // A currently holds octet (l - a_oct)
+                for (uint32_t b = 0; b < nblk; b += 2) {
+                    const uint32_t m4 = (tap_groups >> (2 * b)) & 15u;   // wave-uniform
+                    if (m4 == 0) continue;
+                    const float4 *hq = reinterpret_cast<const float4 *>(s_taps + 8 * b);
+                    if (m4 & 3u) {
+                        if (a_oct != b) load_oct(s_z, HOCT + l - (int)b, A);
+                        load_oct(s_z, HOCT + l - 1 - (int)b, B);
+                        const float4 h0 = hq[0], h1 = hq[1];             // same address in all lanes: LDS broadcast
+                        const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                        if (m4 & 1u) fir_taps<0, 4>(h, A, B, yr, yi);
+                        if (m4 & 2u) fir_taps<4, 4>(h, A, B, yr, yi);
+                    }
+                    if (m4 & 12u) {
+                        if (!(m4 & 3u)) load_oct(s_z, HOCT + l - 1 - (int)b, B);
+                        load_oct(s_z, HOCT + l - 2 - (int)b, A);
+                        const float4 h0 = hq[2], h1 = hq[3];
+                        const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                        if (m4 & 4u) fir_taps<0, 4>(h, B, A, yr, yi);
+                        if (m4 & 8u) fir_taps<4, 4>(h, B, A, yr, yi);
+                        a_oct = b + 2;
+                    }
+                }
             }
+            // 3. power, demodulation
+#pragma unroll
+            for (int j = 0; j < 8; j++) p[j] = fmaf(yr[j], yr[j], yi[j] * yi[j]);
+            if (mode == SSDR_MODE_AM) demod_am<false>(p, dc, aud);
+            else if (mode <= SSDR_MODE_CW) demod_ssb(yr, yi, phi2 + (uint32_t)(8 * l) * dphi2, cs2, ss2, aud);
+            else demod_fm(yr, yi, prev_re, prev_im, aud);
+            // the filter output is an fma chain that ends in "+ 0": a -0 can only come out of the shift path
+            prev_re = lane63(yr[7]);
+            prev_im = lane63(yi[7]);
+            if constexpr (PATH == PATH_DELAY4) { prev_re = prev_re + 0.0f; prev_im = prev_im + 0.0f; }
         }
-        prev_re = lane63(yr[7]);
-        prev_im = lane63(yi[7]);
 
-        // 4. AGC: block peak -> log2 -> (max,+) follower across lanes -> gain
-        float ps = p[0];
-#pragma unroll
-        for (int j = 1; j < 8; j++) ps = ps + p[j];
-        // max of the eight powers and the floor in four three-input maxima (max is exact: any grouping gives the same value)
-        const float pm = vmax3(vmax3(vmax3(p[0], p[1], p[2]), p[3], p[4]), vmax3(p[5], p[6], p[7]), SSDR_P_FLOOR);
-        const float al = ssdr_log2p(pm);
-        const float fl = (float)l;
-        float e;
-        if (K == 0) {
-            const float P = scan_max(fmaf(fl, d8, al));
-            e = vmax(fmaf(-fl, d8, P), fmaf(-(fl + 1.0f), d8, agc_d));
-            agc_d = lane63(e);
-        } else {
-            const float P = scan_max(al);
-            float maxM = agc_m[0], mK = agc_m[0];
-#pragma unroll
-            for (int i = 1; i < 8; i++)
-                if ((uint32_t)i < K) { maxM = fmaxf(maxM, agc_m[i]); mK = agc_m[i]; }
-            e = vmax(vmax(P, maxM), fmaf(-(fl + 1.0f), d8, agc_d));
-            agc_d = fmaxf(fmaf(-64.0f, d8, agc_d), mK);
-#pragma unroll
-            for (int i = 7; i > 0; i--) agc_m[i] = agc_m[i - 1];
-            agc_m[0] = lane63(P);
-        }
-        const float g = ssdr_exp2p(fmaf(c1, vmax(e, knee), c0));
-
-        // 5. round-half-even, saturate, pack 8 x int16 = 16 B, store
-        u32x4 w;
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            // v_cvt_i32_f32 saturates, v_cvt_pk_i16_i32 saturates again to int16: same as clamp(rint(y))
-            const int i0 = __float2int_rn(aud[j] * g), i1 = __float2int_rn(aud[j + 1] * g);
-            w[j >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(i0, i1));
-        }
-        __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(dst));
-
-        // 6. RSSI: sum over the frame = last lane of the inclusive sum scan.  Lane (f mod 64) keeps the sum; the
-        //    conversion to dBm runs once per 64 frames (or at the end of the call) for all kept sums together,
-        //    instead of one log2 per frame on a single lane.
-        const float tot = lane63(scan_sum(ps));
-        if ((f & 63u) == (uint32_t)l) rssi_sum = tot;
-        if ((f & 63u) == 63u || f + 1 == a.n_frames) {
-            if ((uint32_t)l <= (f & 63u))
-                a.rssi[(uint64_t)ch * a.n_frames + (f & ~63u) + l] =
-                    fmaf(ssdr_log2p(fmaxf(rssi_sum, 1e-20f)) - 39.0f, SSDR_DB_PER_LOG2, cal);
-        }
+        // 4./5. AGC, pack, store; 6. RSSI and overflow flag
+        agc_pack_store(p, aud, l, agc, agc_d, agc_m, dst);
+        rssi_flag_step(p, clip, f, a.n_frames, l, cal, rssi_sum, flag_keep, rssi_row, flag_row);
 
         // 7. carry: phases advance one frame; the frame tail becomes the FIR history
         phi1 += (uint32_t)SSDR_FRAME * dphi1;
         phi2 += (uint32_t)SSDR_FRAME * dphi2;
-        lds_sync();
-        if (l < HOCT) {
-            load_oct(s_z, NOCT - HOCT + l, B);
-            store_oct(s_z, l, B);
+        if constexpr (PATH == PATH_GENERAL) {
+            lds_sync();
+            if (l < HOCT) {
+                float2 T[8];
+                load_oct(s_z, NOCT - HOCT + l, T);
+                store_oct(s_z, l, T);
+            }
+            lds_sync();
         }
-        lds_sync();
     }
 
     // state back to HBM (raw tail of the last frame: lanes 48..63 hold it)
     if (a.n_frames) {
+        if constexpr (PATH == PATH_AM_RAW) {
+            // the discriminator memory is the last filter output, y[511] = z1[507]: mix that one block of the last frame
+            const uint32_t rw[8] = {raw0.x, raw0.y, raw0.z, raw0.w, raw1.x, raw1.y, raw1.z, raw1.w};
+            float2 Z[8];
+            float unused = 0.0f;
+            mix8<false>(rw, phi1 - (uint32_t)SSDR_FRAME * dphi1 + (uint32_t)(8 * l) * dphi1, cs1, ss1, Z, unused);
+            prev_re = lane63(Z[3].x) + 0.0f;
+            prev_im = lane63(Z[3].y) + 0.0f;
+        }
         if (l >= 64 - HOCT) {
             u32x4 *hp = reinterpret_cast<u32x4 *>(a.hist + (size_t)ch * SSDR_HIST + 8 * (l - (64 - HOCT)));
             hp[0] = raw0;
@@ -367,6 +507,21 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioA
             a.state[ch] = st;
         }
     }
+}
+
+// One kernel per frame path: the paths differ by a factor of two in registers (the general path holds a 16-sample FIR
+// window, the AM shift path fits 64 VGPRs and needs no LDS), and a wave's register file share is fixed per kernel.  The
+// host keeps the channels of a ctx sorted by path (chan_list) and launches each non-empty group.
+template <int PATH>
+__global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioArgs a)
+{
+    constexpr bool FIR = PATH == PATH_GENERAL;
+    __shared__ __attribute__((aligned(16))) float2 s_z[FIR ? NOCT * OCT : 1];            // 6400 B
+    __shared__ __attribute__((aligned(16))) float s_taps[FIR ? SSDR_NTAP_MAX + 8 : 1];   // + one block of padding for odd block counts
+    const int l = threadIdx.x;
+    if (blockIdx.x >= a.list_n) return;
+    const uint32_t ch = a.chan_list[blockIdx.x];
+    channel_frames<PATH>(a, ch, l, a.consts[ch], s_z, s_taps);
 }
 
 // ---------------------------------------------------------------- synthetic IQ (bench input)
@@ -427,6 +582,12 @@ __global__ void ssdr_sqrt_selftest_kernel(unsigned long long *mismatch)
         bad += (__float_as_uint(ssdr_sqrt_rn(p)) != __float_as_uint(sqrtf(p)));
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) bad += (__float_as_uint(ssdr_sqrt_rn(0.0f)) != 0u);
+    // the unscaled form of the integer-power path: every float in [1, 2^33), and zero
+    for (uint64_t u = 0x3F800000ull + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < 0x50000000ull; u += stride) {
+        const float p = __uint_as_float((uint32_t)u);
+        bad += (__float_as_uint(ssdr_sqrt_rn_int(p)) != __float_as_uint(sqrtf(p)));
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) bad += (__float_as_uint(ssdr_sqrt_rn_int(0.0f)) != 0u);
     if (bad) atomicAdd(mismatch, bad);
 }
 
@@ -438,9 +599,15 @@ hipError_t ssdr_launch_sqrt_selftest(unsigned long long *mismatch, hipStream_t s
     return hipGetLastError();
 }
 
-hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, hipStream_t stream)
+hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, int path, hipStream_t stream)
 {
-    hipLaunchKernelGGL(ssdr_audio_kernel, dim3(a.n_ch), dim3(SSDR_AUDIO_BLOCK), 0, stream, a);
+    if (!a.list_n) return hipSuccess;
+    switch (path) {
+    case SSDR_PATH_GENERAL: hipLaunchKernelGGL(ssdr_audio_kernel<PATH_GENERAL>, dim3(a.list_n), dim3(SSDR_AUDIO_BLOCK), 0, stream, a); break;
+    case SSDR_PATH_DELAY4: hipLaunchKernelGGL(ssdr_audio_kernel<PATH_DELAY4>, dim3(a.list_n), dim3(SSDR_AUDIO_BLOCK), 0, stream, a); break;
+    case SSDR_PATH_AM_RAW: hipLaunchKernelGGL(ssdr_audio_kernel<PATH_AM_RAW>, dim3(a.list_n), dim3(SSDR_AUDIO_BLOCK), 0, stream, a); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

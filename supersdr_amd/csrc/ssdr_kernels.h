@@ -51,7 +51,17 @@ struct SsdrAudioArgs {
     uint32_t *hist;                          // [n_ch][128] raw IQ dwords (oldest first)
     int16_t *pcm;                            // [n_ch][n_frames*512]
     float *rssi;                             // [n_ch][n_frames]
+    uint8_t *flags;                          // [n_ch][n_frames] ADC overflow per frame
+    const uint32_t *chan_list;               // channels of this launch (one frame path), list_n of them
+    uint32_t list_n;
 };
+// frame paths of the audio kernel (ssdr_audio.hip): chosen per channel from its compiled constants
+enum { SSDR_PATH_GENERAL = 0, SSDR_PATH_DELAY4 = 1, SSDR_PATH_AM_RAW = 2, SSDR_PATH_COUNT = 3 };
+static inline int ssdr_audio_path(const ssdr_chan_consts &k)
+{
+    if (!(k.fir_flags & SSDR_FIR_DELAY4)) return SSDR_PATH_GENERAL;
+    return k.mode == SSDR_MODE_AM ? SSDR_PATH_AM_RAW : SSDR_PATH_DELAY4;
+}
 
 struct SsdrSynthArgs {
     uint32_t *iq;
@@ -113,7 +123,7 @@ hipError_t ssdr_launch_adpcm(const uint8_t *data, uint32_t n_streams, uint32_t n
                              hipStream_t stream);
 hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream);
 hipError_t ssdr_wf_blocks_per_cu(int *blocks);
-hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, hipStream_t stream);
+hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, int path, hipStream_t stream);
 hipError_t ssdr_launch_synth(const SsdrSynthArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_sqrt_selftest(unsigned long long *mismatch, hipStream_t stream);
 hipError_t ssdr_launch_quant_selftest(const float *thr, const uint2 *lut, unsigned long long *mismatch, hipStream_t stream);

@@ -122,3 +122,15 @@ SSDR_DEV float ssdr_sqrt_rn(float p)
     r = (ru > 0.0f) ? su : r;
     return r * 0x1p-32f;
 }
+
+// The same for p == 0 or 1 <= p < 2^33 (an integer power I*I + Q*Q rounded to float): the residuals cannot
+// underflow there, so the argument needs no scaling (two multiplies less).  Also checked exhaustively.
+SSDR_DEV float ssdr_sqrt_rn_int(float p)
+{
+    const float s = __builtin_amdgcn_sqrtf(p);
+    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rd = fmaf(-sd, s, p), ru = fmaf(-su, s, p);
+    float r = (rd <= 0.0f) ? sd : s;            // p == 0: s == 0, sd a NaN pattern, compare false -> stays 0; ru = -0 -> stays 0
+    r = (ru > 0.0f) ? su : r;
+    return r;
+}

@@ -133,6 +133,12 @@ int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, flo
     c->ntap = (uint32_t)ntap;
     c->ntap8 = (uint32_t)((ntap + 7) & ~7);
     c->tap_groups = groups;
+    // exactly one tap, a unit one, at index 4: the filter is a 4-sample delay (fl = 6 kHz: sinc vanishes at every other tap)
+    {
+        int nz = 0;
+        for (int i = 0; i < ntap; i++) nz += (taps[i] != 0.0f);
+        c->fir_flags = (nz == 1 && ntap > 4 && taps[4] == 1.0f) ? SSDR_FIR_DELAY4 : 0u;
+    }
     c->dphi1 = dphi_of(p->f_shift_hz + f_bc);
     c->dphi2 = dphi_of(f_bc);
     c->wf_cal_lin = (float)std::pow(10.0, p->wf_cal_db / 10.0);

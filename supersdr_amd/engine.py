@@ -13,7 +13,7 @@ from ._lib import SmeterChan, ChanParams, ChanConsts, ChanState, Db2colChan, Pla
 CONSTS_DTYPE = np.dtype([("mode", "<u4"), ("ntap8", "<u4"), ("dphi1", "<u4"), ("dphi2", "<u4"),
                          ("wf_cal_lin", "<f4"), ("smeter_cal_db", "<f4"), ("agc_c0", "<f4"), ("agc_c1", "<f4"),
                          ("agc_knee", "<f4"), ("agc_delta8", "<f4"), ("hang_frames", "<u4"), ("ntap", "<u4"),
-                         ("tap_groups", "<u4"), ("pad", "<u4", (3,))])
+                         ("tap_groups", "<u4"), ("fir_flags", "<u4"), ("pad", "<u4", (2,))])
 STATE_DTYPE = np.dtype([("phi1", "<u4"), ("phi2", "<u4"), ("dc", "<f4"), ("agc_d", "<f4"), ("agc_m", "<f4", (8,)),
                         ("prev_re", "<f4"), ("prev_im", "<f4"), ("pad", "<u4", (2,))])
 assert CONSTS_DTYPE.itemsize == 64 and STATE_DTYPE.itemsize == 64
@@ -53,6 +53,7 @@ class SsdrEngine:
         self._ctx = L._P()
         check(lib.ssdr_create(int(device), self.n_ch, L.NFFT, L.FRAME, C.byref(self._ctx)), "ssdr_create")
         self.in_frames = 0
+        self.audio_frames = 0          # frames of the last run_audio / set_pcm (extent of the device PCM / RSSI / flags)
 
     def close(self):
         if self._ctx:
@@ -121,6 +122,7 @@ class SsdrEngine:
 
     def run_audio(self, fetch=True):
         """-> (int16 [n_ch, n_frames*512] pcm, float32 [n_ch, n_frames] rssi dBm)."""
+        self.audio_frames = self.in_frames
         if not fetch:
             check(lib.ssdr_run_audio(self._ctx, None, None, 0), "ssdr_run_audio")
             return None
@@ -128,6 +130,13 @@ class SsdrEngine:
         rssi = np.empty((self.n_ch, self.in_frames), np.float32)
         check(lib.ssdr_run_audio(self._ctx, pcm.ctypes.data, rssi.ctypes.data, 0), "ssdr_run_audio")
         return pcm, rssi
+
+    def audio_flags(self):
+        """-> uint8 [n_ch, n_frames]: the SND header's ADC-overflow bit (utils_supersdr.py:1066-1067) for every frame of the
+        last run_audio."""
+        out = np.empty((self.n_ch, self.audio_frames), np.uint8)
+        check(lib.ssdr_audio_flags(self._ctx, out.ctypes.data, 0), "ssdr_audio_flags")
+        return out
 
     def sync(self):
         check(lib.ssdr_sync(self._ctx), "ssdr_sync")
@@ -229,7 +238,7 @@ class SsdrEngine:
         """play_buffer for the frames of the last run_audio -> int16 [n_ch, n_frames*L, 2], L = playbuffer_frame_len()
         (2048 at 12 kHz, 1213 at 20.25 kHz)."""
         arr = (PlayChan * self.n_ch)(*chans)
-        out = np.empty((self.n_ch, self.in_frames * self.playbuffer_frame_len(), 2), np.int16) if fetch else None
+        out = np.empty((self.n_ch, self.audio_frames * self.playbuffer_frame_len(), 2), np.int16) if fetch else None
         check(lib.ssdr_run_playbuffer(self._ctx, arr, out.ctypes.data if fetch else None, 0), "ssdr_run_playbuffer")
         return out
 
@@ -253,8 +262,8 @@ class SsdrEngine:
     def set_pcm(self, pcm):
         """int16 [n_ch, n_frames*512]: stand in for the output of run_audio (golden-vector tests of run_playbuffer)."""
         pcm = np.ascontiguousarray(pcm, np.int16).reshape(self.n_ch, -1)
-        self.in_frames = pcm.shape[1] // L.FRAME
-        check(lib.ssdr_set_pcm(self._ctx, pcm.ctypes.data, self.in_frames), "ssdr_set_pcm")
+        self.audio_frames = pcm.shape[1] // L.FRAME
+        check(lib.ssdr_set_pcm(self._ctx, pcm.ctypes.data, self.audio_frames), "ssdr_set_pcm")
 
     def push_iq_wire(self, bodies):
         """bodies: uint8 [n_ch, n_frames, 2065] SND bodies in IQ mode (kiwi/client.py:384-389, 443-454).
@@ -272,7 +281,7 @@ class SsdrEngine:
         check(lib.ssdr_set_profiling(self._ctx, int(bool(on))), "ssdr_set_profiling")
 
     def set_concurrent(self, on):
-        check(lib.ssdr_set_concurrent(self._ctx, int(bool(on))), "ssdr_set_concurrent")
+        check(lib.ssdr_set_concurrent(self._ctx, int(on)), "ssdr_set_concurrent")
 
     def kernel_stats(self, which, reset=False):
         ms, n = C.c_float(0), C.c_uint32(0)

@@ -162,6 +162,57 @@ def test_audio_bit_exact_vs_twin_and_oracle(S, twin, n_ch, n_frames):
     assert np.abs(rssi - rssi_o).max() < 1e-3
 
 
+def test_full_band_paths_mode_switch_and_adc_overflow_flags(S, twin):
+    """The reference's full-band passband (+-6 kHz at 12 kHz: the filter is a 4-sample delay) takes the kernel's shift
+    paths -- AM without NCO and FIR (integer power), NBFM with a lane shift instead of the FIR.  PCM, RSSI, carried
+    state and the per-frame ADC-overflow flags are bit-exact vs the twin; the modes swap mid-stream (the discriminator
+    memory left by the AM path is the twin's); samples at the rails are flagged in exactly their frame, also the last
+    four of a frame and the first of the next."""
+    n_ch, n_frames = 12, 8
+    iq = O.synth_iq(n_ch, n_frames * 512, seed=404)
+    modes = ["am", "nbfm", "usb"] * 4
+    iq[0, 1 * 512 + 511, 0] = 32767
+    iq[1, 2 * 512 + 508, 1] = -32768
+    iq[2, 3 * 512 + 0, 0] = -32767
+    iq[3, 4 * 512 + 100, 1] = 32766                      # one below the rail: no flag
+    iq[4, 0, 0] = iq[4, 0, 1] = -32768                   # I*I + Q*Q = 2^31
+    iq[5, 7 * 512 + 509, 1] = 32767
+    iq[6, 5 * 512 + 3, 0] = 32767
+    want_flags = (np.abs(iq.astype(np.int32)).reshape(n_ch, n_frames, -1).max(axis=2) >= 32767).astype(np.uint8)
+    assert want_flags.sum() == 6
+
+    def params(ms):
+        return [S.default_params(m, f_shift_hz=((c * 37) % 97 - 48) * 100.0) for c, m in enumerate(ms)]
+
+    swapped = [{"am": "nbfm", "nbfm": "am", "usb": "usb"}[m] for m in modes]
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, params(modes))
+        eng.push_iq(iq[:, : 3 * 512])
+        p1, r1 = eng.run_audio()
+        f1 = eng.audio_flags()
+        c1, t1 = eng.get_consts()
+        eng.set_params(0, params(swapped))
+        eng.push_iq(iq[:, 3 * 512:])
+        p2, r2 = eng.run_audio()
+        f2 = eng.audio_flags()
+        c2, t2 = eng.get_consts()
+        st_g, hist_g = eng.get_state()
+    assert (c1["fir_flags"][[0, 1]] == 1).all() and c1["fir_flags"][2] == 0
+    st, hist = twinlib.fresh_state(c1)
+    q1, s1, g1 = twin.audio(iq[:, : 3 * 512], c1, t1, st, hist, want_flags=True)
+    q2, s2, g2 = twin.audio(iq[:, 3 * 512:], c2, t2, st, hist, want_flags=True)
+    assert np.array_equal(p1, q1) and np.array_equal(p2, q2)
+    assert np.array_equal(r1, s1) and np.array_equal(r2, s2)
+    assert st_g.tobytes() == st.tobytes() and np.array_equal(hist_g, hist)
+    got = np.concatenate([f1, f2], axis=1)
+    assert np.array_equal(got, np.concatenate([g1, g2], axis=1)) and np.array_equal(got, want_flags)
+    ops = [O.ChanParams(mode=m, f_shift_hz=((c * 37) % 97 - 48) * 100.0,
+                        **({"low_cut": 30.0, "high_cut": 3000.0} if m == "usb" else {})) for c, m in enumerate(modes)]
+    pcm_o, _ = O.audio_chain(iq[:, : 3 * 512], ops)
+    rms = np.sqrt(((p1.astype(np.float64) - pcm_o) ** 2).mean(axis=1)) / 32768.0
+    assert rms.max() < PCM_RMS_TOL
+
+
 def test_audio_state_carry_across_calls(S, twin):
     """frame-by-frame pushes == one multi-frame push (FIR history, NCO phase, DC, AGC all carried)"""
     n_ch, n_frames = 8, 6
@@ -285,7 +336,7 @@ def test_random_parameter_surface_bit_exact_vs_twin(S, twin, seed, n_frames):
                            smeter_cal_db=k["smeter_cal_db"]) for k in kw]
     with S.SsdrEngine(n_ch) as eng:
         eng.set_params(0, ps)
-        wfs, ps_, rs, pos = [], [], [], 0
+        wfs, ps_, rs, fl, pos = [], [], [], [], 0
         while pos < n_frames:                                    # several calls: state crosses call boundaries
             k = min(n_frames - pos, 2 * int(rng.integers(1, 6)))
             eng.push_iq(iq[:, pos * 512:(pos + k) * 512])
@@ -293,13 +344,15 @@ def test_random_parameter_surface_bit_exact_vs_twin(S, twin, seed, n_frames):
             p, r = eng.run_audio()
             ps_.append(p)
             rs.append(r)
+            fl.append(eng.audio_flags())
             pos += k
         consts, taps = eng.get_consts()
         st_g, hist_g = eng.get_state()
     st, hist = twinlib.fresh_state(consts)
-    pcm_t, rssi_t = twin.audio(iq, consts, taps, st, hist)
+    pcm_t, rssi_t, flags_t = twin.audio(iq, consts, taps, st, hist, want_flags=True)
     assert np.array_equal(np.concatenate(ps_, axis=1), pcm_t)
     assert np.array_equal(np.concatenate(rs, axis=1), rssi_t)
+    assert np.array_equal(np.concatenate(fl, axis=1), flags_t)
     assert st_g.tobytes() == st.tobytes() and np.array_equal(hist_g, hist)
     assert np.array_equal(np.concatenate(wfs), twin.wf(iq, 1, consts["wf_cal_lin"]))
     # the host-compiled constants are the oracle's

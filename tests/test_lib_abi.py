@@ -76,7 +76,7 @@ def test_param_compile_equals_oracle(S, mode, over):
                       hang=p.agc_hang, thresh=p.agc_thresh, slope=p.agc_slope, decay=p.agc_decay,
                       man_gain=p.agc_man_gain, wf_cal_db=p.wf_cal_db, smeter_cal_db=p.smeter_cal_db)
     ok = O.compile_params(op)
-    for f in ("mode", "ntap", "dphi1", "dphi2", "hang_frames", "tap_groups"):
+    for f in ("mode", "ntap", "dphi1", "dphi2", "hang_frames", "tap_groups", "fir_flags"):
         assert int(k[f]) == int(ok[f]), f
     assert int(k["ntap8"]) == (int(ok["ntap"]) + 7) // 8 * 8
     for f in ("wf_cal_lin", "smeter_cal_db", "agc_c0", "agc_c1", "agc_knee", "agc_delta8"):
@@ -98,7 +98,7 @@ def test_param_compile_equals_oracle_on_random_parameters(S):
                              smeter_cal_db=kw["smeter_cal_db"])
         k, taps = S.compile_params(p)
         ok = O.compile_params(O.ChanParams(**kw))
-        for f in ("mode", "ntap", "dphi1", "dphi2", "hang_frames", "tap_groups"):
+        for f in ("mode", "ntap", "dphi1", "dphi2", "hang_frames", "tap_groups", "fir_flags"):
             assert int(k[f]) == int(ok[f]), (i, f, kw)
         for f in ("wf_cal_lin", "smeter_cal_db", "agc_c0", "agc_c1", "agc_knee", "agc_delta8"):
             assert np.float32(k[f]) == np.float32(ok[f]), (i, f, kw)

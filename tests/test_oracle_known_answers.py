@@ -28,7 +28,7 @@ def consts_for(params):
     for c, p in enumerate(params):
         k = O.compile_params(p)
         for f in ("mode", "ntap", "dphi1", "dphi2", "wf_cal_lin", "smeter_cal_db", "agc_c0", "agc_c1", "agc_knee",
-                  "agc_delta8", "hang_frames"):
+                  "agc_delta8", "hang_frames", "fir_flags"):
             consts[f][c] = k[f]
         consts["ntap8"][c] = (k["ntap"] + 7) // 8 * 8
         taps[c] = k["taps"]

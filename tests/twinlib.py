@@ -12,7 +12,7 @@ SO = os.path.join(ORACLE, "libssdr_twin.so")
 CONSTS_DTYPE = np.dtype([("mode", "<u4"), ("ntap8", "<u4"), ("dphi1", "<u4"), ("dphi2", "<u4"),
                          ("wf_cal_lin", "<f4"), ("smeter_cal_db", "<f4"), ("agc_c0", "<f4"), ("agc_c1", "<f4"),
                          ("agc_knee", "<f4"), ("agc_delta8", "<f4"), ("hang_frames", "<u4"), ("ntap", "<u4"),
-                         ("tap_groups", "<u4"), ("pad", "<u4", (3,))])
+                         ("tap_groups", "<u4"), ("fir_flags", "<u4"), ("pad", "<u4", (2,))])
 STATE_DTYPE = np.dtype([("phi1", "<u4"), ("phi2", "<u4"), ("dc", "<f4"), ("agc_d", "<f4"), ("agc_m", "<f4", (8,)),
                         ("prev_re", "<f4"), ("prev_im", "<f4"), ("pad", "<u4", (2,))])
 
@@ -25,6 +25,7 @@ class Twin:
         lib.twin_wf.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, P, P, P, P, P, P]
         lib.twin_wf_line.argtypes = [P, P, P, P, P, C.c_float, P]
         lib.twin_audio.argtypes = [P, C.c_uint32, C.c_uint32, P, P, P, P, P, P]
+        lib.twin_audio2.argtypes = [P, C.c_uint32, C.c_uint32, P, P, P, P, P, P, P]
         lib.twin_quantise.argtypes = [C.c_float, P]
         lib.twin_quantise.restype = C.c_int
         for f in ("twin_log2p", "twin_exp2p"):
@@ -49,8 +50,8 @@ class Twin:
                          self.wr.ctypes.data, self.wi.ctypes.data, self.thr.ctypes.data, out.ctypes.data)
         return out
 
-    def audio(self, iq, consts, taps, state, hist):
-        """iq int16[n_ch, n_frames*512, 2]; state/hist updated in place -> (pcm, rssi)"""
+    def audio(self, iq, consts, taps, state, hist, want_flags=False):
+        """iq int16[n_ch, n_frames*512, 2]; state/hist updated in place -> (pcm, rssi[, adc-overflow flags uint8])"""
         iq = np.ascontiguousarray(iq, np.int16)
         n_ch, n_frames = iq.shape[0], iq.shape[1] // 512
         consts = np.ascontiguousarray(consts, CONSTS_DTYPE)
@@ -58,9 +59,10 @@ class Twin:
         assert state.dtype == STATE_DTYPE and state.flags.c_contiguous and hist.flags.c_contiguous
         pcm = np.zeros((n_ch, n_frames * 512), np.int16)
         rssi = np.zeros((n_ch, n_frames), np.float32)
-        self.lib.twin_audio(iq.ctypes.data, n_ch, n_frames, consts.ctypes.data, taps.ctypes.data,
-                            state.ctypes.data, hist.ctypes.data, pcm.ctypes.data, rssi.ctypes.data)
-        return pcm, rssi
+        flags = np.zeros((n_ch, n_frames), np.uint8)
+        self.lib.twin_audio2(iq.ctypes.data, n_ch, n_frames, consts.ctypes.data, taps.ctypes.data,
+                             state.ctypes.data, hist.ctypes.data, pcm.ctypes.data, rssi.ctypes.data, flags.ctypes.data)
+        return (pcm, rssi, flags) if want_flags else (pcm, rssi)
 
     def sincos20(self, ph):
         c, s = C.c_float(), C.c_float()

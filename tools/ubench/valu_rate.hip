@@ -45,6 +45,19 @@ __global__ void k(float *out, int iters)
                 if (KIND == 24) asm volatile("v_sub_f32 %0, %0, %1\n v_mul_f32 %0, %0, %2 clamp" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
                 if (KIND == 25) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
                 if (KIND == 26) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
+                if (KIND == 27) asm volatile("v_dot2c_i32_i16 %0, %1, %1" : "+v"(a[i].x) : "v"(b.x));
+                if (KIND == 28) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(a[i].x));
+                if (KIND == 29) asm volatile("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
+                if (KIND == 30) asm volatile("s_nop 1\n v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i].x) : "v"(b.x));
+                if (KIND == 31) asm volatile("s_nop 1\n v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i].x));
+                if (KIND == 32) asm volatile("v_readlane_b32 s20, %0, 63" : : "v"(a[i].x) : "s20");
+                if (KIND == 33) asm volatile("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(a[i].x) : "v"(b.x));
+                if (KIND == 34) asm volatile("v_cvt_pk_i16_i32 %0, %0, %1" : "+v"(a[i].x) : "v"(b.x));
+                if (KIND == 35) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
+                if (KIND == 36) asm volatile("v_fmac_f32 %0, %1, %2\n v_sqrt_f32 %3, %3" : "+v"(a[i].x), "+v"(a[(i + 4) & 7].y) : "v"(b.x), "v"(c.x));
+                if (KIND == 37) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
+                if (KIND == 38) asm volatile("v_rndne_f32 %0, %0" : "+v"(a[i].x));
+                if (KIND == 39) asm volatile("v_fma_f32 %0, %1, %2, %0\n v_cvt_f32_i32 %3, %3" : "+v"(a[i].x), "+v"(a[(i + 4) & 7].y) : "v"(b.x), "v"(c.x));
             }
         }
     }
@@ -104,5 +117,18 @@ int main()
     run<24>("v_sub_f32 + v_mul_f32 clamp (2 instr)", d);
     run<25>("v_perm_b32", d);
     run<26>("v_mad_u32_u24", d);
+    run<27>("v_dot2c_i32_i16", d);
+    run<28>("v_cvt_f32_u32", d);
+    run<29>("v_max3_f32 abs abs", d);
+    run<37>("v_max3_f32", d);
+    run<30>("s_nop 1 + v_mov_b32_dpp wave_shr:1", d);
+    run<31>("s_nop 1 + v_max_f32_dpp row_shr:1", d);
+    run<32>("v_readlane_b32", d);
+    run<33>("v_cvt_f32_i32_sdwa WORD_1 sext", d);
+    run<34>("v_cvt_pk_i16_i32", d);
+    run<35>("v_fmac_f32", d);
+    run<36>("v_fmac_f32 + v_sqrt_f32 (pair)", d);
+    run<39>("v_fma_f32 + v_cvt_f32_i32 (pair)", d);
+    run<38>("v_rndne_f32", d);
     return 0;
 }
