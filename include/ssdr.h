@@ -163,6 +163,11 @@ int ssdr_run_playbuffer(ssdr_ctx *ctx, const ssdr_play_chan *chans, int16_t *out
  * (2048 or 1213 = int(512 * SAMPLE_RATIO), the OutputStream blocksize of :1211). */
 #define SSDR_RATE_WIDE 20250
 int ssdr_set_kiwi_rate(ssdr_ctx *ctx, uint32_t kiwi_rate);
+/* audio_rec.recording_flag (utils_supersdr.py:149-157, 1139-1140): while set, ssdr_run_playbuffer also keeps what play_buffer
+ * appends to audio_rec.audio_buffer -- the interpolated block before the pan, pyaudio_buffer.astype(np.int16) -- and
+ * ssdr_playbuffer_mono returns it for the last run: int16 [n_ch][n_frames*L], L = ssdr_playbuffer_frame_len(). */
+int ssdr_set_recording(ssdr_ctx *ctx, int on);
+int ssdr_playbuffer_mono(ssdr_ctx *ctx, int16_t *mono_out, int out_is_device);
 int ssdr_playbuffer_frame_len(ssdr_ctx *ctx, uint32_t *samples_per_frame);
 
 /* -- display reductions on device-resident state
@@ -244,6 +249,9 @@ int ssdr_set_profiling(ssdr_ctx *ctx, int on);                  /* HIP-event pai
 int ssdr_set_concurrent(ssdr_ctx *ctx, int on);
 enum { SSDR_K_WF = 0, SSDR_K_AUDIO = 1, SSDR_K_SYNTH = 2, SSDR_K_DB2COL = 3, SSDR_K_PLAY = 4, SSDR_K_WIRE = 5, SSDR_K_TRACE = 6, SSDR_K_SMETER = 7, SSDR_K_COUNT = 8 };
 int ssdr_kernel_stats(ssdr_ctx *ctx, int which, float *total_ms, uint32_t *launches, int reset);
+/* channels per frame path of the audio stage (one kernel each, timed together as SSDR_K_AUDIO): counts[0] general
+ * (NCO -> FIR), counts[1] full-band lane shift, counts[2] full-band AM (no NCO, no FIR) */
+int ssdr_audio_paths(ssdr_ctx *ctx, uint32_t counts[3]);
 int ssdr_elapsed_ms(ssdr_ctx *ctx, float *ms);                  /* last run_* call, device time */
 
 /* -- synthetic input generated on the device (bench): makes a batch of

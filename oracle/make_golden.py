@@ -139,7 +139,8 @@ def gold_playbuffer(U):
         snd.mute_counter = 0
         snd.max_rssi_before_mute = -20
         snd.muting_delay = 15
-        snd.audio_rec = types.SimpleNamespace(recording_flag=False)
+        # the recording branch (:1139-1140) runs too: what audio_rec.audio_buffer collects is the mono block before the pan
+        snd.audio_rec = types.SimpleNamespace(recording_flag=True, audio_buffer=[])
         frames = (rng.standard_normal((4, 512)) * 9000).clip(-32768, 32767).astype(np.int16)
         frames[1, 100:110] = 32767                        # drives the truncating cast into wrap at volume 150
         outs = []
@@ -152,6 +153,7 @@ def gold_playbuffer(U):
         out["in_%d" % case] = frames
         out["cfg_%d" % case] = np.array([volume, balance], np.float64)
         out["out_%d" % case] = np.stack(outs)
+        out["rec_%d" % case] = np.stack(snd.audio_rec.audio_buffer)
         case += 1
     out["count"] = np.int64(case)
     out["n_tap"] = np.int64(U.filtering(6000, 48000).n_tap)
@@ -173,7 +175,7 @@ def gold_playbuffer(U):
         snd.mute_counter = 0
         snd.max_rssi_before_mute = -20
         snd.muting_delay = 15
-        snd.audio_rec = types.SimpleNamespace(recording_flag=False)
+        snd.audio_rec = types.SimpleNamespace(recording_flag=True, audio_buffer=[])
         frames = (rng.standard_normal((3, 512)) * 9000).clip(-32768, 32767).astype(np.int16)
         frames[1, 200:210] = 32767
         frames[2, 0], frames[2, -1] = -30000, 30000      # a steep line through the end points
@@ -188,6 +190,7 @@ def gold_playbuffer(U):
         out["rs_in_%d" % case] = frames
         out["rs_cfg_%d" % case] = np.array([volume, balance], np.float64)
         out["rs_out_%d" % case] = np.stack(outs)
+        out["rs_rec_%d" % case] = np.stack(snd.audio_rec.audio_buffer)
         case += 1
     out["rs_count"] = np.int64(case)
     out["rs_ratio"] = np.array([64, 27], np.int64)

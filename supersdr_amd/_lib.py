@@ -87,6 +87,8 @@ _SIGS = {
     "ssdr_run_smeter": (C.c_int, [_P, C.POINTER(SmeterChan), _P, C.c_double]),
     "ssdr_set_kiwi_rate": (C.c_int, [_P, C.c_uint32]),
     "ssdr_playbuffer_frame_len": (C.c_int, [_P, C.POINTER(C.c_uint32)]),
+    "ssdr_set_recording": (C.c_int, [_P, C.c_int]),
+    "ssdr_playbuffer_mono": (C.c_int, [_P, _P, C.c_int]),
     "ssdr_push_iq_wire": (C.c_int, [_P, _P, C.c_uint32, _P]),
     "ssdr_adpcm_decode": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "ssdr_feed_open": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
@@ -100,6 +102,7 @@ _SIGS = {
     "ssdr_set_profiling": (C.c_int, [_P, C.c_int]),
     "ssdr_set_concurrent": (C.c_int, [_P, C.c_int]),
     "ssdr_kernel_stats": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.c_int]),
+    "ssdr_audio_paths": (C.c_int, [_P, C.POINTER(C.c_uint32 * 3)]),
     "ssdr_elapsed_ms": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "ssdr_synth_iq": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "ssdr_read_input": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),

@@ -110,6 +110,10 @@ struct ssdr_ctx {
     uint32_t kiwi_rate = SSDR_RATE;         // kiwi_sound.KIWI_RATE: 12000, or 20250 (fractional SAMPLE_RATIO path)
     int16_t *d_play_out = nullptr;
     size_t play_frames = 0;
+    bool recording = false;                 // audio_rec.recording_flag: play_buffer also keeps the mono block (:1139-1140)
+    int16_t *d_play_mono = nullptr;
+    size_t play_mono_frames = 0;
+    uint32_t play_run_frames = 0, play_run_len = 0;
     uint8_t *d_wire = nullptr;
     size_t wire_frames = 0;
     float *d_wire_rssi = nullptr;
@@ -189,7 +193,7 @@ void ssdr_destroy(ssdr_ctx *c)
     void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_flags, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
                     c->d_play_taps, c->d_play_hist, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
-                    c->d_smeter_in, c->d_wire, c->d_wire_rssi};
+                    c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -677,6 +681,14 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
     return SSDR_OK;
 }
 
+int ssdr_audio_paths(ssdr_ctx *c, uint32_t counts[3])
+{
+    if (!c || !counts) return SSDR_EINVAL;
+    for (int p = 0; p < SSDR_PATH_COUNT; p++) counts[p] = 0;
+    for (uint32_t ch = 0; ch < c->n_ch; ch++) counts[ssdr_audio_path(c->h_consts[ch])]++;
+    return SSDR_OK;
+}
+
 int ssdr_audio_flags(ssdr_ctx *c, uint8_t *flags_out, int out_is_device)
 {
     if (!c || !flags_out) return SSDR_EINVAL;
@@ -1117,6 +1129,11 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
         HIP_TRY(hipMalloc(&c->d_play_out, (size_t)c->n_ch * nf * 2048 * 2 * sizeof(int16_t)));
         c->play_frames = nf;
     }
+    if (c->recording && c->play_mono_frames < nf) {
+        if (c->d_play_mono) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_play_mono)); c->d_play_mono = nullptr; c->play_mono_frames = 0; }
+        HIP_TRY(hipMalloc(&c->d_play_mono, (size_t)c->n_ch * nf * 2048 * sizeof(int16_t)));
+        c->play_mono_frames = nf;
+    }
     HIP_TRY(hipMemcpyAsync(c->d_play, chans, (size_t)c->n_ch * sizeof(ssdr_play_chan), hipMemcpyHostToDevice, c->stream));
     SsdrPlayArgs a;
     a.pcm = c->d_pcm;
@@ -1127,6 +1144,9 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
     a.hist = c->d_play_hist;
     a.out = c->d_play_out;
     a.rs_taps = c->d_play_rs_taps;
+    a.mono = c->recording ? c->d_play_mono : nullptr;
+    c->play_run_frames = c->recording ? nf : 0;
+    c->play_run_len = (uint32_t)per_frame;
     int rc;
     if ((rc = timed_begin(c)) != SSDR_OK) return rc;
     HIP_TRY(wide ? ssdr_launch_play_rs(a, c->stream) : ssdr_launch_play(a, c->stream));
@@ -1134,6 +1154,25 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
     if (out)
         HIP_TRY(hipMemcpyAsync(out, c->d_play_out, (size_t)c->n_ch * nf * per_frame * 2 * sizeof(int16_t),
                                out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_set_recording(ssdr_ctx *c, int on)
+{
+    if (!c) return SSDR_EINVAL;
+    c->recording = on != 0;
+    if (!c->recording) c->play_run_frames = 0;
+    return SSDR_OK;
+}
+
+int ssdr_playbuffer_mono(ssdr_ctx *c, int16_t *mono_out, int out_is_device)
+{
+    if (!c || !mono_out) return SSDR_EINVAL;
+    if (!c->d_play_mono || c->play_run_frames == 0) return SSDR_ESTATE;       // the last ssdr_run_playbuffer did not record
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(mono_out, c->d_play_mono, (size_t)c->n_ch * c->play_run_frames * c->play_run_len * sizeof(int16_t),
+                           out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
 }

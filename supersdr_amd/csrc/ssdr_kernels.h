@@ -88,6 +88,8 @@ struct SsdrPlayArgs {
     double *hist;                            // [n_ch][8] last 8 volume-scaled samples (the non-zero part of old_buffer)
     int16_t *out;                            // [n_ch][n_frames*2048][2]   (resampled path: [n_ch][n_frames*1213][2])
     const double *rs_taps;                   // resampled path: [64*21] polyphase taps (ssdr_resample_taps.h)
+    int16_t *mono;                           // [n_ch][n_frames*L] the block before the pan, truncated (the recording branch,
+                                             // utils_supersdr.py:1139-1140), or null
 };
 
 struct SsdrTraceArgs {

@@ -180,6 +180,7 @@ __global__ __launch_bounds__(64) void ssdr_play_kernel(SsdrPlayArgs a)
                 acc *= 4.0;
                 const int li = (int)(acc * l2), ri = (int)(acc * r2);    // trunc toward zero, then wrap to int16
                 dst[o4 + r] = ((uint32_t)li & 0xFFFFu) | ((uint32_t)ri << 16);
+                if (a.mono) a.mono[((uint64_t)ch * a.n_frames + f) * 2048 + i] = (int16_t)(int)acc;    // recording branch (:1139-1140)
             }
         }
         __syncthreads();
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(256) void ssdr_play_rs_kernel(SsdrPlayArgs a)
         }
         const int li = (int)(acc * l2), ri = (int)(acc * r2);            // trunc toward zero, then wrap to int16
         dst[k] = ((uint32_t)li & 0xFFFFu) | ((uint32_t)ri << 16);
+        if (a.mono) a.mono[((uint64_t)ch * a.n_frames + f) * SSDR_RS_OUT_PER_FRAME + k] = (int16_t)(int)acc;
     }
 }
 

@@ -242,6 +242,16 @@ class SsdrEngine:
         check(lib.ssdr_run_playbuffer(self._ctx, arr, out.ctypes.data if fetch else None, 0), "ssdr_run_playbuffer")
         return out
 
+    def set_recording(self, on):
+        """audio_rec.recording_flag: run_playbuffer also keeps the mono block play_buffer appends to audio_rec.audio_buffer"""
+        check(lib.ssdr_set_recording(self._ctx, int(bool(on))), "ssdr_set_recording")
+
+    def playbuffer_mono(self):
+        """-> int16 [n_ch, n_frames*L]: pyaudio_buffer.astype(np.int16) of the last run_playbuffer (utils_supersdr.py:1139-1140)"""
+        out = np.empty((self.n_ch, self.audio_frames * self.playbuffer_frame_len()), np.int16)
+        check(lib.ssdr_playbuffer_mono(self._ctx, out.ctypes.data, 0), "ssdr_playbuffer_mono")
+        return out
+
     def adpcm_decode(self, data, state=None):
         """data uint8 [n_streams, n_bytes]; state int32 [n_streams, 2] {index, prev} (updated in place)
         -> int16 [n_streams, 2*n_bytes].  IMA ADPCM of compressed SND / W-F payloads (kiwi/client.py:58-87)."""
@@ -287,6 +297,12 @@ class SsdrEngine:
         ms, n = C.c_float(0), C.c_uint32(0)
         check(lib.ssdr_kernel_stats(self._ctx, int(which), C.byref(ms), C.byref(n), int(reset)), "ssdr_kernel_stats")
         return ms.value, n.value
+
+    def audio_paths(self):
+        """-> (general, shift, AM-shift) channel counts of the audio stage's frame paths (one kernel each)"""
+        n = (C.c_uint32 * 3)()
+        check(lib.ssdr_audio_paths(self._ctx, C.byref(n)), "ssdr_audio_paths")
+        return tuple(int(x) for x in n)
 
     def elapsed_ms(self):
         ms = C.c_float(0)

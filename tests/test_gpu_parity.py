@@ -554,3 +554,68 @@ def test_million_channel_batch(S, twin):
     assert np.array_equal(pcm[sub], pcm_t) and np.array_equal(rssi[sub], rssi_t)
     assert (wf.max(axis=2) > 0).all()                       # every channel's line was written (a carrier is in every channel)
     assert (np.abs(pcm).max(axis=1) > 0).all() and np.isfinite(rssi).all()
+
+
+def _checksum(*arrays):
+    return tuple(int(np.asarray(a).astype(np.int64).sum()) if np.asarray(a).dtype.kind in "iu" else
+                 float(np.asarray(a).astype(np.float64).sum()) for a in arrays)
+
+
+def test_parity_at_the_timed_shape_waterfall_only(S, twin):
+    """bench.py --workload wf (BASELINE configs[1]) exactly as timed: 4096 channels x 256 lines in ONE launch, N = 1.
+    A strided subset of channels, all 256 lines, bit-exact vs the twin on the same bytes; run-to-run checksum."""
+    n_ch, n_lines = 4096, 256
+    sub = np.arange(0, n_ch, 131)[:24]
+    with S.SsdrEngine(n_ch) as eng:
+        ps = [S.default_params("am", f_shift_hz=((c * 37) % 97 - 48) * 100.0) for c in range(388)]
+        for first in range(0, n_ch, 388):
+            eng.set_params(first, ps[: min(388, n_ch - first)])
+        eng.synth_iq(2 * n_lines, seed=0x5D5D)
+        iq_sub = np.stack([eng.read_input(int(c), 1)[0] for c in sub])
+        n1 = eng.run_wf(fetch=False)
+        wf = eng.run_wf()                                   # the same launch again: N = 1 carries nothing
+        consts, _ = eng.get_consts()
+    assert n1 == n_lines and wf.shape == (n_lines, n_ch, 1024)
+    assert np.array_equal(wf[:, sub], twin.wf(iq_sub, 1, consts["wf_cal_lin"][sub]))
+    assert (wf.max(axis=2) > 150).all()                     # a carrier in every line of every channel
+    with S.SsdrEngine(n_ch) as eng:
+        for first in range(0, n_ch, 388):
+            eng.set_params(first, ps[: min(388, n_ch - first)])
+        eng.synth_iq(2 * n_lines, seed=0x5D5D)
+        assert _checksum(eng.run_wf()) == _checksum(wf)
+
+
+def test_parity_at_the_timed_shape_full_chain(S, twin):
+    """bench.py's default workload (BASELINE configs[2]) exactly as timed: 65536 channels x 16 superframes per launch,
+    N = 1, AM on the reference's full-band passband.  A strided subset bit-exact vs the twin (waterfall, PCM, RSSI,
+    flags, carried state after the launch), then a second step on the carried state, and a checksum of everything."""
+    n_ch, sf = 65536, 16
+    sub = np.arange(0, n_ch, 2039)[:32]
+    ps = [S.default_params("am", f_shift_hz=((c * 37) % 97 - 48) * 100.0) for c in range(388)]
+    with S.SsdrEngine(n_ch) as eng:
+        for first in range(0, n_ch, 388):
+            eng.set_params(first, ps[: min(388, n_ch - first)])
+        eng.reset_state()
+        eng.synth_iq(2 * sf, seed=0x5D5D)
+        assert eng.audio_paths() == (0, 0, n_ch)            # the path the bench times
+        iq_sub = np.stack([eng.read_input(int(c), 1)[0] for c in sub])
+        wf = eng.run_wf()
+        pcm, rssi = eng.run_audio()
+        flags = eng.audio_flags()
+        pcm2, rssi2 = eng.run_audio()                       # the bench's next step: same input, carried state
+        consts, taps = eng.get_consts()
+        st_g, hist_g = eng.get_state()
+    k, t = consts[sub], taps[sub]
+    assert wf.shape == (sf, n_ch, 1024) and np.array_equal(wf[:, sub], twin.wf(iq_sub, 1, k["wf_cal_lin"]))
+    st, hist = twinlib.fresh_state(k)
+    pcm_t, rssi_t, flags_t = twin.audio(iq_sub, k, t, st, hist, want_flags=True)
+    assert np.array_equal(pcm[sub], pcm_t) and np.array_equal(rssi[sub], rssi_t) and np.array_equal(flags[sub], flags_t)
+    pcm_t2, rssi_t2 = twin.audio(iq_sub, k, t, st, hist)
+    assert np.array_equal(pcm2[sub], pcm_t2) and np.array_equal(rssi2[sub], rssi_t2)
+    assert st_g[sub].tobytes() == st.tobytes() and np.array_equal(hist_g[sub], hist)
+    assert not flags.any() and (np.abs(pcm).max(axis=1) > 1000).all() and np.isfinite(rssi).all()
+    # vs the float64 definition on a few of them
+    ops = [O.ChanParams(mode="am", f_shift_hz=((int(c) * 37) % 97 - 48) * 100.0) for c in sub[:6]]
+    pcm_o, _ = O.audio_chain(iq_sub[:6], ops)
+    rms = np.sqrt(((pcm[sub[:6]].astype(np.float64) - pcm_o) ** 2).mean(axis=1)) / 32768.0
+    assert rms.max() < PCM_RMS_TOL

@@ -135,12 +135,21 @@ def test_play_buffer_matches_reference_golden(S):
     for c in range(n):
         for f in range(frames.shape[1]):
             assert np.array_equal(outs[f][c], g["out_%d" % c][f]), (c, f)
-    # and several frames in one call
+    # and several frames in one call, with the recording branch on (utils_supersdr.py:1139-1140): the stereo blocks are
+    # unchanged and the mono block is what the real play_buffer appended to audio_rec.audio_buffer
     with S.SsdrEngine(n) as eng:
         eng.set_pcm(frames.reshape(n, -1))
+        eng.run_playbuffer([PlayChan(100.0, 0.0)] * n, fetch=False)
+        with pytest.raises(S.SsdrError):
+            eng.playbuffer_mono()                       # not recording: nothing was kept
+    with S.SsdrEngine(n) as eng:
+        eng.set_pcm(frames.reshape(n, -1))
+        eng.set_recording(True)
         out = eng.run_playbuffer([PlayChan(*g["cfg_%d" % c]) for c in range(n)])
+        mono = eng.playbuffer_mono()
     for c in range(n):
         assert np.array_equal(out[c].reshape(4, 2048, 2), g["out_%d" % c])
+        assert np.array_equal(mono[c].reshape(4, 2048), g["rec_%d" % c])
 
 
 def test_play_buffer_random_vs_oracle(S):
@@ -178,10 +187,14 @@ def test_play_buffer_resampled_matches_reference_golden(S):
         eng.set_kiwi_rate(20250)
         assert eng.playbuffer_frame_len() == 1213
         eng.set_pcm(frames.reshape(n, -1))
+        eng.set_recording(True)
         out = eng.run_playbuffer([PlayChan(*g["rs_cfg_%d" % c]) for c in range(n)])
+        mono = eng.playbuffer_mono()
+        eng.set_recording(False)
         assert out.shape == (n, 3 * 1213, 2)
         for c in range(n):
             assert np.array_equal(out[c].reshape(3, 1213, 2), g["rs_out_%d" % c]), c
+            assert np.array_equal(mono[c].reshape(3, 1213), g["rs_rec_%d" % c]), c
         with pytest.raises(S.SsdrError):
             eng.set_kiwi_rate(44100)
         eng.set_kiwi_rate(12000)                                            # and back: the x4 path again

@@ -72,6 +72,7 @@ def test_play_buffer_matches_reference():
         for f in range(frames.shape[0]):
             out = pb(frames[f], volume=volume, balance=balance)
             assert np.array_equal(out, g["out_%d" % c][f]), (c, f)
+            assert np.array_equal(pb.rec, g["rec_%d" % c][f]), (c, f)          # the recording branch (:1139-1140)
 
 
 def test_play_buffer_resampled_matches_reference():
@@ -86,6 +87,7 @@ def test_play_buffer_resampled_matches_reference():
             out = pb(frames[f], volume=volume, balance=balance)
             assert out.shape == (1213, 2)
             assert np.array_equal(out, g["rs_out_%d" % c][f]), (c, f)
+            assert np.array_equal(pb.rec, g["rs_rec_%d" % c][f]), (c, f)
 
 
 def test_resample_tap_table_is_scipys():
