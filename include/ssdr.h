@@ -61,7 +61,7 @@ typedef struct ssdr_chan_params {
     int32_t agc_on;             /* kiwi_sound.on      (utils_supersdr.py:937)           */
     int32_t agc_hang;           /* kiwi_sound.hang    (:938)                            */
     int32_t reserved;
-    double f_shift_hz;          /* tuning offset inside the 12 kHz IQ band              */
+    double f_shift_hz;          /* tuning offset inside the 12 kHz IQ band: |f| <= 6000, else SSDR_EINVAL */
     double low_cut, high_cut;   /* passband Hz (kiwi_sound.lc/hc, :932; change_passband)*/
     double agc_thresh;          /* dBm  (:939, UI range -135..-20 supersdr.py:551-564)  */
     double agc_slope;           /* dB   (:940)                                          */

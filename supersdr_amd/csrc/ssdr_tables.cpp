@@ -105,6 +105,9 @@ int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, flo
 {
     if (!p || !c || !taps) return SSDR_EINVAL;
     if (p->mode < SSDR_MODE_AM || p->mode > SSDR_MODE_NBFM) return SSDR_EINVAL;
+    // the tuning offset must lie inside the IQ band: beyond +-RATE/2 the NCO step wraps mod 2^32 and the channel would
+    // silently demodulate an alias
+    if (!(std::fabs(p->f_shift_hz) <= SSDR_RATE / 2.0)) return SSDR_EINVAL;
     std::memset(c, 0, sizeof *c);
     double f_bc, fl;
     if (p->mode >= SSDR_MODE_LSB && p->mode <= SSDR_MODE_CW) {

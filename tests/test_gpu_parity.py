@@ -490,6 +490,50 @@ def test_workers_end_to_end_on_gpu(S, twin):
     hub.close()
 
 
+def test_hub_pipelined_feed_equals_the_synchronous_hub_and_flags_reach_the_seam(S):
+    """IQHub on ring buffers: pipeline=True (ssdr_feed_*: pinned slots, three streams) hands out the same lines and
+    frames as the synchronous hub, `depth - 1` superframes later; on the synchronous hub a clipped sample sets
+    kiwi_sound.adc_overflow_flag for exactly its frame (utils_supersdr.py:1066-1067)."""
+    from supersdr_amd.workers import IQHub, kiwi_waterfall, kiwi_sound
+    n_ch, n_sf = 3, 7
+    iq = O.synth_iq(n_ch, n_sf * 1024, seed=61)
+    iq[1, 2 * 1024 + 600, 1] = -32768                              # superframe 2, second audio frame, channel 1
+    ps, _ = mixed_params(S, n_ch)
+    hubs = [IQHub(n_ch, gpu_post=False), IQHub(n_ch, gpu_post=False, pipeline=True, depth=3)]
+    for h in hubs:
+        for c in range(n_ch):
+            h.set_params(c, ps[c])
+        for k in range(n_sf):
+            for c in range(n_ch):
+                h.feed(c, iq[c, k * 1024: k * 1024 + 300])
+                h.feed(c, iq[c, k * 1024 + 300: (k + 1) * 1024])
+    assert hubs[1].wf_queue[0].qsize() == n_sf - 2                 # two superframes still in flight
+    hubs[1].flush()
+    for c in range(n_ch):
+        for k in range(n_sf):
+            la, lb = hubs[0].wf_queue[c].get_nowait(), hubs[1].wf_queue[c].get_nowait()
+            assert np.array_equal(la[0], lb[0]) and la[1] == lb[1] == 1
+            for f in range(2):
+                fa, fb = hubs[0].snd_queue[c].get_nowait(), hubs[1].snd_queue[c].get_nowait()
+                assert np.array_equal(fa, fb) and fa.rssi == fb.rssi
+                assert fa.adc_overflow == (c == 1 and k == 2 and f == 1)
+    for h in hubs:
+        h.close()
+
+    class Disp:
+        DISPLAY_WIDTH, WF_HEIGHT = 1024, 8
+    hub = IQHub(1)
+    wf = kiwi_waterfall("gpu", 0, "", 10, 7100.0, None, Disp(), hub=hub, channel=0, timeout=1.0)
+    snd = kiwi_sound(7100.0, "AM", -6000, 6000, "", wf, 4)
+    hub.feed(0, iq[1, 2 * 1024: 3 * 1024])
+    flags = []
+    for f in range(2):
+        snd.process_audio_stream()
+        flags.append(snd.adc_overflow_flag)
+    assert flags == [False, True]
+    hub.close()
+
+
 def test_full_size_batch_properties(S, twin):
     """BASELINE configs[2]/[3] size (65536 channels, mixed modes, 10x binning): device-generated input,
     (i) a strided subset of channels bit-exact vs the twin on the same bytes, (ii) a channel's result does not

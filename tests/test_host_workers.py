@@ -62,8 +62,20 @@ class TwinEngine:
         return self.last_wf
 
     def run_audio(self):
-        self.pcm, rssi = self.twin.audio(self.iq, self.consts, self.taps, self.state, self.hist)
+        self.pcm, rssi, self.flags = self.twin.audio(self.iq, self.consts, self.taps, self.state, self.hist, want_flags=True)
         return self.pcm, rssi
+
+    def audio_flags(self):
+        return self.flags
+
+    def set_wf_lines(self, lines):
+        self.last_wf = np.array(lines, np.int16)
+
+    def set_recording(self, on):
+        self.recording = bool(on)
+
+    def playbuffer_mono(self):
+        return self.mono
 
     # the two post kernels, answered by the oracle's restatements of the reference
     def set_kiwi_rate(self, rate):
@@ -92,9 +104,11 @@ class TwinEngine:
         L = self.playbuffer_frame_len()
         nf = self.pcm.shape[1] // 512
         out = np.empty((self.n_ch, nf * L, 2), np.int16)
+        self.mono = np.empty((self.n_ch, nf * L), np.int16)
         for c, k in enumerate(chans):
             for f in range(nf):
                 out[c, f * L:(f + 1) * L] = self.players[c](self.pcm[c, f * 512:(f + 1) * 512], k.volume, k.balance)
+                self.mono[c, f * L:(f + 1) * L] = self.players[c].rec
         return out
 
     def close(self):
@@ -156,9 +170,11 @@ def test_waterfall_run_loop_binning_scroll_and_db2col_vs_reference_golden():
     # run loop with N = 3 time binning on the GPU side
     wf.zoom, wf.wf_auto_scaling, wf.delta_low_db, wf.delta_high_db = 8, True, 0, 0
     wf.averaging_n = 3
-    iq = O.synth_iq(1, 15 * 1024, seed=9)
+    iq = O.synth_iq(1, 16 * 1024, seed=9)
+    hub.feed(0, iq[0][:1024])                                  # a first line at the old N = 1: stale for an N = 3 client
     hub.set_averaging(3)
-    hub.feed(0, iq[0])
+    hub.feed(0, iq[0][1024:])
+    iq = iq[:, 1024:]
     lines = twinlib.load().wf(iq, 1)[:, 0].astype(np.float32)     # the byte lines the engine double produces
     for k in range(5):
         wf.step()
@@ -338,3 +354,182 @@ def test_kiwi_wav_reader_vs_reference_golden():
     assert [s[3] for s in stamps] == [42666667 * i for i in range(5)]
     with pytest.raises(ValueError):
         read_kiwi_iq_wav(b"RIFX" + bytes(40))
+
+
+# ------------------------------------------------------------------ round 2: hardening of the host shim
+def test_sound_run_pacing_late_drop_and_refill_cycle(monkeypatch):
+    """kiwi_sound.run (utils_supersdr.py:1150-1186) through a whole late / refill cycle on a scripted clock: frames on
+    time are queued; a stall longer than (FULL_BUFF_LEN + 2) frames sets late_flag, frames read while late are dropped
+    (with their 48 kHz blocks: nothing is left behind) and play_buffer plays silence; once the delay is worked off the
+    queue is refilled to FULL_BUFF_LEN and playback resumes."""
+    import supersdr_amd.ref_surface as RS
+    from supersdr_amd.workers import Frame
+    hub, wf, snd = make_pair(n_ch=1, channel=0)
+    clock = {"ns": 10 ** 12}
+    monkeypatch.setattr(RS.time, "time_ns", lambda: clock["ns"])
+    ms = 512 / 12000 * 1000
+    # (read duration in ms) per get_audio_chunk call: 8 on time, one 400 ms stall, then fast reads
+    script = [ms] * 8 + [400.0] + [1.0] * 40
+    log = []
+
+    def get_audio_chunk():
+        i = len(log)
+        if i >= len(script):
+            snd.terminate = True
+            return None
+        clock["ns"] += int(script[i] * 1e6)
+        while snd.audio_buffer.full() and not snd.late_flag:     # the PortAudio callback drains the queue while playing
+            snd.audio_buffer.get()
+        f = Frame.make(np.full(512, i, np.int16), -60.0, play_block=np.full((2048, 2), i, np.int16))
+        log.append((i, snd.late_flag, snd.audio_buffer.qsize()))
+        return f
+
+    snd.get_audio_chunk = get_audio_chunk
+    seen_late = []
+    orig_put = snd.audio_buffer.put
+    snd.audio_buffer.put = lambda x, *a, **k: (seen_late.append((int(x[0]), snd.late_flag)), orig_put(x, *a, **k))[1]
+    snd.run()
+    late_at = [i for i, late, _ in log if late]
+    assert late_at and late_at[0] == 9                            # the call after the 400 ms stall sees late_flag
+    assert snd.FULL_BUFF_LEN == 4 and 400.0 > (snd.FULL_BUFF_LEN + 2) * ms
+    queued = [i for i, _ in seen_late]
+    dropped = [i for i in range(len(script)) if i not in queued]
+    assert dropped and dropped[0] == 9 and dropped == list(range(9, 9 + len(dropped)))      # a contiguous run of dropped frames
+    # (400 - 42.7) ms of delay is worked off at (42.7 - 1) ms per dropped frame: 8 or 9 frames
+    assert 7 <= len(dropped) <= 10
+    assert not snd.late_flag                                      # refilled and reset (utils_supersdr.py:1183-1186)
+    assert all(q == snd.FULL_BUFF_LEN for i, late, q in log if late)    # nothing is consumed while late: the queue stays full
+    first_after = queued[queued.index(8) + 1]
+    assert first_after == dropped[-1] + 1                         # playback resumes with the frame after the dropped run
+    # while late the callback plays silence and consumes nothing
+    snd.late_flag = True
+    out = np.ones((2048, 2), np.int16)
+    n0 = snd.audio_buffer.qsize()
+    snd.play_buffer(out, 2048, None, None)
+    assert (out == 0).all() and snd.audio_buffer.qsize() == n0
+
+
+def test_adc_overflow_flag_drift_skip_and_recording_branch(tmp_path, monkeypatch):
+    """the SND header semantics at the seam: adc_overflow_flag follows the frame's flag (utils_supersdr.py:1066-1067), the
+    sample-rate drift rule reads and discards one frame (:1049-1052), and while audio_rec records, play_buffer appends
+    the mono block that the same GPU run produced (:1139-1140) -- written out as a 48 kHz mono WAV by stop()."""
+    import wave
+    hub, wf, snd = make_pair(n_ch=1, channel=0)
+    iq = O.synth_iq(1, 3 * 1024, seed=3)
+    iq[0, 1024 + 700, 0] = 32767                                  # frame 3 (second frame of superframe 1) clips
+    hub.feed(0, iq[0][:2048])
+    flags = []
+    for f in range(4):
+        snd.process_audio_stream()
+        flags.append(snd.adc_overflow_flag)
+    assert flags == [False, False, False, True]
+    # drift: delta_t = KIWI_RATE_TRUE - KIWI_RATE; after run_index frames the surplus reaches one frame -> skip one
+    hub.feed(0, iq[0][2048:])
+    snd.delta_t, snd.run_index = 12.0, 1001                       # 1001 * 12 * 512 / 12000 = 512.5 >= 512
+    a = snd.process_audio_stream()
+    assert snd.run_index == 0
+    twin = twinlib.load()
+    st, hist = twinlib.fresh_state(hub.engine.consts)
+    ref_pcm, _ = twin.audio(iq, hub.engine.consts, hub.engine.taps, st, hist)
+    assert np.array_equal(a, ref_pcm[0, 5 * 512:6 * 512])         # frame 4 was read and discarded
+    snd.delta_t = 0.0
+    # recording
+    monkeypatch.chdir(tmp_path)
+    hub2, wf2, snd2 = make_pair(n_ch=1, channel=0)
+    snd2.audio_rec.start()
+    assert snd2.audio_rec.recording_flag
+    hub2.feed(0, iq[0][:2048])
+    ref = O.PlayBuffer()
+    want = []
+    for f in range(4):
+        s = snd2.process_audio_stream()
+        snd2.audio_buffer.put(s)
+        out = np.zeros((2048, 2), np.int16)
+        snd2.play_buffer(out, 2048, None, None)
+        ref(s, volume=snd2.volume, balance=snd2.audio_balance)
+        want.append(ref.rec.copy())
+    assert len(snd2.audio_rec.audio_buffer) == 4
+    snd2.audio_rec.stop()
+    with wave.open(snd2.audio_rec.filename, "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 48000)
+        data = np.frombuffer(w.readframes(w.getnframes()), np.int16)
+    assert np.array_equal(data, np.concatenate(want))
+
+
+def test_unknown_mode_and_out_of_band_tuning_are_errors():
+    hub, wf, snd = make_pair(n_ch=1, channel=0)
+    n0 = len(hub.engine.param_log)
+    snd.radio_mode = "IQ"
+    with pytest.raises(ValueError, match="no demodulator"):
+        snd.set_mode_freq_pb()
+    snd.radio_mode = "AM"
+    snd.freq = wf.freq + 6.5                                       # 6.5 kHz from the centre of a 12 kHz band
+    with pytest.raises(ValueError, match="outside"):
+        snd.set_mode_freq_pb()
+    assert len(hub.engine.param_log) == n0                         # neither reached the engine: nothing aliased silently
+    snd.freq = wf.freq - 5.9
+    snd.set_mode_freq_pb()
+    assert hub.engine.param_log[-1][1].f_shift_hz == pytest.approx(-5900.0)
+    # the library refuses it too
+    import supersdr_amd as S
+    with pytest.raises(S.SsdrError):
+        S.compile_params(S.default_params("usb", f_shift_hz=6000.5))
+    # the true axis of the GPU waterfall: 12 kHz around the channel centre, whatever the zoom says
+    wf.set_freq_zoom(7100.0, 3)
+    assert wf.iq_bin_to_khz(512) == 7100.0 and wf.iq_bin_to_khz(0) == 7094.0 and wf.iq_khz_to_bin(7106.0) == 1024
+
+
+def test_two_waterfall_clients_with_different_averaging_do_not_disturb_each_other():
+    """averaging is per kiwi_waterfall (utils_supersdr.py:881-886).  Client 0 wants N = 1, client 1 wants
+    N = 3 on the same hub: the GPU then delivers single lines, client 1 takes the reference's mean of 3 of them and
+    gets its db2col from the GPU for the binned line; nobody's group is restarted, nobody spins."""
+    from supersdr_amd.workers import IQHub, kiwi_waterfall
+    hub = IQHub(2, engine=TwinEngine(2))
+    a = kiwi_waterfall("gpu", 0, "", 10, 7100.0, None, Disp(), hub=hub, channel=0, timeout=0.2)
+    b = kiwi_waterfall("gpu", 0, "", 10, 7100.0, None, Disp(), hub=hub, channel=1, timeout=0.2)
+    b.averaging_n = 3
+    iq = O.synth_iq(2, 6 * 1024, seed=12)
+    hub.set_averaging(1, 0)
+    hub.set_averaging(3, 1)
+    assert hub.averaging_n == 1                                    # they disagree: the GPU sums nothing
+    for k in range(6):
+        for c in range(2):
+            hub.feed(c, iq[c, k * 1024:(k + 1) * 1024])
+    lines = twinlib.load().wf(iq, 1).astype(np.float32)            # [6, 2, 1024]
+    for k in range(6):
+        a.step()
+        assert np.array_equal(a.spectrum, lines[k, 0])
+    for k in range(2):
+        b.step()
+        assert np.array_equal(b.spectrum, np.mean(list(lines[3 * k:3 * k + 3, 1]), axis=0))
+        col = O.spectrum_db2col(b.spectrum, b.zoom)[0]
+        assert np.array_equal(b.wf_color, col)
+    assert hub.averaging_n == 1
+    # when they agree the GPU does the summing
+    a.averaging_n = 3
+    hub.set_averaging(3, 0)
+    assert hub.averaging_n == 3
+
+
+def test_a_stalled_receiver_does_not_freeze_the_hub_and_backlogs_are_bounded():
+    """one receiver that stops feeding (reconnect sleeps of 5-15 s in GpuKiwiWorker) must not freeze the
+    others nor grow their buffers without bound: the hub runs once a healthy channel is 4 superframes ahead, the lagging
+    channel gets zero-filled superframes, and its samples resume in order when it comes back."""
+    from supersdr_amd.workers import IQHub
+    hub = IQHub(2, engine=TwinEngine(2), gpu_post=False)
+    iq = O.synth_iq(2, 12 * 1024, seed=14)
+    hub.feed(0, iq[0, :1024])
+    hub.feed(1, iq[1, :1024])
+    assert hub.superframes == 1
+    for k in range(1, 8):                                          # channel 1 goes quiet
+        hub.feed(0, iq[0, k * 1024:(k + 1) * 1024])
+    assert hub.superframes >= 4 and hub.stalled[1] == hub.superframes - 1 and hub.stalled[0] == 0
+    assert hub._wr[0] - hub._rd[0] <= 4 * 1024                    # backlog bounded by the stall threshold
+    got0 = np.concatenate([hub.snd_queue[0].get_nowait() for _ in range(2 * hub.superframes)])
+    st, hist = twinlib.fresh_state(hub.engine.consts[:1])
+    ref, _ = twinlib.load().audio(iq[:1, :hub.superframes * 1024], hub.engine.consts[:1], hub.engine.taps[:1], st, hist)
+    assert np.array_equal(got0, ref[0])                            # the healthy channel's audio is uninterrupted
+    # a burst far beyond the ring on a hub whose other channel stays silent: bounded memory, oldest dropped, counted
+    hub2 = IQHub(2, engine=TwinEngine(2), gpu_post=False, backlog_superframes=4, stall_superframes=100)
+    hub2.feed(0, iq[0])
+    assert hub2._ring.shape[1] == 4 * 1024 and hub2.dropped[0] == 8 * 1024 and hub2.superframes == 0
