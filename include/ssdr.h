@@ -266,6 +266,14 @@ int ssdr_compile_params(const ssdr_chan_params *p, ssdr_chan_consts *consts, flo
 int ssdr_get_consts(ssdr_ctx *ctx, uint32_t first, uint32_t count, ssdr_chan_consts *consts, float *taps);
 int ssdr_get_state(ssdr_ctx *ctx, uint32_t first, uint32_t count, ssdr_chan_state *state, int16_t *hist);
 int ssdr_set_state(ssdr_ctx *ctx, uint32_t first, uint32_t count, const ssdr_chan_state *state, const int16_t *hist);
+/* Checkpoint: everything a ctx carries from one call to the next -- compiled channel constants and taps, NCO phases, FIR
+ * history, DC / AGC / discriminator state, the waterfall's partial sums with their phase and N, the play_buffer
+ * history -- as one blob of ssdr_checkpoint_size bytes (host memory).  Loading it into a ctx of the same channel count
+ * (fresh or not) continues the streams bit for bit; the restored stream counts as live, so a later ssdr_set_params
+ * keeps its state. */
+int ssdr_checkpoint_size(ssdr_ctx *ctx, uint64_t *bytes);
+int ssdr_checkpoint_save(ssdr_ctx *ctx, void *blob);
+int ssdr_checkpoint_load(ssdr_ctx *ctx, const void *blob);
 /* inject results as if ssdr_run_wf / ssdr_run_audio had produced them (golden-vector tests of the post-processing) */
 int ssdr_set_wf_lines(ssdr_ctx *ctx, const int16_t *wf_sum /*[lines][n_ch][1024]*/, uint32_t lines);
 int ssdr_set_pcm(ssdr_ctx *ctx, const int16_t *pcm /*[n_ch][n_frames*512]*/, uint32_t n_frames);

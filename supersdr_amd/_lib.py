@@ -111,6 +111,9 @@ _SIGS = {
     "ssdr_get_consts": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
     "ssdr_get_state": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
     "ssdr_set_state": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
+    "ssdr_checkpoint_size": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "ssdr_checkpoint_save": (C.c_int, [_P, _P]),
+    "ssdr_checkpoint_load": (C.c_int, [_P, _P]),
     "ssdr_set_wf_lines": (C.c_int, [_P, _P, C.c_uint32]),
     "ssdr_set_pcm": (C.c_int, [_P, _P, C.c_uint32]),
     "ssdr_selftest_quantiser": (C.c_int, [_P, C.POINTER(C.c_uint64)]),

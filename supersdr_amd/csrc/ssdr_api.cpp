@@ -110,6 +110,7 @@ struct ssdr_ctx {
     uint32_t kiwi_rate = SSDR_RATE;         // kiwi_sound.KIWI_RATE: 12000, or 20250 (fractional SAMPLE_RATIO path)
     int16_t *d_play_out = nullptr;
     size_t play_frames = 0;
+    std::vector<double> pending_play_hist;  // ssdr_checkpoint_load before the first ssdr_run_playbuffer
     bool recording = false;                 // audio_rec.recording_flag: play_buffer also keeps the mono block (:1139-1140)
     int16_t *d_play_mono = nullptr;
     size_t play_mono_frames = 0;
@@ -896,6 +897,80 @@ int ssdr_set_state(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan_
     return SSDR_OK;
 }
 
+// ---- checkpoint: everything a stream carries from one call to the next, as one blob -------------------------
+// header | consts | taps | state | hist | waterfall partial sums | play_buffer history (zeros if never used)
+struct SsdrCkptHeader {
+    uint32_t magic, version, n_ch, n_avg, wf_phase, audio_started, kiwi_rate, has_play;
+    uint64_t synth_sample0;
+};
+static const uint32_t kCkptMagic = 0x52445353u;          // "SSDR"
+
+int ssdr_checkpoint_size(ssdr_ctx *c, uint64_t *bytes)
+{
+    if (!c || !bytes) return SSDR_EINVAL;
+    const uint64_t n = c->n_ch;
+    *bytes = sizeof(SsdrCkptHeader) + n * (sizeof(ssdr_chan_consts) + SSDR_NTAP_MAX * sizeof(float) + sizeof(ssdr_chan_state) +
+                                           SSDR_HIST * 4 + SSDR_NFFT * 2 + 8 * sizeof(double));
+    return SSDR_OK;
+}
+
+int ssdr_checkpoint_save(ssdr_ctx *c, void *blob)
+{
+    if (!c || !blob) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
+    const size_t n = c->n_ch;
+    SsdrCkptHeader h = {kCkptMagic, 1, c->n_ch, c->n_avg, c->wf_phase, c->audio_started ? 1u : 0u, c->kiwi_rate,
+                        c->d_play_hist ? 1u : 0u, c->synth_sample0};
+    char *p = static_cast<char *>(blob);
+    memcpy(p, &h, sizeof h); p += sizeof h;
+    const hipMemcpyKind d2h = hipMemcpyDeviceToHost;
+    HIP_TRY(hipMemcpyAsync(p, c->d_consts, n * sizeof(ssdr_chan_consts), d2h, c->stream)); p += n * sizeof(ssdr_chan_consts);
+    HIP_TRY(hipMemcpyAsync(p, c->d_taps, n * SSDR_NTAP_MAX * sizeof(float), d2h, c->stream)); p += n * SSDR_NTAP_MAX * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(p, c->d_state, n * sizeof(ssdr_chan_state), d2h, c->stream)); p += n * sizeof(ssdr_chan_state);
+    HIP_TRY(hipMemcpyAsync(p, c->d_hist, n * SSDR_HIST * 4, d2h, c->stream)); p += n * SSDR_HIST * 4;
+    HIP_TRY(hipMemcpyAsync(p, c->d_wf_acc[c->wf_acc_cur], n * SSDR_NFFT * 2, d2h, c->stream)); p += n * SSDR_NFFT * 2;
+    if (c->d_play_hist) HIP_TRY(hipMemcpyAsync(p, c->d_play_hist, n * 8 * sizeof(double), d2h, c->stream));
+    else memset(p, 0, n * 8 * sizeof(double));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob)
+{
+    if (!c || !blob) return SSDR_EINVAL;
+    SsdrCkptHeader h;
+    memcpy(&h, blob, sizeof h);
+    if (h.magic != kCkptMagic || h.version != 1 || h.n_ch != c->n_ch || h.n_avg < 1 || h.n_avg > 100 || h.wf_phase >= h.n_avg)
+        return SSDR_EINVAL;
+    if (!c->feed.empty()) return SSDR_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
+    const size_t n = c->n_ch;
+    const char *p = static_cast<const char *>(blob) + sizeof h;
+    const hipMemcpyKind h2d = hipMemcpyHostToDevice;
+    memcpy(c->h_consts.data(), p, n * sizeof(ssdr_chan_consts));
+    HIP_TRY(hipMemcpyAsync(c->d_consts, p, n * sizeof(ssdr_chan_consts), h2d, c->stream)); p += n * sizeof(ssdr_chan_consts);
+    HIP_TRY(hipMemcpyAsync(c->d_taps, p, n * SSDR_NTAP_MAX * sizeof(float), h2d, c->stream)); p += n * SSDR_NTAP_MAX * sizeof(float);
+    HIP_TRY(hipMemcpyAsync(c->d_state, p, n * sizeof(ssdr_chan_state), h2d, c->stream)); p += n * sizeof(ssdr_chan_state);
+    HIP_TRY(hipMemcpyAsync(c->d_hist, p, n * SSDR_HIST * 4, h2d, c->stream)); p += n * SSDR_HIST * 4;
+    HIP_TRY(hipMemcpyAsync(c->d_wf_acc[c->wf_acc_cur], p, n * SSDR_NFFT * 2, h2d, c->stream)); p += n * SSDR_NFFT * 2;
+    if (h.has_play && c->d_play_hist) HIP_TRY(hipMemcpyAsync(c->d_play_hist, p, n * 8 * sizeof(double), h2d, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->n_avg = h.n_avg;
+    c->wf_phase = h.wf_phase;
+    c->audio_started = h.audio_started != 0;
+    c->kiwi_rate = h.kiwi_rate;
+    c->synth_sample0 = h.synth_sample0;
+    c->chan_list_dirty = true;
+    c->pending_play_hist.clear();
+    if (h.has_play && !c->d_play_hist) {                    // play_buffer state arrives before its buffers exist: applied at first use
+        const double *q = reinterpret_cast<const double *>(p);
+        c->pending_play_hist.assign(q, q + n * 8);
+    }
+    return SSDR_OK;
+}
+
 int ssdr_selftest_quantiser(ssdr_ctx *c, uint64_t *mismatches)
 {
     if (!c || !mismatches) return SSDR_EINVAL;
@@ -1118,6 +1193,11 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
         HIP_TRY(hipMalloc(&c->d_play_hist, (size_t)c->n_ch * 8 * sizeof(double)));
         HIP_TRY(hipMalloc(&c->d_play_rs_taps, sizeof(SSDR_RS_TAPS)));
         HIP_TRY(hipMemsetAsync(c->d_play_hist, 0, (size_t)c->n_ch * 8 * sizeof(double), c->stream));   // old_buffer = zeros (:1005)
+        if (c->pending_play_hist.size() == (size_t)c->n_ch * 8) {
+            HIP_TRY(hipMemcpyAsync(c->d_play_hist, c->pending_play_hist.data(), (size_t)c->n_ch * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->pending_play_hist.clear();
+        }
         double h[64];
         if (ssdr_design_lowpass(SSDR_RATE / 2.0, 48000.0, 63, h) != 33) return SSDR_EINVAL;             // filtering(KIWI_RATE/2, AUDIO_RATE)
         HIP_TRY(hipMemcpyAsync(c->d_play_taps, h, 33 * sizeof(double), hipMemcpyHostToDevice, c->stream));

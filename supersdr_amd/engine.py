@@ -332,6 +332,18 @@ class SsdrEngine:
         hist = np.ascontiguousarray(hist, np.int16)
         check(lib.ssdr_set_state(self._ctx, int(first), len(state), state.ctypes.data, hist.ctypes.data), "ssdr_set_state")
 
+    def checkpoint(self):
+        """-> bytes: everything the streams carry between calls (ssdr_checkpoint_save)"""
+        n = C.c_uint64(0)
+        check(lib.ssdr_checkpoint_size(self._ctx, C.byref(n)), "ssdr_checkpoint_size")
+        buf = (C.c_char * n.value)()
+        check(lib.ssdr_checkpoint_save(self._ctx, buf), "ssdr_checkpoint_save")
+        return bytes(buf)
+
+    def restore(self, blob):
+        buf = (C.c_char * len(blob)).from_buffer_copy(blob)
+        check(lib.ssdr_checkpoint_load(self._ctx, buf), "ssdr_checkpoint_load")
+
     def selftest_sqrt(self):
         n = C.c_uint64(0)
         check(lib.ssdr_selftest_sqrt(self._ctx, C.byref(n)), "ssdr_selftest_sqrt")

@@ -663,3 +663,38 @@ def test_parity_at_the_timed_shape_full_chain(S, twin):
     pcm_o, _ = O.audio_chain(iq_sub[:6], ops)
     rms = np.sqrt(((pcm[sub[:6]].astype(np.float64) - pcm_o) ** 2).mean(axis=1)) / 32768.0
     assert rms.max() < PCM_RMS_TOL
+
+
+def test_checkpoint_restore_continues_bit_exactly(S):
+    """ssdr_checkpoint_save / _load: a fresh ctx restored from the blob continues every stream bit for bit --
+    NCO phases, FIR history, DC / AGC / discriminator memory, the waterfall's partial sums in the middle of an N = 3
+    group, the play_buffer history -- and a ssdr_set_params issued right after the restore does not wipe the state."""
+    from supersdr_amd._lib import PlayChan
+    n_ch, nf = 9, 4
+    iq = O.synth_iq(n_ch, 3 * nf * 512, seed=71)
+    ps, _ = mixed_params(S, n_ch)
+    play = [PlayChan(100.0 + 5 * c, (c % 3 - 1) * 0.5) for c in range(n_ch)]
+
+    def batch(eng, k):
+        eng.push_iq(iq[:, k * nf * 512:(k + 1) * nf * 512])
+        wf = eng.run_wf().copy()
+        pcm, rssi = eng.run_audio()
+        return wf, pcm.copy(), rssi.copy(), eng.run_playbuffer(play).copy()
+
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.set_averaging(3)                       # 2 lines per batch: groups straddle the batches
+        batch(eng, 0)
+        blob = eng.checkpoint()
+        want = [batch(eng, 1), batch(eng, 2)]
+    with S.SsdrEngine(n_ch) as eng:                # a brand-new ctx: default parameters, no play_buffer buffers yet
+        eng.restore(blob)
+        eng.set_params(3, [ps[3]])                 # "any set_params issued before the first run" must keep the restored state
+        got = [batch(eng, 1), batch(eng, 2)]
+    for k in range(2):
+        for a, b in zip(want[k], got[k]):
+            assert a.shape == b.shape and np.array_equal(a, b), k
+    assert want[0][0].shape[0] == 1 and want[1][0].shape[0] == 1    # 2 lines per batch, N = 3: a group closes in each of them
+    with S.SsdrEngine(n_ch + 1) as eng:
+        with pytest.raises(S.SsdrError):
+            eng.restore(blob)                      # channel count mismatch
