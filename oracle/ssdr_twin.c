@@ -152,6 +152,8 @@ float twin_log2p(float x) { return log2p(x); }
 float twin_exp2p(float x) { return exp2p(x); }
 float twin_atan2p(float y, float x) { return atan2p(y, x); }
 void twin_sincos20(uint32_t ph, float *c, float *s) { sincos20(ph, c, s); }
+static void phasor32(uint32_t ph, float *c, float *s);
+void twin_phasor32(uint32_t ph, float *c, float *s) { phasor32(ph, c, s); }
 
 /* ------------------------------------------------------------------ tables */
 /* Restates the table definitions (double libm, rounded once to float32). */
@@ -285,22 +287,30 @@ typedef struct {
     uint32_t pad[2];
 } twin_state;               /* 64 bytes */
 
-/* NCO step phasor cos/sin(2 pi dphi / 2^32): 20-bit evaluation + first-order term for the low 12 bits */
-static void step_phasor(uint32_t dphi, float *c, float *s)
+/* P(x) = cos/sin(2 pi x / 2^32) at all 32 bits of the phase: 20-bit evaluation + first-order term for the low 12 bits */
+static void phasor32(uint32_t ph, float *c, float *s)
 {
     const float C_2PI_32 = 0x1.921fb6p-30f;         /* float32(2*pi/2^32) */
     float c20, s20;
-    sincos20(dphi, &c20, &s20);
-    float eps = (float)(dphi & 0xFFFu) * C_2PI_32;
+    sincos20(ph, &c20, &s20);
+    float eps = (float)(ph & 0xFFFu) * C_2PI_32;
     *c = fmaf(-s20, eps, c20);
     *s = fmaf(c20, eps, s20);
 }
 
-/* block NCO: phasor of sample j of an 8-sample block = P20(block-start phase) * S^j */
-static void mix8(const int16_t *x /*[8][2]*/, uint32_t phase0, float cs, float ss, float *zr, float *zi)
+/* The NCO: the phasor of sample 8 b + j of a frame that starts at phase phi is P(phi) * P(8 b dphi) * S^j, S = P(dphi)
+ * -- the ideal oscillator in real arithmetic, three fp32 phasors multiplied here.  block_phasor = the first two. */
+static void block_phasor(uint32_t frame_phase, uint32_t dphi, int b /*0..63*/, float *c, float *s)
 {
-    float c, s;
-    sincos20(phase0, &c, &s);
+    float fc, fs, qc, qs;
+    phasor32(frame_phase, &fc, &fs);
+    phasor32((uint32_t)(8 * b) * dphi, &qc, &qs);
+    *c = fmaf(fc, qc, -(fs * qs));
+    *s = fmaf(fs, qc, fc * qs);
+}
+
+static void mix8(const int16_t *x /*[8][2]*/, float c, float s, float cs, float ss, float *zr, float *zi)
+{
     for (int j = 0; j < 8; j++) {
         float xr = (float)x[2 * j], xi = (float)x[2 * j + 1];
         zr[j] = fmaf(xr, c, xi * s);
@@ -333,13 +343,16 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
 {
     static _Thread_local float z1r[HIST + FRAME], z1i[HIST + FRAME];
     float z2r[FRAME], z2i[FRAME], p[FRAME], aud[FRAME];
-    /* 1. block NCO mix of history + frame (the history blocks are the last 16 blocks of the previous frame) */
+    /* 1. NCO mix of history + frame (the history blocks are blocks 48..63 of the previous frame, mixed as that frame did) */
     float cs1, ss1, cs2, ss2;
-    step_phasor(c->dphi1, &cs1, &ss1);
-    step_phasor(c->dphi2, &cs2, &ss2);
+    phasor32(c->dphi1, &cs1, &ss1);
+    phasor32(c->dphi2, &cs2, &ss2);
     for (int b = -HIST / 8; b < FRAME / 8; b++) {
         const int16_t *x = (b < 0) ? hist + 2 * (HIST + 8 * b) : iq + 2 * 8 * b;
-        mix8(x, st->phi1 + (uint32_t)(8 * b) * c->dphi1, cs1, ss1, z1r + HIST + 8 * b, z1i + HIST + 8 * b);
+        float bc, bs;
+        if (b < 0) block_phasor(st->phi1 - (uint32_t)FRAME * c->dphi1, c->dphi1, 64 + b, &bc, &bs);
+        else block_phasor(st->phi1, c->dphi1, b, &bc, &bs);
+        mix8(x, bc, bs, cs1, ss1, z1r + HIST + 8 * b, z1i + HIST + 8 * b);
     }
     /* 2. FIR, taps ascending, fma chain from zero */
     for (int n = 0; n < FRAME; n++) {
@@ -397,7 +410,7 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
     } else if (c->mode <= 3) {
         for (int b = 0; b < FRAME / 8; b++) {
             float co, si;
-            sincos20(st->phi2 + (uint32_t)(8 * b) * c->dphi2, &co, &si);
+            block_phasor(st->phi2, c->dphi2, b, &co, &si);
             for (int j = 0; j < 8; j++) {
                 int n = 8 * b + j;
                 aud[n] = fmaf(z2r[n], co, -(z2i[n] * si));

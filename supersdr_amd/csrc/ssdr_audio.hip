@@ -114,25 +114,49 @@ SSDR_DEV void scan_affine(float &A, float &B)
 #undef STEP
 }
 
-// cos/sin of 2 pi dphi / 2^32 for the per-channel NCO step: 20-bit table-free evaluation plus the
-// first-order term for the 12 bits below it (|eps| < 6e-6, eps^2/2 < 2e-11).
-SSDR_DEV void step_phasor(uint32_t dphi, float &c, float &s)
+// The NCO.  The phasor of sample n = 8 b + j of a frame that starts at phase phi is
+//     P(phi) * P(8 b dphi) * S^j,     P(x) = e^{j 2 pi x / 2^32} at all 32 bits (ssdr_phasor32), S = P(dphi):
+// mathematically the ideal oscillator e^{j 2 pi (phi + n dphi) / 2^32}; in fp32 a product of three phasors of
+// ~1e-7 error each.  P(8 b dphi) depends on the channel only: lane b keeps it for the whole call.  P(phi) is one value per
+// frame: lane i evaluates it for frame i of the call (64 frames per polynomial evaluation), the frame loop broadcasts it
+// with two v_readlane.  What is left per frame and lane: one complex multiply for the block phasor and a rotation per
+// sample -- no polynomial in the frame loop.
+struct Nco {
+    uint32_t dphi;
+    float cs, ss;               // S
+    float qc, qs;               // P(8 l dphi) of this lane
+    float tc, ts;               // lane i: P(phase of frame (f & ~63) + i)
+};
+SSDR_DEV void nco_setup(Nco &n, uint32_t dphi, int l)
 {
-    float c20, s20;
-    ssdr_sincos20(dphi, c20, s20);
-    const float eps = (float)(dphi & 0xFFFu) * SSDR_C_2PI_32;
-    c = fmaf(-s20, eps, c20);
-    s = fmaf(c20, eps, s20);
+    n.dphi = dphi;
+    ssdr_phasor32(dphi, n.cs, n.ss);
+    ssdr_phasor32((uint32_t)(8 * l) * dphi, n.qc, n.qs);
+    n.tc = 1.0f; n.ts = 0.0f;
+}
+SSDR_DEV void nco_frame_table(Nco &n, uint32_t phase_of_frame, int l)       // every 64 frames
+{
+    ssdr_phasor32(phase_of_frame + (uint32_t)(SSDR_FRAME * l) * n.dphi, n.tc, n.ts);
+}
+SSDR_DEV float lane_f(float x, uint32_t lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), (int)lane)); }
+// block phasor of this lane for frame f: (frame phasor) * (lane's block offset phasor)
+SSDR_DEV void nco_block(const Nco &n, uint32_t f, float &c, float &s)
+{
+    const float fc = lane_f(n.tc, f & 63u), fs = lane_f(n.ts, f & 63u);
+    c = fmaf(fc, n.qc, -(fs * n.qs));
+    s = fmaf(fs, n.qc, fc * n.qs);
+}
+SSDR_DEV void phasor_mul(float ac, float as, float bc, float bs, float &c, float &s)
+{
+    c = fmaf(ac, bc, -(as * bs));
+    s = fmaf(as, bc, ac * bs);
 }
 
-// Block NCO: the phasor of sample j of an 8-sample block is P20(phase of the block start) * S^j.
-// One polynomial sincos per 8 samples, a complex rotation (4 full-rate ops) for each of the others.
+// Mix eight samples with the block phasor (c, s) and the step S: x * conj(P S^j).
 // CLIP: amax = max(amax, |I|, |Q|) over the block (ADC-overflow detection on the samples as they arrive).
 template <bool CLIP>
-SSDR_DEV void mix8(const uint32_t (&rw)[8], uint32_t phase0, float cs, float ss, float2 (&z)[8], float &amax)
+SSDR_DEV void mix8(const uint32_t (&rw)[8], float c, float s, float cs, float ss, float2 (&z)[8], float &amax)
 {
-    float c, s;
-    ssdr_sincos20(phase0, c, s);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const float xr = (float)(int16_t)(rw[j] & 0xFFFFu);
@@ -208,11 +232,9 @@ SSDR_DEV void demod_am(const float (&p)[8], float &dc, float (&aud)[8])
     dc = lane63(m);
 }
 
-// SSB / CW product detector: Re{y * e^{+j phi2}}, block NCO as in mix8
-SSDR_DEV void demod_ssb(const float (&yr)[8], const float (&yi)[8], uint32_t phase0, float cs2, float ss2, float (&aud)[8])
+// SSB / CW product detector: Re{y * e^{+j phi2}}, the second NCO with the same structure as the first
+SSDR_DEV void demod_ssb(const float (&yr)[8], const float (&yi)[8], float c, float s, float cs2, float ss2, float (&aud)[8])
 {
-    float c, s;
-    ssdr_sincos20(phase0, c, s);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         aud[j] = fmaf(yr[j], c, -(yi[j] * s));       // Re{y * (c + j s)}
@@ -323,9 +345,10 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
     const uint32_t dphi1 = kc.dphi1, dphi2 = kc.dphi2;
     const AgcK agc = {kc.agc_c0, kc.agc_c1, kc.agc_knee, kc.agc_delta8, kc.hang_frames};
     const float cal = kc.smeter_cal_db;
-    float cs1, ss1, cs2, ss2;
-    step_phasor(dphi1, cs1, ss1);
-    step_phasor(dphi2, cs2, ss2);
+    Nco n1, n2;
+    nco_setup(n1, dphi1, l);
+    nco_setup(n2, dphi2, l);
+    const float cs1 = n1.cs, ss1 = n1.ss, cs2 = n2.cs, ss2 = n2.ss;
 
     ssdr_chan_state st = a.state[ch];
     uint32_t phi1 = st.phi1, phi2 = st.phi2;
@@ -351,8 +374,11 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
             const uint4 h0 = hp[0], h1 = hp[1];
             const uint32_t rw[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
             float2 H[8];
-            float unused = 0.0f;
-            mix8<false>(rw, phi1 - (uint32_t)(SSDR_HIST - 8 * l) * dphi1, cs1, ss1, H, unused);
+            float unused = 0.0f, fc, fs, qc, qs, bc, bs;
+            ssdr_phasor32(phi1 - (uint32_t)SSDR_FRAME * dphi1, fc, fs);                 // the previous frame's phasor
+            ssdr_phasor32((uint32_t)(8 * (64 - HOCT + l)) * dphi1, qc, qs);               // its block 48 + l
+            phasor_mul(fc, fs, qc, qs, bc, bs);
+            mix8<false>(rw, bc, bs, cs1, ss1, H, unused);
             store_oct(s_z, l, H);
         }
     } else {
@@ -362,8 +388,10 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
         const uint32_t rw[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
         if constexpr (PATH == PATH_DELAY4) {
             float2 H[8];
-            float unused = 0.0f;
-            mix8<false>(rw, phi1 - 8u * dphi1, cs1, ss1, H, unused);
+            float unused = 0.0f, fc, fs, bc, bs;
+            ssdr_phasor32(phi1 - (uint32_t)SSDR_FRAME * dphi1, fc, fs);                 // block 63 of the previous frame
+            phasor_mul(fc, fs, lane63(n1.qc), lane63(n1.qs), bc, bs);
+            mix8<false>(rw, bc, bs, cs1, ss1, H, unused);
 #pragma unroll
             for (int j = 0; j < 4; j++) tail_z[j] = H[4 + j];
         } else {
@@ -381,6 +409,10 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
     uint32_t flag_keep = 0;
 
     for (uint32_t f = 0; f < a.n_frames; f++, src += SSDR_FRAME, dst += SSDR_FRAME) {
+        if ((f & 63u) == 0) {                               // the next 64 frames' phasors, one per lane
+            if constexpr (PATH != PATH_AM_RAW) nco_frame_table(n1, phi1, l);
+            if constexpr (PATH != PATH_AM_RAW) if (mode >= SSDR_MODE_LSB && mode <= SSDR_MODE_CW) nco_frame_table(n2, phi2, l);
+        }
         raw0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src));
         raw1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src) + 1);
         const uint32_t rw[8] = {raw0.x, raw0.y, raw0.z, raw0.w, raw1.x, raw1.y, raw1.z, raw1.w};
@@ -408,7 +440,9 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
             float yr[8], yi[8];
             float amax = 0.0f;
             float2 A[8], B[8];
-            mix8<true>(rw, phi1 + (uint32_t)(8 * l) * dphi1, cs1, ss1, A, amax);
+            float bc, bs;
+            nco_block(n1, f, bc, bs);
+            mix8<true>(rw, bc, bs, cs1, ss1, A, amax);
             clip = wave_any(amax >= 32767.0f);
             if constexpr (PATH == PATH_DELAY4) {
                 // y[n] = z1[n - 4]: the previous lane's last four samples, then this lane's first four
@@ -457,7 +491,11 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
 #pragma unroll
             for (int j = 0; j < 8; j++) p[j] = fmaf(yr[j], yr[j], yi[j] * yi[j]);
             if (mode == SSDR_MODE_AM) demod_am<false>(p, dc, aud);
-            else if (mode <= SSDR_MODE_CW) demod_ssb(yr, yi, phi2 + (uint32_t)(8 * l) * dphi2, cs2, ss2, aud);
+            else if (mode <= SSDR_MODE_CW) {
+                float b2c, b2s;
+                nco_block(n2, f, b2c, b2s);
+                demod_ssb(yr, yi, b2c, b2s, cs2, ss2, aud);
+            }
             else demod_fm(yr, yi, prev_re, prev_im, aud);
             // the filter output is an fma chain that ends in "+ 0": a -0 can only come out of the shift path
             prev_re = lane63(yr[7]);
@@ -489,8 +527,10 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
             // the discriminator memory is the last filter output, y[511] = z1[507]: mix that one block of the last frame
             const uint32_t rw[8] = {raw0.x, raw0.y, raw0.z, raw0.w, raw1.x, raw1.y, raw1.z, raw1.w};
             float2 Z[8];
-            float unused = 0.0f;
-            mix8<false>(rw, phi1 - (uint32_t)SSDR_FRAME * dphi1 + (uint32_t)(8 * l) * dphi1, cs1, ss1, Z, unused);
+            float unused = 0.0f, fc, fs, bc, bs;
+            ssdr_phasor32(phi1 - (uint32_t)SSDR_FRAME * dphi1, fc, fs);                 // the last frame's phasor
+            phasor_mul(fc, fs, n1.qc, n1.qs, bc, bs);
+            mix8<false>(rw, bc, bs, cs1, ss1, Z, unused);
             prev_re = lane63(Z[3].x) + 0.0f;
             prev_im = lane63(Z[3].y) + 0.0f;
         }

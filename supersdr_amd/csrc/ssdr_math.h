@@ -33,6 +33,17 @@ SSDR_DEV void ssdr_sincos20(uint32_t phase, float &c_out, float &s_out)
     s_out = (k & 2u) ? -ss : ss;              // k=2,3 -> negative sin side
 }
 
+// cos/sin of 2 pi phase / 2^32 at the full 32 bits of the phase: the 20-bit evaluation above plus the first-order term
+// for the 12 bits below it (|eps| < 6e-6, eps^2/2 < 2e-11 -- under fp32 rounding).
+SSDR_DEV void ssdr_phasor32(uint32_t phase, float &c, float &s)
+{
+    float c20, s20;
+    ssdr_sincos20(phase, c20, s20);
+    const float eps = (float)(phase & 0xFFFu) * SSDR_C_2PI_32;
+    c = fmaf(-s20, eps, c20);
+    s = fmaf(c20, eps, s20);
+}
+
 // 1/d for d in [1, 2.42]: cubic seed (|rel err| < 5.5e-3) + two Newton steps (-> 1e-9, i.e. fp32 rounding is what is left).
 // Seven full-rate ops; an IEEE divide is ~15 instructions, several of them quarter-rate.  The twin states the same ops.
 SSDR_DEV float ssdr_rcp_1to2p42(float d)

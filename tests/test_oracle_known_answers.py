@@ -195,8 +195,12 @@ def test_twin_helpers_accuracy(twin):
     rng = np.random.default_rng(0)
     ph = rng.integers(0, 2 ** 32, 20000, dtype=np.uint64)
     cs = np.array([twin.sincos20(int(p)) for p in ph[:4000]])
-    ref = O.nco_phasor(ph[:4000])
+    p20 = (ph[:4000] >> np.uint64(12)).astype(np.float64)             # the 20-bit evaluation on its own grid ...
+    ref = np.exp(2j * np.pi * p20 / 2.0 ** 20)
     assert np.abs(cs[:, 0] - ref.real).max() < 2e-7 and np.abs(cs[:, 1] - ref.imag).max() < 2e-7
+    p32 = np.array([twin.phasor32(int(p)) for p in ph[:4000]])         # ... and the NCO's phasor at all 32 bits of the phase
+    ref = O.nco(0, 1, 0, 1)[0] * np.exp(2j * np.pi * ph[:4000].astype(np.float64) / 2.0 ** 32)
+    assert np.abs(p32[:, 0] - ref.real).max() < 2.5e-7 and np.abs(p32[:, 1] - ref.imag).max() < 2.5e-7
     x = np.exp(rng.uniform(-20, 45, 4000)).astype(np.float32)
     l2 = np.array([twin.lib.twin_log2p(float(v)) for v in x])
     assert np.abs(l2 - np.log2(x.astype(np.float64))).max() < 8e-6      # fp32 resolution at |log2| ~ 64

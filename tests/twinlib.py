@@ -34,6 +34,7 @@ class Twin:
         lib.twin_atan2p.argtypes = [C.c_float, C.c_float]
         lib.twin_atan2p.restype = C.c_float
         lib.twin_sincos20.argtypes = [C.c_uint32, P, P]
+        lib.twin_phasor32.argtypes = [C.c_uint32, P, P]
         self.win = np.empty(1024, np.float32)
         self.wr = np.empty(512, np.float32)
         self.wi = np.empty(512, np.float32)
@@ -63,6 +64,11 @@ class Twin:
         self.lib.twin_audio2(iq.ctypes.data, n_ch, n_frames, consts.ctypes.data, taps.ctypes.data,
                              state.ctypes.data, hist.ctypes.data, pcm.ctypes.data, rssi.ctypes.data, flags.ctypes.data)
         return (pcm, rssi, flags) if want_flags else (pcm, rssi)
+
+    def phasor32(self, ph):
+        c, s = C.c_float(), C.c_float()
+        self.lib.twin_phasor32(int(ph), C.byref(c), C.byref(s))
+        return c.value, s.value
 
     def sincos20(self, ph):
         c, s = C.c_float(), C.c_float()
