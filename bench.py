@@ -173,7 +173,7 @@ def spawn_ranks(gpus, argv):
 # one measurement
 # ---------------------------------------------------------------------------------------------------------------
 def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sframes, steps, warmup, spinup,
-            concurrent=0, host_feed=0):
+            concurrent=0, host_feed=0, hop=1024):
     """Spin the clocks up, W warm-up steps, then exactly `steps` timed steps between barrier + synchronize pairs.
     -> dict(value, ms_per_step, stages)."""
     _, _, n_avg, modes, do_wf, do_audio = WORKLOADS[workload]
@@ -184,6 +184,7 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     for first in range(0, channels, len(params)):
         eng.set_params(first, params[: min(len(params), channels - first)])
     eng.reset_state()
+    eng.set_hop(hop)
     eng.set_averaging(n_avg)
     eng.set_concurrent(concurrent)
     eng.synth_iq(n_frames, seed=0x5D5D, first_channel_id=rank * channels)    # resident in HBM from here on
@@ -254,9 +255,11 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     stages = {}
     if wf_n:
         avg = wf_ms / wf_n
-        b = channels * sframes * (4096.0 + 2048.0 / n_avg)
-        stages["wf"] = {"kernel": "ssdr_wf_kernel<%s>" % ("true" if n_avg > 1 else "false"), "avg_ms": avg, "launches": wf_n,
-                        "bytes": b, "GBps": b / avg / 1e6}
+        # per line: hop 1024 reads 4096 B, hop 512 reads 2048 new bytes (the other half-line was the previous line's); 2048/N out
+        lines = channels * sframes * (2 if hop == 512 else 1)
+        b = lines * ((2048.0 if hop == 512 else 4096.0) + 2048.0 / n_avg)
+        stages["wf"] = {"kernel": "ssdr_wf_kernel<%s, %s>" % ("true" if n_avg > 1 else "false", "true" if hop == 512 else "false"),
+                        "avg_ms": avg, "launches": wf_n, "bytes": b, "GBps": b / avg / 1e6, "lines_per_launch": lines}
     if au_n:
         avg = au_ms / au_n
         b = channels * n_frames * 3072.0
@@ -311,6 +314,8 @@ def main():
                     help="1: inputs come from (pinned) host memory (2: as SND wire bodies, unpacked on the device) and results go back to it through the pipelined feed "
                          "(ssdr_feed_*): the PCIe-inclusive rate of DESIGN.md, never the headline value")
     ap.add_argument("--concurrent", type=int, default=0, help="bit 0: audio stage on a second stream beside the waterfall kernel; bit 1: the audio stage's per-path kernels one after the other")
+    ap.add_argument("--hop", type=int, default=1024, choices=[512, 1024],
+                    help="samples between waterfall lines: 512 = 23.4 lines/s, the reference's waterfall rate (utils_supersdr.py:597)")
     ap.add_argument("--dry-run", action="store_true",
                     help="control flow only (ranks, rendezvous over gloo, channel blocks, JSON line), no GPU work: the CPU test of --gpus")
     args = ap.parse_args()
@@ -354,7 +359,7 @@ def main():
     from supersdr_amd import _lib as L
 
     m = measure(S, L, torch, rdv, rank, world, local_rank, args.workload, channels, sframes, args.steps, args.warmup,
-                args.spinup, args.concurrent, args.host_feed)
+                args.spinup, args.concurrent, args.host_feed, args.hop)
     stages = m["stages"]
     dom = max(stages, key=lambda k: stages[k]["avg_ms"])
     traffic, src = pmc_traffic(args.workload, channels, sframes)
@@ -365,7 +370,7 @@ def main():
         "higher_is_better": True, "scaling": "strong" if args.workload == "million" else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOAD_TEXT[args.workload],
-                   "channels_per_gpu": channels, "superframes_per_step": sframes, "averaging_n": n_avg,
+                   "channels_per_gpu": channels, "superframes_per_step": sframes, "averaging_n": n_avg, "wf_hop": args.hop,
                    "clock_spinup_s": args.spinup,
                    "input": "pinned host memory, pipelined H2D / kernels / D2H (PCIe-inclusive)" if args.host_feed else "resident in HBM",
                    "sharding": "channel blocks per GPU, no collectives", "rendezvous": rdv.backend if world > 1 else "none"},
@@ -376,7 +381,7 @@ def main():
             out[label] = roofline(stages[k], traffic.get(stages[k]["kernel"]), src)
     if "wf" in stages and "audio" in stages:
         # the chain as one unit (fused budget): the input counted once, 4096 + 2048/N + 2048 B per channel-superframe
-        b = channels * sframes * (4096.0 + 2048.0 / n_avg + 2048.0)
+        b = channels * sframes * (4096.0 + (2 if args.hop == 512 else 1) * 2048.0 / n_avg + 2048.0)
         ms = stages["wf"]["avg_ms"] + stages["audio"]["avg_ms"]
         out["roofline_chain"] = {"kernel": "waterfall + audio stage", "bound": "hbm", "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBPS,
                                  "unit": "GB/s", "frac": b / ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "avg_kernel_ms": ms,

@@ -114,6 +114,13 @@ int ssdr_reset_state(ssdr_ctx *ctx, uint32_t first, uint32_t count);
 /* kiwi_waterfall.averaging_n (utils_supersdr.py:616, 881-886; supersdr.py:376-385), 1..100 */
 int ssdr_set_averaging(ssdr_ctx *ctx, uint32_t n);
 
+/* Waterfall line rate.  hop = 1024 (default): one line per 1024 samples, 11.72 lines/s.  hop = 512: lines overlap by half,
+ * 23.44 lines/s -- the rate the reference's waterfall runs at (kiwi_waterfall.MAX_FPS = 23, "SET wf_speed=4",
+ * utils_supersdr.py:597, 742).  Line k then covers the 512 samples before frame k and frame k itself; ssdr_run_wf
+ * accepts any frame count and delivers one line per frame; the half-line before the first frame is carried from the
+ * previous batch (silence after ssdr_create / ssdr_set_hop).  A change restarts the averaging group. */
+int ssdr_set_hop(ssdr_ctx *ctx, uint32_t hop);
+
 /* -- data plane.  ssdr_push_iq is the IQ ingest hook: KiwiSDRStream._process_iq_samples
  *    (kiwi/client.py:493-494).  iq may be a host pointer (copied) or a device pointer
  *    (referenced, must stay valid until the run_* calls on it have completed). */

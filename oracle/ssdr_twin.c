@@ -265,6 +265,19 @@ void twin_wf(const int16_t *iq, uint32_t n_ch, uint32_t n_lines, uint32_t n_avg,
     }
 }
 
+/* overlapping lines: line k of channel c covers samples [k*hop, k*hop + 1024) of that channel's stream
+ * iq[n_ch][(n_lines-1)*hop + 1024][2]  ->  bytes[n_lines][n_ch][1024]  (hop 512: 23.4 lines/s, the reference's MAX_FPS = 23,
+ * utils_supersdr.py:597; hop 1024 is twin_wf's framing) */
+void twin_wf_lines(const int16_t *iq, uint32_t n_ch, uint32_t n_lines, uint32_t hop, const float *cal_lin /*[n_ch]*/,
+                   const float *win, const float *wr, const float *wi, const float *thr, uint8_t *out)
+{
+    const size_t per_ch = (size_t)(n_lines - 1) * hop + NFFT;
+    for (uint32_t c = 0; c < n_ch; c++)
+        for (uint32_t k = 0; k < n_lines; k++)
+            twin_wf_line(iq + (c * per_ch + (size_t)k * hop) * 2, win, wr, wi, thr, cal_lin[c],
+                         out + ((size_t)k * n_ch + c) * NFFT);
+}
+
 /* ------------------------------------------------------------------- audio */
 typedef struct {            /* per-channel kernel constants; same layout as the product's */
     uint32_t mode;          /* 0 am, 1 lsb, 2 usb, 3 cw, 4 nbfm */

@@ -73,6 +73,7 @@ _SIGS = {
     "ssdr_default_params": (C.c_int, [C.c_int, C.POINTER(ChanParams)]),
     "ssdr_reset_state": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "ssdr_set_averaging": (C.c_int, [_P, C.c_uint32]),
+    "ssdr_set_hop": (C.c_int, [_P, C.c_uint32]),
     "ssdr_push_iq": (C.c_int, [_P, _P, C.c_uint32, C.c_int]),
     "ssdr_run_wf": (C.c_int, [_P, _P, C.POINTER(C.c_uint32), C.c_int]),
     "ssdr_run_audio": (C.c_int, [_P, _P, _P, C.c_int]),

@@ -24,6 +24,8 @@ struct ssdr_ctx {
     int device = 0;
     uint32_t n_ch = 0;
     uint32_t n_avg = 1, wf_phase = 0;
+    uint32_t hop = SSDR_NFFT;                           // samples between waterfall lines: 1024, or 512 (lines overlap by half)
+    uint32_t *d_wf_tail = nullptr;                      // hop 512: [n_ch][512] the last half-line of the previous batch
     hipStream_t own_stream = nullptr, stream = nullptr;
     hipStream_t stream2 = nullptr;                      // audio kernel when running concurrently with the waterfall
     hipEvent_t ev_in = nullptr, ev_a = nullptr;
@@ -191,7 +193,7 @@ void ssdr_destroy(ssdr_ctx *c)
     (void)hipSetDevice(c->device);
     (void)ssdr_feed_close(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_wf_acc[0], c->d_wf_acc[1],
+    void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_wf_tail, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_flags, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
                     c->d_play_taps, c->d_play_hist, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
                     c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono};
@@ -405,6 +407,22 @@ int ssdr_set_averaging(ssdr_ctx *c, uint32_t n)
     return SSDR_OK;
 }
 
+int ssdr_set_hop(ssdr_ctx *c, uint32_t hop)
+{
+    if (!c || (hop != SSDR_NFFT && hop != SSDR_NFFT / 2)) return SSDR_EINVAL;
+    if (!c->feed.empty()) return SSDR_ESTATE;                 // the feed's slots are sized for the hop they were opened with
+    if (hop == c->hop) return SSDR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (hop == SSDR_NFFT / 2) {
+        if (!c->d_wf_tail) HIP_TRY(hipMalloc(&c->d_wf_tail, (size_t)c->n_ch * (SSDR_NFFT / 2) * 4));
+        HIP_TRY(hipMemsetAsync(c->d_wf_tail, 0, (size_t)c->n_ch * (SSDR_NFFT / 2) * 4, c->stream));   // silence before the stream
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    c->hop = hop;
+    c->wf_phase = 0;                                          // a change of framing restarts the averaging group
+    return SSDR_OK;
+}
+
 int ssdr_set_stream(ssdr_ctx *c, void *hip_stream)
 {
     if (!c) return SSDR_EINVAL;
@@ -541,9 +559,10 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
 {
     if (!c) return SSDR_EINVAL;
     if (!c->have_input) return SSDR_ESTATE;
-    if (c->in_frames & 1u) return SSDR_EINVAL;
+    const bool hop512 = c->hop == SSDR_NFFT / 2;
+    if (!hop512 && (c->in_frames & 1u)) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
-    const uint32_t n_lines = c->in_frames / 2;
+    const uint32_t n_lines = hop512 ? c->in_frames : c->in_frames / 2;
     const uint32_t total = c->wf_phase + n_lines;
     const uint32_t n_out = total / c->n_avg;
     const uint32_t n_groups = (total + c->n_avg - 1) / c->n_avg;
@@ -557,6 +576,7 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
     a.ch_stride = (uint64_t)c->in_frames * SSDR_FRAME;
     a.n_ch = c->n_ch;
     a.n_lines = n_lines;
+    a.tail = hop512 ? c->d_wf_tail : nullptr;
     a.n_avg = c->n_avg;
     a.phase = c->wf_phase;
     a.n_groups = n_groups;
@@ -575,6 +595,9 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
     if ((rc = timed_begin(c)) != SSDR_OK) return rc;
     HIP_TRY(ssdr_launch_wf(a, grid ? grid : 1, c->stream));
     if ((rc = timed_end(c, SSDR_K_WF)) != SSDR_OK) return rc;
+    if (hop512)                  // the batch's last half-line is the next batch's first: [n_ch] rows of 2 KB out of the input
+        HIP_TRY(hipMemcpy2DAsync(c->d_wf_tail, (SSDR_NFFT / 2) * 4, c->d_iq + (size_t)(c->in_frames - 1) * SSDR_FRAME,
+                                 (size_t)c->in_frames * SSDR_FRAME * 4, (SSDR_NFFT / 2) * 4, c->n_ch, hipMemcpyDeviceToDevice, c->stream));
     c->wf_phase = total % c->n_avg;
     if (c->wf_phase) c->wf_acc_cur ^= 1;             // a partial group was written to acc_out
     c->wf_lines_ready = n_out;
@@ -739,7 +762,7 @@ int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth, uint32_t flag
     const size_t wire_b = (size_t)c->n_ch * n_frames * SSDR_WIRE_BODY;
     const bool wire = (flags & SSDR_FEED_WIRE) != 0;
     c->feed_wire = wire;
-    const size_t wf_b = (size_t)(n_frames / 2) * c->n_ch * SSDR_NFFT * 2;
+    const size_t wf_b = (size_t)(c->hop == SSDR_NFFT / 2 ? n_frames : n_frames / 2) * c->n_ch * SSDR_NFFT * 2;
     const size_t pcm_b = (size_t)c->n_ch * n_frames * SSDR_FRAME * 2;
     const size_t rssi_b = (size_t)c->n_ch * n_frames * sizeof(float);
     c->feed.resize(depth);
@@ -806,7 +829,7 @@ int ssdr_feed_submit(ssdr_ctx *c)
     int16_t *k_wf = c->d_wf_out; const size_t k_wf_lines = c->wf_out_lines; const uint32_t k_ready = c->wf_lines_ready;
     int16_t *k_pcm = c->d_pcm; float *k_rssi = c->d_rssi; const size_t k_af = c->audio_frames; const uint32_t k_arf = c->audio_run_frames;
     c->d_iq = s.d_in; c->in_frames = nf; c->have_input = true;
-    c->d_wf_out = s.d_wf; c->wf_out_lines = nf / 2;
+    c->d_wf_out = s.d_wf; c->wf_out_lines = c->hop == SSDR_NFFT / 2 ? nf : nf / 2;
     c->d_pcm = s.d_pcm; c->d_rssi = s.d_rssi; c->audio_frames = nf;
     uint32_t lines = 0;
     int rc = ssdr_run_wf(c, nullptr, &lines, 0);
@@ -902,6 +925,7 @@ int ssdr_set_state(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan_
 struct SsdrCkptHeader {
     uint32_t magic, version, n_ch, n_avg, wf_phase, audio_started, kiwi_rate, has_play;
     uint64_t synth_sample0;
+    uint32_t hop, pad;
 };
 static const uint32_t kCkptMagic = 0x52445353u;          // "SSDR"
 
@@ -910,7 +934,7 @@ int ssdr_checkpoint_size(ssdr_ctx *c, uint64_t *bytes)
     if (!c || !bytes) return SSDR_EINVAL;
     const uint64_t n = c->n_ch;
     *bytes = sizeof(SsdrCkptHeader) + n * (sizeof(ssdr_chan_consts) + SSDR_NTAP_MAX * sizeof(float) + sizeof(ssdr_chan_state) +
-                                           SSDR_HIST * 4 + SSDR_NFFT * 2 + 8 * sizeof(double));
+                                           SSDR_HIST * 4 + SSDR_NFFT * 2 + 8 * sizeof(double) + (SSDR_NFFT / 2) * 4);
     return SSDR_OK;
 }
 
@@ -920,8 +944,8 @@ int ssdr_checkpoint_save(ssdr_ctx *c, void *blob)
     HIP_TRY(hipSetDevice(c->device));
     { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     const size_t n = c->n_ch;
-    SsdrCkptHeader h = {kCkptMagic, 1, c->n_ch, c->n_avg, c->wf_phase, c->audio_started ? 1u : 0u, c->kiwi_rate,
-                        c->d_play_hist ? 1u : 0u, c->synth_sample0};
+    SsdrCkptHeader h = {kCkptMagic, 2, c->n_ch, c->n_avg, c->wf_phase, c->audio_started ? 1u : 0u, c->kiwi_rate,
+                        c->d_play_hist ? 1u : 0u, c->synth_sample0, c->hop, 0u};
     char *p = static_cast<char *>(blob);
     memcpy(p, &h, sizeof h); p += sizeof h;
     const hipMemcpyKind d2h = hipMemcpyDeviceToHost;
@@ -932,6 +956,9 @@ int ssdr_checkpoint_save(ssdr_ctx *c, void *blob)
     HIP_TRY(hipMemcpyAsync(p, c->d_wf_acc[c->wf_acc_cur], n * SSDR_NFFT * 2, d2h, c->stream)); p += n * SSDR_NFFT * 2;
     if (c->d_play_hist) HIP_TRY(hipMemcpyAsync(p, c->d_play_hist, n * 8 * sizeof(double), d2h, c->stream));
     else memset(p, 0, n * 8 * sizeof(double));
+    p += n * 8 * sizeof(double);
+    if (c->hop == SSDR_NFFT / 2) HIP_TRY(hipMemcpyAsync(p, c->d_wf_tail, n * (SSDR_NFFT / 2) * 4, d2h, c->stream));
+    else memset(p, 0, n * (SSDR_NFFT / 2) * 4);
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
 }
@@ -941,10 +968,12 @@ int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob)
     if (!c || !blob) return SSDR_EINVAL;
     SsdrCkptHeader h;
     memcpy(&h, blob, sizeof h);
-    if (h.magic != kCkptMagic || h.version != 1 || h.n_ch != c->n_ch || h.n_avg < 1 || h.n_avg > 100 || h.wf_phase >= h.n_avg)
+    if (h.magic != kCkptMagic || h.version != 2 || h.n_ch != c->n_ch || h.n_avg < 1 || h.n_avg > 100 || h.wf_phase >= h.n_avg ||
+        (h.hop != SSDR_NFFT && h.hop != SSDR_NFFT / 2))
         return SSDR_EINVAL;
     if (!c->feed.empty()) return SSDR_ESTATE;
     HIP_TRY(hipSetDevice(c->device));
+    { int rch = ssdr_set_hop(c, h.hop); if (rch != SSDR_OK) return rch; }
     { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     const size_t n = c->n_ch;
     const char *p = static_cast<const char *>(blob) + sizeof h;
@@ -956,6 +985,8 @@ int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob)
     HIP_TRY(hipMemcpyAsync(c->d_hist, p, n * SSDR_HIST * 4, h2d, c->stream)); p += n * SSDR_HIST * 4;
     HIP_TRY(hipMemcpyAsync(c->d_wf_acc[c->wf_acc_cur], p, n * SSDR_NFFT * 2, h2d, c->stream)); p += n * SSDR_NFFT * 2;
     if (h.has_play && c->d_play_hist) HIP_TRY(hipMemcpyAsync(c->d_play_hist, p, n * 8 * sizeof(double), h2d, c->stream));
+    if (h.hop == SSDR_NFFT / 2)
+        HIP_TRY(hipMemcpyAsync(c->d_wf_tail, p + n * 8 * sizeof(double), n * (SSDR_NFFT / 2) * 4, h2d, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_avg = h.n_avg;
     c->wf_phase = h.wf_phase;

@@ -24,6 +24,10 @@
 #include "ssdr_math.h"
 #include "ssdr_kernels.h"
 
+#ifndef SSDR_AUDIO_PREFETCH
+#define SSDR_AUDIO_PREFETCH 0
+#endif
+
 namespace {
 
 constexpr int OCT = 10;                         // LDS slots (float2) per 8 samples: 8 + 2 pad
@@ -405,6 +409,13 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
     float *rssi_row = a.rssi + (uint64_t)ch * a.n_frames;
     uint8_t *flag_row = a.flags + (uint64_t)ch * a.n_frames;
     u32x4 raw0, raw1;
+#if SSDR_AUDIO_PREFETCH
+    u32x4 nxt0 = {0, 0, 0, 0}, nxt1 = {0, 0, 0, 0};
+    if (a.n_frames) {
+        nxt0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src));
+        nxt1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src) + 1);
+    }
+#endif
     float rssi_sum = 0.0f;
     uint32_t flag_keep = 0;
 
@@ -413,8 +424,18 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
             if constexpr (PATH != PATH_AM_RAW) nco_frame_table(n1, phi1, l);
             if constexpr (PATH != PATH_AM_RAW) if (mode >= SSDR_MODE_LSB && mode <= SSDR_MODE_CW) nco_frame_table(n2, phi2, l);
         }
+#if SSDR_AUDIO_PREFETCH
+        // the next frame's 2 KB are requested before this frame's arithmetic starts: their HBM latency hides under it
+        raw0 = nxt0;
+        raw1 = nxt1;
+        if (f + 1 < a.n_frames) {
+            nxt0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + SSDR_FRAME));
+            nxt1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + SSDR_FRAME) + 1);
+        }
+#else
         raw0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src));
         raw1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src) + 1);
+#endif
         const uint32_t rw[8] = {raw0.x, raw0.y, raw0.z, raw0.w, raw1.x, raw1.y, raw1.z, raw1.w};
         float p[8], aud[8];
         bool clip;

@@ -28,7 +28,8 @@
 struct SsdrWfArgs {
     const uint32_t *iq;                      // [n_ch][ch_stride] dwords, each = I | Q << 16
     uint64_t ch_stride;                      // dwords between channels
-    uint32_t n_ch, n_lines;                  // lines (1024 samples) in this batch
+    uint32_t n_ch, n_lines;                  // lines in this batch (one per 1024 samples; with `tail` one per 512)
+    const uint32_t *tail;                    // hop 512: [n_ch][512] the half-line before the batch (null: hop 1024)
     uint32_t n_avg, phase;                   // averaging N; lines already summed in `acc`
     uint32_t n_groups;                       // averaging groups touched by this batch
     int16_t *out;                            // [n_complete_groups][n_ch][1024]

@@ -209,6 +209,16 @@ SSDR_DEV void load_line(const uint32_t *__restrict__ src /* + lane */, uint32_t 
 #pragma unroll
     for (int r = 0; r < 32; r++) raw[r] = __builtin_nontemporal_load(src + 32 * r);
 }
+// hop 512: a line is the previous half-line followed by a new one.  The older half is the neighbouring line's newer
+// half: the wave next door (work items of a channel pair are adjacent, see wf_item) loads it at about the same time, so
+// one of the two reads is served by the L2 -- plain loads, not non-temporal ones.
+SSDR_DEV void load_line_halves(const uint32_t *__restrict__ older, const uint32_t *__restrict__ newer, uint32_t (&raw)[32])
+{
+#pragma unroll
+    for (int r = 0; r < 16; r++) raw[r] = older[32 * r];
+#pragma unroll
+    for (int r = 0; r < 16; r++) raw[16 + r] = newer[32 * r];
+}
 
 // raw int16 IQ dwords of one line -> windowed complex samples in a-index (bit-reversed) order.
 // The window is symmetric, w[n] = w[1024-n]: samples of the second half read the same 513-entry table
@@ -326,11 +336,18 @@ struct WfItem {                 // one (channel pair, averaging group) work item
     bool ch_ok, carry_in, complete;
 };
 
+template <bool HOP>
 SSDR_DEV WfItem wf_item(const SsdrWfArgs &a, uint32_t item, uint32_t n_pairs, int h)
 {
     WfItem it;
-    it.grp = item / n_pairs;
-    const uint32_t pair = item - it.grp * n_pairs;
+    uint32_t pair;
+    if (HOP) {                      // groups of a channel pair side by side: neighbouring waves share a half-line
+        pair = item / a.n_groups;
+        it.grp = item - pair * a.n_groups;
+    } else {
+        it.grp = item / n_pairs;
+        pair = item - it.grp * n_pairs;
+    }
     const uint32_t ch_raw = 2 * pair + h;
     it.ch_ok = ch_raw < a.n_ch;
     it.ch = it.ch_ok ? ch_raw : a.n_ch - 1;
@@ -355,7 +372,9 @@ SSDR_DEV void load_tables(unsigned char *smem, const float *win, const float2 *t
 }
 
 // AVG == false: averaging N == 1, every line is an output line (no accumulators at all).
-template <bool AVG>
+// HOP == true: lines overlap by half (hop 512 samples = 23.4 lines/s, the reference's waterfall rate, utils_supersdr.py:597):
+// line k of the batch covers half-lines k-1 and k, half-line -1 being the tail the previous call left behind.
+template <bool AVG, bool HOP>
 __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_kernel(SsdrWfArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];     // the kernel's only LDS object: address 0
@@ -371,21 +390,23 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
     const uint32_t wave_stride = gridDim.x * WAVES;
 
     for (uint32_t item = blockIdx.x * WAVES + wave; item < n_items; item += wave_stride) {
-        const WfItem it = wf_item(a, item, n_pairs, h);
+        const WfItem it = wf_item<HOP>(a, item, n_pairs, h);
         const float cal = a.consts[it.ch].wf_cal_lin;
         uint32_t acc[AVG ? 16 : 1];
 #pragma unroll
         for (int j = 0; j < (AVG ? 16 : 1); j++) acc[j] = 0;
-        const uint32_t *src = a.iq + (uint64_t)it.ch * a.ch_stride + (uint64_t)it.l0 * SSDR_NFFT + l;
+        constexpr uint32_t LINE_STEP = HOP ? SSDR_NFFT / 2 : SSDR_NFFT;
+        const uint32_t *src = a.iq + (uint64_t)it.ch * a.ch_stride + (uint64_t)it.l0 * LINE_STEP + l;
 
-        for (uint32_t line = it.l0; line < it.l1; line++, src += SSDR_NFFT) {
+        for (uint32_t line = it.l0; line < it.l1; line++, src += LINE_STEP) {
             f32x2 z[32];
             uint32_t raw[32];
 #if SSDR_WF_ABLATE == 2      // ablation: no global loads
 #pragma unroll
             for (int r = 0; r < 32; r++) raw[r] = (uint32_t)(line * 2654435761u + r * 40503u + lane * 97u) & 0x1FFF1FFFu;
 #else
-            load_line(src, raw);
+            if (HOP) load_line_halves(line ? src - SSDR_NFFT / 2 : a.tail + (uint64_t)it.ch * (SSDR_NFFT / 2) + l, src, raw);
+            else load_line(src, raw);
 #endif
 #if SSDR_WF_ABLATE == 1      // ablation: memory traffic only
             int16_t *x16 = reinterpret_cast<int16_t *>(xch_wave + opaque(h) * XCH_FLOATS) + opaque(l);
@@ -466,8 +487,14 @@ __global__ __launch_bounds__(256) void ssdr_quant_selftest_kernel(const float *t
 
 hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream)
 {
-    if (a.n_avg > 1) hipLaunchKernelGGL(ssdr_wf_kernel<true>, dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL(ssdr_wf_kernel<false>, dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
+    const dim3 g(grid), b(SSDR_WF_BLOCK);
+    if (a.tail) {
+        if (a.n_avg > 1) hipLaunchKernelGGL((ssdr_wf_kernel<true, true>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((ssdr_wf_kernel<false, true>), g, b, 0, stream, a);
+    } else {
+        if (a.n_avg > 1) hipLaunchKernelGGL((ssdr_wf_kernel<true, false>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((ssdr_wf_kernel<false, false>), g, b, 0, stream, a);
+    }
     return hipGetLastError();
 }
 
@@ -475,11 +502,14 @@ hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream
 hipError_t ssdr_wf_blocks_per_cu(int *blocks)
 {
     int b0 = 0, b1 = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, ssdr_wf_kernel<false>, SSDR_WF_BLOCK, 0);
+    int b[4] = {0, 0, 0, 0};
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b[0], ssdr_wf_kernel<false, false>, SSDR_WF_BLOCK, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b[1], ssdr_wf_kernel<true, false>, SSDR_WF_BLOCK, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b[2], ssdr_wf_kernel<false, true>, SSDR_WF_BLOCK, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b[3], ssdr_wf_kernel<true, true>, SSDR_WF_BLOCK, 0);
     if (e != hipSuccess) return e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, ssdr_wf_kernel<true>, SSDR_WF_BLOCK, 0);
-    if (e != hipSuccess) return e;
-    *blocks = b0 < b1 ? b0 : b1;
+    *blocks = b[0];
+    for (int i = 1; i < 4; i++) *blocks = b[i] < *blocks ? b[i] : *blocks;
     return hipSuccess;
 }
 

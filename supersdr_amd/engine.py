@@ -53,6 +53,7 @@ class SsdrEngine:
         self._ctx = L._P()
         check(lib.ssdr_create(int(device), self.n_ch, L.NFFT, L.FRAME, C.byref(self._ctx)), "ssdr_create")
         self.in_frames = 0
+        self.hop = L.NFFT
         self.audio_frames = 0          # frames of the last run_audio / set_pcm (extent of the device PCM / RSSI / flags)
 
     def close(self):
@@ -85,6 +86,11 @@ class SsdrEngine:
     def set_averaging(self, n):
         check(lib.ssdr_set_averaging(self._ctx, int(n)), "ssdr_set_averaging")
 
+    def set_hop(self, hop):
+        """samples between waterfall lines: 1024 (default) or 512 (lines overlap by half: 23.4 lines/s, the reference's rate)"""
+        check(lib.ssdr_set_hop(self._ctx, int(hop)), "ssdr_set_hop")
+        self.hop = int(hop)
+
     # ---- data plane
     def push_iq(self, iq):
         """iq: int16 [n_ch, n_frames*512, 2] host array (copied to the GPU)."""
@@ -115,7 +121,7 @@ class SsdrEngine:
         if not fetch:
             check(lib.ssdr_run_wf(self._ctx, None, C.byref(n), 0), "ssdr_run_wf")
             return n.value
-        total_lines = self.in_frames // 2 + 1          # upper bound incl. a carried partial group
+        total_lines = (self.in_frames if self.hop == L.NFFT // 2 else self.in_frames // 2) + 1    # upper bound incl. a carried partial group
         out = np.empty((total_lines, self.n_ch, L.NFFT), np.int16)
         check(lib.ssdr_run_wf(self._ctx, out.ctypes.data, C.byref(n), 0), "ssdr_run_wf")
         return out[: n.value]

@@ -89,9 +89,11 @@ class IQHub:
     """
 
     def __init__(self, n_channels, device=0, engine=None, max_queue=64, gpu_post=True, kiwi_rate=12000, trace_rows=0,
-                 backlog_superframes=8, stall_superframes=4, pipeline=False, depth=3):
+                 backlog_superframes=8, stall_superframes=4, pipeline=False, depth=3, hop=1024):
         self.n_ch = int(n_channels)
         self.engine = engine if engine is not None else SsdrEngine(self.n_ch, device)
+        if hop != L.NFFT:                            # 512: two waterfall lines per superframe, 23.4 lines/s (MAX_FPS = 23, utils:597)
+            self.engine.set_hop(hop)
         # spectrum_db2col and play_buffer run on the GPU with every superframe
         self.gpu_post = bool(gpu_post)
         self.kiwi_rate = int(kiwi_rate)              # kiwi_sound.KIWI_RATE: selects play_buffer's branch (:1125)

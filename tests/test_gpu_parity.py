@@ -698,3 +698,43 @@ def test_checkpoint_restore_continues_bit_exactly(S):
     with S.SsdrEngine(n_ch + 1) as eng:
         with pytest.raises(S.SsdrError):
             eng.restore(blob)                      # channel count mismatch
+
+
+@pytest.mark.parametrize("n_ch,n_avg", [(1, 1), (5, 1), (6, 3), (33, 10)])
+def test_wf_hop_512_bit_exact_vs_twin_and_oracle(S, twin, n_ch, n_avg):
+    """ssdr_set_hop(512): lines overlap by half (23.4 lines/s, the reference's MAX_FPS = 23, utils_supersdr.py:597).  One
+    line per 512-sample frame, the half-line before the first frame carried from the previous call (silence at the
+    start); ragged pushes incl. odd frame counts; N-line sums with groups straddling calls; bit-exact vs the twin, vs
+    the float64 oracle outside the guard band."""
+    n_frames = 23
+    iq = O.synth_iq(n_ch, n_frames * 512, seed=40 + n_ch)
+    cal = np.linspace(-6, 6, n_ch)
+    outs, pos = [], 0
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, [S.default_params("am", wf_cal_db=float(cal[c])) for c in range(n_ch)])
+        eng.set_hop(512)
+        eng.set_averaging(n_avg)
+        for k in (1, 2, 7, 3, 10):
+            eng.push_iq(iq[:, pos * 512:(pos + k) * 512])
+            outs.append(eng.run_wf())
+            pos += k
+        consts, _ = eng.get_consts()
+    got = np.concatenate(outs, axis=0)
+    stream = np.concatenate([np.zeros((n_ch, 512, 2), np.int16), iq], axis=1)          # silence in front
+    ref = twin.wf_hop(stream, 512, n_avg, consts["wf_cal_lin"])
+    assert got.shape == ref.shape == (n_frames // n_avg, n_ch, 1024) and np.array_equal(got, ref)
+    if n_avg == 1:
+        for c in range(min(n_ch, 3)):
+            o = O.wf_lines_hop(stream[c], 512, cal[c]).astype(np.int32)
+            idx = np.arange(n_frames)[:, None] * 512 + np.arange(1024)[None, :]
+            gb = O.wf_allowed_diff(stream[c][idx], cal[c])
+            assert not (np.abs(got[:, c].astype(np.int32) - o) > gb).any()
+    # every second line of the hop-512 stream (the aligned ones) is a hop-1024 line of the same samples
+    if n_avg == 1:
+        with S.SsdrEngine(n_ch) as eng:
+            eng.set_params(0, [S.default_params("am", wf_cal_db=float(cal[c])) for c in range(n_ch)])
+            eng.push_iq(iq[:, : 22 * 512])
+            assert np.array_equal(eng.run_wf(), got[1:22:2])
+        with S.SsdrEngine(2) as eng:
+            with pytest.raises(S.SsdrError):
+                eng.set_hop(256)

@@ -24,6 +24,7 @@ class Twin:
         lib.twin_make_tables.argtypes = [P, P, P, P]
         lib.twin_wf.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, P, P, P, P, P, P]
         lib.twin_wf_line.argtypes = [P, P, P, P, P, C.c_float, P]
+        lib.twin_wf_lines.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, P, P, P, P, P, P]
         lib.twin_audio.argtypes = [P, C.c_uint32, C.c_uint32, P, P, P, P, P, P]
         lib.twin_audio2.argtypes = [P, C.c_uint32, C.c_uint32, P, P, P, P, P, P, P]
         lib.twin_quantise.argtypes = [C.c_float, P]
@@ -50,6 +51,20 @@ class Twin:
         self.lib.twin_wf(iq.ctypes.data, n_ch, n_lines, n_avg, cal.ctypes.data, self.win.ctypes.data,
                          self.wr.ctypes.data, self.wi.ctypes.data, self.thr.ctypes.data, out.ctypes.data)
         return out
+
+    def wf_hop(self, stream, hop, n_avg=1, cal_lin=None):
+        """stream int16[n_ch, n, 2] (for hop 512: the carried 512-sample tail in front) -> int16[(lines // n_avg), n_ch, 1024]
+        sums of n_avg consecutive overlapping lines; line k covers samples [k*hop, k*hop + 1024)"""
+        stream = np.ascontiguousarray(stream, np.int16)
+        n_ch = stream.shape[0]
+        n_lines = (stream.shape[1] - 1024) // hop + 1
+        stream = np.ascontiguousarray(stream[:, :(n_lines - 1) * hop + 1024])
+        cal = np.ones(n_ch, np.float32) if cal_lin is None else np.ascontiguousarray(cal_lin, np.float32)
+        b = np.zeros((n_lines, n_ch, 1024), np.uint8)
+        self.lib.twin_wf_lines(stream.ctypes.data, n_ch, n_lines, hop, cal.ctypes.data, self.win.ctypes.data,
+                               self.wr.ctypes.data, self.wi.ctypes.data, self.thr.ctypes.data, b.ctypes.data)
+        L = n_lines // n_avg
+        return b[: L * n_avg].astype(np.int16).reshape(L, n_avg, n_ch, 1024).sum(axis=1).astype(np.int16)
 
     def audio(self, iq, consts, taps, state, hist, want_flags=False):
         """iq int16[n_ch, n_frames*512, 2]; state/hist updated in place -> (pcm, rssi[, adc-overflow flags uint8])"""
