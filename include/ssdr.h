@@ -79,7 +79,8 @@ typedef struct ssdr_chan_consts {
     uint32_t hang_frames, ntap;
     uint32_t tap_groups;            /* bit g set: taps 4g..4g+3 are not all zero (the FIR skips the others) */
     uint32_t fir_flags;             /* SSDR_FIR_*                                                            */
-    uint32_t pad[2];
+    uint32_t decim;                 /* D: the IQ arrives at D * 12 kHz (ssdr_set_decimation); taps are then stream-major, ntap8 per stream */
+    uint32_t pad[1];
 } ssdr_chan_consts;
 /* the channel filter is exactly a 4-sample delay (one unit tap at index 4: the full-band passband +-6 kHz at 12 kHz,
  * the reference's AM default, utils_supersdr.py:46).  The kernel then shifts samples across lanes instead of filtering,
@@ -113,6 +114,15 @@ int ssdr_default_params(int mode, ssdr_chan_params *out);      /* reference defa
 int ssdr_reset_state(ssdr_ctx *ctx, uint32_t first, uint32_t count);
 /* kiwi_waterfall.averaging_n (utils_supersdr.py:616, 881-886; supersdr.py:376-385), 1..100 */
 int ssdr_set_averaging(ssdr_ctx *ctx, uint32_t n);
+
+/* Input rate.  D = 1 (default): the IQ arrives at 12 kHz.  D = 2 or 4: it arrives at D * 12 kHz and the audio chain's
+ * channel filter is a decimating FIR (the reference's tap formula, utils_supersdr.py:334-344, evaluated at the input
+ * rate; output y[m] = sum_k h[k] z[D m - k]) down to the 12 kHz the demodulators, the AGC and the PCM frames run at.
+ * A frame is still what yields 512 PCM samples: ssdr_push_iq then takes int16 [n_ch][n_frames*512*D][2], f_shift_hz may
+ * reach +-D*6000, and the waterfall draws its lines (1024 or 512 input samples apart) from the wide stream.  Changing D
+ * recompiles every channel's parameters and resets the streams.  Not available on the pipelined feed / wire input. */
+int ssdr_set_decimation(ssdr_ctx *ctx, uint32_t decim);
+int ssdr_compile_params_decim(const ssdr_chan_params *p, uint32_t decim, ssdr_chan_consts *consts, float *taps /*[128]*/);
 
 /* Waterfall line rate.  hop = 1024 (default): one line per 1024 samples, 11.72 lines/s.  hop = 512: lines overlap by half,
  * 23.44 lines/s -- the rate the reference's waterfall runs at (kiwi_waterfall.MAX_FPS = 23, "SET wf_speed=4",

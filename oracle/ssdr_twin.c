@@ -288,7 +288,8 @@ typedef struct {            /* per-channel kernel constants; same layout as the 
     uint32_t hang_frames, ntap;
     uint32_t tap_groups;    /* unused here: zero taps are exact no-ops in the fma chain */
     uint32_t fir_flags;     /* bit 0: the filter is a pure 4-sample delay (one unit tap at index 4) */
-    uint32_t pad[2];
+    uint32_t decim;         /* D (0 or 1: none): the IQ arrives at D * 12 kHz; taps are stream-major, ntap8 per stream */
+    uint32_t pad[1];
 } twin_consts;              /* 64 bytes */
 #define FIR_DELAY4 1u
 
@@ -313,6 +314,14 @@ static void phasor32(uint32_t ph, float *c, float *s)
 
 /* The NCO: the phasor of sample 8 b + j of a frame that starts at phase phi is P(phi) * P(8 b dphi) * S^j, S = P(dphi)
  * -- the ideal oscillator in real arithmetic, three fp32 phasors multiplied here.  block_phasor = the first two. */
+static void block_phasor_n(uint32_t frame_phase, uint32_t dphi, int first_sample, float *c, float *s)
+{
+    float fc, fs, qc, qs;
+    phasor32(frame_phase, &fc, &fs);
+    phasor32((uint32_t)first_sample * dphi, &qc, &qs);
+    *c = fmaf(fc, qc, -(fs * qs));
+    *s = fmaf(fs, qc, fc * qs);
+}
 static void block_phasor(uint32_t frame_phase, uint32_t dphi, int b /*0..63*/, float *c, float *s)
 {
     float fc, fs, qc, qs;
@@ -322,6 +331,16 @@ static void block_phasor(uint32_t frame_phase, uint32_t dphi, int b /*0..63*/, f
     *s = fmaf(fs, qc, fc * qs);
 }
 
+static void mixn(const int16_t *x /*[n][2]*/, int n, float c, float s, float cs, float ss, float *zr, float *zi)
+{
+    for (int j = 0; j < n; j++) {
+        float xr = (float)x[2 * j], xi = (float)x[2 * j + 1];
+        zr[j] = fmaf(xr, c, xi * s);
+        zi[j] = fmaf(xi, c, -(xr * s));
+        float cn = fmaf(c, cs, -(s * ss)), sn = fmaf(s, cs, c * ss);
+        c = cn; s = sn;
+    }
+}
 static void mix8(const int16_t *x /*[8][2]*/, float c, float s, float cs, float ss, float *zr, float *zi)
 {
     for (int j = 0; j < 8; j++) {
@@ -354,13 +373,41 @@ static const float P_FLOOR = 9.5367431640625e-07f;   /* 2^-20 */
 static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, const float *taps,
                         twin_state *st, int16_t *hist /*[HIST][2]*/, int16_t *pcm, float *rssi, uint8_t *flag)
 {
-    static _Thread_local float z1r[HIST + FRAME], z1i[HIST + FRAME];
+    static _Thread_local float z1r[HIST + FRAME * 4], z1i[HIST + FRAME * 4];
     float z2r[FRAME], z2i[FRAME], p[FRAME], aud[FRAME];
+    const int D = c->decim > 1 ? (int)c->decim : 1;
     /* 1. NCO mix of history + frame (the history blocks are blocks 48..63 of the previous frame, mixed as that frame did) */
     float cs1, ss1, cs2, ss2;
     phasor32(c->dphi1, &cs1, &ss1);
     phasor32(c->dphi2, &cs2, &ss2);
-    for (int b = -HIST / 8; b < FRAME / 8; b++) {
+    if (D > 1) {
+        /* Decimating front end: the IQ arrives at D * 12 kHz, a frame is 512 D inputs, "lane" l owns inputs 8 D l ..: one
+         * block phasor and a rotation chain per lane.  y[m] = sum_k h[k] z[D m - k], summed stream by stream: v_q[m] =
+         * z[D m + q], stream q's taps at taps[q * 128/D ...] (stream q >= 1 behind one zero tap), taps ascending. */
+        const int NB = 8 * D, n_in = FRAME * D, slots = NTAP_MAX / D, tail_lanes = HIST / NB;
+        for (int t = 0; t < tail_lanes; t++) {
+            float bc, bs;
+            block_phasor_n(st->phi1 - (uint32_t)n_in * c->dphi1, c->dphi1, NB * (64 - tail_lanes + t), &bc, &bs);
+            mixn(hist + 2 * NB * t, NB, bc, bs, cs1, ss1, z1r + NB * t, z1i + NB * t);
+        }
+        for (int l = 0; l < NLANE; l++) {
+            float bc, bs;
+            block_phasor_n(st->phi1, c->dphi1, NB * l, &bc, &bs);
+            mixn(iq + 2 * NB * l, NB, bc, bs, cs1, ss1, z1r + HIST + NB * l, z1i + HIST + NB * l);
+        }
+        for (int m = 0; m < FRAME; m++) {
+            float ar = 0.0f, ai = 0.0f;
+            for (int q = 0; q < D; q++)
+                for (uint32_t i = 0; i < c->ntap8; i++) {
+                    const int idx = HIST + D * (m - (int)i) + q;
+                    ar = fmaf(taps[q * slots + i], z1r[idx], ar);
+                    ai = fmaf(taps[q * slots + i], z1i[idx], ai);
+                }
+            z2r[m] = ar; z2i[m] = ai;
+            p[m] = fmaf(ar, ar, ai * ai);
+        }
+    }
+    for (int b = -HIST / 8; b < FRAME / 8 && D == 1; b++) {
         const int16_t *x = (b < 0) ? hist + 2 * (HIST + 8 * b) : iq + 2 * 8 * b;
         float bc, bs;
         if (b < 0) block_phasor(st->phi1 - (uint32_t)FRAME * c->dphi1, c->dphi1, 64 + b, &bc, &bs);
@@ -368,7 +415,7 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
         mix8(x, bc, bs, cs1, ss1, z1r + HIST + 8 * b, z1i + HIST + 8 * b);
     }
     /* 2. FIR, taps ascending, fma chain from zero */
-    for (int n = 0; n < FRAME; n++) {
+    for (int n = 0; n < FRAME && D == 1; n++) {
         float ar = 0.0f, ai = 0.0f;
         for (uint32_t k = 0; k < c->ntap8; k++) {
             ar = fmaf(taps[k], z1r[HIST + n - (int)k], ar);
@@ -380,7 +427,7 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
     /* AM behind a filter that is a pure delay: |x e^{j phi}| = |x|, so envelope, AGC level and RSSI do not depend on
      * the NCO.  The power of a sample is then taken exactly in integers, I*I + Q*Q (< 2^32), and rounded once.
      * (z2 keeps its mixed value: its last sample is the discriminator memory carried in the state.) */
-    const int am_raw = (c->mode == 0) && (c->fir_flags & FIR_DELAY4);
+    const int am_raw = (c->mode == 0) && (c->fir_flags & FIR_DELAY4) && D == 1;
     if (am_raw) {
         for (int n = 0; n < FRAME; n++) {
             const int16_t *x = (n < 4) ? hist + 2 * (HIST + n - 4) : iq + 2 * (n - 4);
@@ -391,7 +438,7 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
     /* ADC overflow (SND header flags bit 1, utils_supersdr.py:1066-1067): a sample of this frame at the rails */
     {
         int ovf = 0;
-        for (int n = 0; n < 2 * FRAME; n++) ovf |= (iq[n] >= 32767) || (iq[n] <= -32767);
+        for (int n = 0; n < 2 * FRAME * D; n++) ovf |= (iq[n] >= 32767) || (iq[n] <= -32767);
         *flag = (uint8_t)ovf;
     }
     /* 3. demod */
@@ -490,10 +537,10 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
     }
     *rssi = fmaf(log2p(fmaxf(psum[NLANE - 1], 1e-20f)) - 39.0f, 0x1.815182p+1f /* 10*log10(2) */, c->smeter_cal_db);
     /* 6. state carry */
-    st->phi1 += (uint32_t)FRAME * c->dphi1;
+    st->phi1 += (uint32_t)(FRAME * D) * c->dphi1;
     st->phi2 += (uint32_t)FRAME * c->dphi2;
     /* HIST <= FRAME: the new history is the frame tail */
-    memcpy(hist, iq + 2 * (FRAME - HIST), HIST * 2 * sizeof(int16_t));
+    memcpy(hist, iq + 2 * (FRAME * D - HIST), HIST * 2 * sizeof(int16_t));
 }
 
 /* batch: iq[n_ch][n_frames*512][2]; consts[n_ch]; taps[n_ch][128]; state[n_ch]; hist[n_ch][128][2]
@@ -502,9 +549,10 @@ void twin_audio2(const int16_t *iq, uint32_t n_ch, uint32_t n_frames, const twin
                  const float *taps, twin_state *state, int16_t *hist, int16_t *pcm, float *rssi, uint8_t *flags)
 {
     uint8_t dummy;
+    const size_t D = consts[0].decim > 1 ? consts[0].decim : 1;     /* one input rate per batch */
     for (uint32_t c = 0; c < n_ch; c++)
         for (uint32_t f = 0; f < n_frames; f++)
-            audio_frame(iq + ((size_t)c * n_frames + f) * FRAME * 2, consts + c,
+            audio_frame(iq + ((size_t)c * n_frames + f) * FRAME * D * 2, consts + c,
                         taps + (size_t)c * NTAP_MAX, state + c, hist + (size_t)c * HIST * 2,
                         pcm + ((size_t)c * n_frames + f) * FRAME, rssi + (size_t)c * n_frames + f,
                         flags ? flags + (size_t)c * n_frames + f : &dummy);

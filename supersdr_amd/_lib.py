@@ -31,7 +31,7 @@ class ChanConsts(C.Structure):
                 ("wf_cal_lin", C.c_float), ("smeter_cal_db", C.c_float),
                 ("agc_c0", C.c_float), ("agc_c1", C.c_float), ("agc_knee", C.c_float), ("agc_delta8", C.c_float),
                 ("hang_frames", C.c_uint32), ("ntap", C.c_uint32), ("tap_groups", C.c_uint32), ("fir_flags", C.c_uint32),
-                ("pad", C.c_uint32 * 2)]
+                ("decim", C.c_uint32), ("pad", C.c_uint32 * 1)]
 
 
 class Db2colChan(C.Structure):
@@ -74,6 +74,8 @@ _SIGS = {
     "ssdr_reset_state": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "ssdr_set_averaging": (C.c_int, [_P, C.c_uint32]),
     "ssdr_set_hop": (C.c_int, [_P, C.c_uint32]),
+    "ssdr_set_decimation": (C.c_int, [_P, C.c_uint32]),
+    "ssdr_compile_params_decim": (C.c_int, [C.POINTER(ChanParams), C.c_uint32, C.POINTER(ChanConsts), _P]),
     "ssdr_push_iq": (C.c_int, [_P, _P, C.c_uint32, C.c_int]),
     "ssdr_run_wf": (C.c_int, [_P, _P, C.POINTER(C.c_uint32), C.c_int]),
     "ssdr_run_audio": (C.c_int, [_P, _P, _P, C.c_int]),

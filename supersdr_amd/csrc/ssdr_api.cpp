@@ -24,6 +24,8 @@ struct ssdr_ctx {
     int device = 0;
     uint32_t n_ch = 0;
     uint32_t n_avg = 1, wf_phase = 0;
+    uint32_t decim = 1;                                 // D: the IQ arrives at D * 12 kHz, the audio chain decimates to 12 kHz
+    std::vector<ssdr_chan_params> h_params;             // the parameters the channels were last given (recompiled when D changes)
     uint32_t hop = SSDR_NFFT;                           // samples between waterfall lines: 1024, or 512 (lines overlap by half)
     uint32_t *d_wf_tail = nullptr;                      // hop 512: [n_ch][512] the last half-line of the previous batch
     hipStream_t own_stream = nullptr, stream = nullptr;
@@ -240,7 +242,7 @@ int ssdr_default_params(int mode, ssdr_chan_params *p)
 
 int ssdr_compile_params(const ssdr_chan_params *p, ssdr_chan_consts *consts, float *taps)
 {
-    return ssdr_compile_params_host(p, consts, taps);
+    return ssdr_compile_params_host(p, consts, taps, 1);
 }
 
 int ssdr_table(int which, float *out, uint32_t n)
@@ -297,9 +299,10 @@ int ssdr_set_params(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan
     std::vector<ssdr_chan_consts> k(count);
     std::vector<float> taps((size_t)count * SSDR_NTAP_MAX);
     for (uint32_t i = 0; i < count; i++) {
-        const int rc = ssdr_compile_params_host(p + i, &k[i], taps.data() + (size_t)i * SSDR_NTAP_MAX);
+        const int rc = ssdr_compile_params_host(p + i, &k[i], taps.data() + (size_t)i * SSDR_NTAP_MAX, c->decim);
         if (rc != SSDR_OK) return rc;
     }
+    for (uint32_t i = 0; i < count; i++) c->h_params[first + i] = p[i];
     for (uint32_t i = 0; i < count; i++) c->h_consts[first + i] = k[i];
     c->chan_list_dirty = true;
     HIP_TRY(hipMemcpyAsync(c->d_consts + first, k.data(), count * sizeof(ssdr_chan_consts), hipMemcpyHostToDevice, c->stream));
@@ -351,6 +354,7 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         HIP_TRY(hipMalloc(&c->d_state, (size_t)n_channels * sizeof(ssdr_chan_state)));
         HIP_TRY(hipMalloc(&c->d_chan_list, (size_t)n_channels * sizeof(uint32_t)));
         c->h_consts.resize(n_channels);
+        c->h_params.resize(n_channels);
         HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         for (int i = 0; i < SSDR_PATH_COUNT - 1; i++) {
             HIP_TRY(hipStreamCreateWithFlags(&c->path_stream[i], hipStreamNonBlocking));
@@ -405,6 +409,26 @@ int ssdr_set_averaging(ssdr_ctx *c, uint32_t n)
         c->n_avg = n;
     }
     return SSDR_OK;
+}
+
+int ssdr_compile_params_decim(const ssdr_chan_params *p, uint32_t decim, ssdr_chan_consts *consts, float *taps)
+{
+    return ssdr_compile_params_host(p, consts, taps, decim);
+}
+
+int ssdr_set_decimation(ssdr_ctx *c, uint32_t decim)
+{
+    if (!c || (decim != 1 && decim != 2 && decim != 4)) return SSDR_EINVAL;
+    if (!c->feed.empty()) return SSDR_ESTATE;
+    if (decim == c->decim) return SSDR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const uint32_t keep = c->decim;
+    c->decim = decim;
+    std::vector<ssdr_chan_params> all = c->h_params;              // recompile every channel for the new input rate
+    int rc = ssdr_set_params(c, 0, c->n_ch, all.data());
+    if (rc != SSDR_OK) { c->decim = keep; (void)ssdr_set_params(c, 0, c->n_ch, all.data()); return rc; }
+    c->have_input = false;                                        // a batch pushed at the old rate has the wrong extent
+    return ssdr_reset_state(c, 0, c->n_ch);                       // phases and histories of the old rate mean nothing now
 }
 
 int ssdr_set_hop(ssdr_ctx *c, uint32_t hop)
@@ -491,13 +515,17 @@ static int join_audio(ssdr_ctx *c)
     return SSDR_OK;
 }
 
+// input samples (dwords) per channel of a batch of n_frames frames: a frame yields 512 PCM samples and takes 512 * D of IQ
+static inline size_t in_len(const ssdr_ctx *c, uint32_t n_frames) { return (size_t)n_frames * SSDR_FRAME * c->decim; }
+
 static int ensure_input(ssdr_ctx *c, uint32_t n_frames)
 {
     { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
-    if (c->iq_own_frames < n_frames) {
+    const size_t need = (size_t)n_frames * c->decim;             // capacity is kept in 512-sample units
+    if (c->iq_own_frames < need) {
         if (c->d_iq_own) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_iq_own)); c->d_iq_own = nullptr; c->iq_own_frames = 0; }
-        HIP_TRY(hipMalloc(&c->d_iq_own, (size_t)c->n_ch * n_frames * SSDR_FRAME * 4));
-        c->iq_own_frames = n_frames;
+        HIP_TRY(hipMalloc(&c->d_iq_own, (size_t)c->n_ch * need * SSDR_FRAME * 4));
+        c->iq_own_frames = need;
     }
     return SSDR_OK;
 }
@@ -512,7 +540,7 @@ int ssdr_push_iq(ssdr_ctx *c, const int16_t *iq, uint32_t n_frames, int is_devic
     } else {
         int rc = ensure_input(c, n_frames);
         if (rc != SSDR_OK) return rc;
-        HIP_TRY(hipMemcpyAsync(c->d_iq_own, iq, (size_t)c->n_ch * n_frames * SSDR_FRAME * 4, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_iq_own, iq, (size_t)c->n_ch * in_len(c, n_frames) * 4, hipMemcpyHostToDevice, c->stream));
         c->d_iq = c->d_iq_own;
     }
     c->in_frames = n_frames;
@@ -528,9 +556,9 @@ int ssdr_synth_iq(ssdr_ctx *c, uint32_t n_frames, uint32_t seed, uint32_t first_
     if (rc != SSDR_OK) return rc;
     SsdrSynthArgs a;
     a.iq = c->d_iq_own;
-    a.ch_stride = (uint64_t)n_frames * SSDR_FRAME;
+    a.ch_stride = (uint64_t)in_len(c, n_frames);
     a.n_ch = c->n_ch;
-    a.n_samples = n_frames * SSDR_FRAME;
+    a.n_samples = (uint32_t)in_len(c, n_frames);
     a.seed = seed;
     a.first_channel_id = first_channel_id;
     a.sample0 = c->synth_sample0;
@@ -549,7 +577,7 @@ int ssdr_read_input(ssdr_ctx *c, uint32_t first, uint32_t count, int16_t *iq_out
     if (!c || !iq_out || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     if (!c->have_input) return SSDR_ESTATE;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t per_ch = (size_t)c->in_frames * SSDR_FRAME;
+    const size_t per_ch = in_len(c, c->in_frames);
     HIP_TRY(hipMemcpyAsync(iq_out, c->d_iq + (size_t)first * per_ch, (size_t)count * per_ch * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
@@ -560,9 +588,10 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
     if (!c) return SSDR_EINVAL;
     if (!c->have_input) return SSDR_ESTATE;
     const bool hop512 = c->hop == SSDR_NFFT / 2;
-    if (!hop512 && (c->in_frames & 1u)) return SSDR_EINVAL;
+    const uint32_t halves = c->in_frames * c->decim;                 // 512-sample half-lines in the batch
+    if (!hop512 && (halves & 1u)) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
-    const uint32_t n_lines = hop512 ? c->in_frames : c->in_frames / 2;
+    const uint32_t n_lines = hop512 ? halves : halves / 2;
     const uint32_t total = c->wf_phase + n_lines;
     const uint32_t n_out = total / c->n_avg;
     const uint32_t n_groups = (total + c->n_avg - 1) / c->n_avg;
@@ -573,7 +602,7 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
     }
     SsdrWfArgs a;
     a.iq = c->d_iq;
-    a.ch_stride = (uint64_t)c->in_frames * SSDR_FRAME;
+    a.ch_stride = (uint64_t)in_len(c, c->in_frames);
     a.n_ch = c->n_ch;
     a.n_lines = n_lines;
     a.tail = hop512 ? c->d_wf_tail : nullptr;
@@ -596,8 +625,8 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
     HIP_TRY(ssdr_launch_wf(a, grid ? grid : 1, c->stream));
     if ((rc = timed_end(c, SSDR_K_WF)) != SSDR_OK) return rc;
     if (hop512)                  // the batch's last half-line is the next batch's first: [n_ch] rows of 2 KB out of the input
-        HIP_TRY(hipMemcpy2DAsync(c->d_wf_tail, (SSDR_NFFT / 2) * 4, c->d_iq + (size_t)(c->in_frames - 1) * SSDR_FRAME,
-                                 (size_t)c->in_frames * SSDR_FRAME * 4, (SSDR_NFFT / 2) * 4, c->n_ch, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpy2DAsync(c->d_wf_tail, (SSDR_NFFT / 2) * 4, c->d_iq + (size_t)(halves - 1) * SSDR_FRAME,
+                                 in_len(c, c->in_frames) * 4, (SSDR_NFFT / 2) * 4, c->n_ch, hipMemcpyDeviceToDevice, c->stream));
     c->wf_phase = total % c->n_avg;
     if (c->wf_phase) c->wf_acc_cur ^= 1;             // a partial group was written to acc_out
     c->wf_lines_ready = n_out;
@@ -633,7 +662,7 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
     }
     SsdrAudioArgs a;
     a.iq = c->d_iq;
-    a.ch_stride = (uint64_t)c->in_frames * SSDR_FRAME;
+    a.ch_stride = (uint64_t)in_len(c, c->in_frames);
     a.n_ch = c->n_ch;
     a.n_frames = c->in_frames;
     a.consts = c->d_consts;
@@ -680,7 +709,9 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
             if (!c->path_n[p]) continue;
             a.chan_list = c->d_chan_list + c->path_off[p];
             a.list_n = c->path_n[p];
-            if (first || !side) {
+            if (c->decim > 1) {                     // one kernel: every channel takes the decimating FIR path
+                HIP_TRY(ssdr_launch_audio_dec(a, c->decim, s));
+            } else if (first || !side) {
                 HIP_TRY(ssdr_launch_audio(a, p, s));
             } else {
                 hipStream_t ps = c->path_stream[n_side];
@@ -756,7 +787,7 @@ int ssdr_feed_close(ssdr_ctx *c)
 int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth, uint32_t flags)
 {
     if (!c || n_frames == 0 || (n_frames & 1u) || depth < 2 || depth > 16 || (flags & ~(uint32_t)SSDR_FEED_WIRE)) return SSDR_EINVAL;
-    if (!c->feed.empty() || c->concurrent) return SSDR_ESTATE;
+    if (!c->feed.empty() || c->concurrent || c->decim != 1) return SSDR_ESTATE;      // the feed's slots are sized for 12 kHz IQ
     HIP_TRY(hipSetDevice(c->device));
     const size_t in_b = (size_t)c->n_ch * n_frames * SSDR_FRAME * 4;
     const size_t wire_b = (size_t)c->n_ch * n_frames * SSDR_WIRE_BODY;
@@ -1291,6 +1322,7 @@ int ssdr_playbuffer_mono(ssdr_ctx *c, int16_t *mono_out, int out_is_device)
 int ssdr_push_iq_wire(ssdr_ctx *c, const uint8_t *bodies, uint32_t n_frames, float *rssi_out)
 {
     if (!c || !bodies || n_frames == 0) return SSDR_EINVAL;
+    if (c->decim != 1) return SSDR_ESTATE;                       // SND bodies carry 512 IQ samples at 12 kHz
     HIP_TRY(hipSetDevice(c->device));
     int rc = ensure_input(c, n_frames);
     if (rc != SSDR_OK) return rc;

@@ -131,16 +131,17 @@ struct Nco {
     float qc, qs;               // P(8 l dphi) of this lane
     float tc, ts;               // lane i: P(phase of frame (f & ~63) + i)
 };
-SSDR_DEV void nco_setup(Nco &n, uint32_t dphi, int l)
+// block = samples per lane (8; 8 D in front of a decimating filter), frame = samples per frame at this NCO's rate
+SSDR_DEV void nco_setup(Nco &n, uint32_t dphi, int l, int block = 8)
 {
     n.dphi = dphi;
     ssdr_phasor32(dphi, n.cs, n.ss);
-    ssdr_phasor32((uint32_t)(8 * l) * dphi, n.qc, n.qs);
+    ssdr_phasor32((uint32_t)(block * l) * dphi, n.qc, n.qs);
     n.tc = 1.0f; n.ts = 0.0f;
 }
-SSDR_DEV void nco_frame_table(Nco &n, uint32_t phase_of_frame, int l)       // every 64 frames
+SSDR_DEV void nco_frame_table(Nco &n, uint32_t phase_of_frame, int l, int frame = SSDR_FRAME)       // every 64 frames
 {
-    ssdr_phasor32(phase_of_frame + (uint32_t)(SSDR_FRAME * l) * n.dphi, n.tc, n.ts);
+    ssdr_phasor32(phase_of_frame + (uint32_t)(frame * l) * n.dphi, n.tc, n.ts);
 }
 SSDR_DEV float lane_f(float x, uint32_t lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), (int)lane)); }
 // block phasor of this lane for frame f: (frame phasor) * (lane's block offset phasor)
@@ -158,11 +159,11 @@ SSDR_DEV void phasor_mul(float ac, float as, float bc, float bs, float &c, float
 
 // Mix eight samples with the block phasor (c, s) and the step S: x * conj(P S^j).
 // CLIP: amax = max(amax, |I|, |Q|) over the block (ADC-overflow detection on the samples as they arrive).
-template <bool CLIP>
-SSDR_DEV void mix8(const uint32_t (&rw)[8], float c, float s, float cs, float ss, float2 (&z)[8], float &amax)
+template <bool CLIP, int N = 8>
+SSDR_DEV void mix8(const uint32_t (&rw)[N], float c, float s, float cs, float ss, float2 (&z)[N], float &amax)
 {
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < N; j++) {
         const float xr = (float)(int16_t)(rw[j] & 0xFFFFu);
         const float xi = (float)((int32_t)rw[j] >> 16);
         if (CLIP) amax = vmax3_abs(amax, xr, xi);
@@ -570,6 +571,175 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
     }
 }
 
+// ---- decimating front end (ssdr_set_decimation: the IQ arrives at D * 12 kHz) -------------------------------------
+// Lane l owns the 8 D consecutive inputs that produce its 8 outputs.  Mixed, they de-interleave into D polyphase streams
+// v_q[m] = z[D m + q]; y[m] = sum_k h[k] z[D m - k] is then the sum of D ordinary FIRs, one per stream, each on the taps
+// the host laid out for it (stream q >= 1 carries its taps behind one zero tap: ssdr_tables.cpp) -- the same register-window
+// FIR as the 12 kHz path, run D times on D regions of LDS, 2 FMAs per tap and output sample in total.  Everything behind
+// the filter (demodulators, AGC, PCM, RSSI) is the 12 kHz chain.
+template <int D>
+SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, const int l, const ssdr_chan_consts &kc,
+                                 float2 *s_z, float *s_taps)
+{
+    constexpr int SLOTS = SSDR_NTAP_MAX / D;             // tap slots per stream
+    constexpr int HOCT_S = SSDR_HIST / D / 8;            // history octets per stream
+    constexpr int ROCT = HOCT_S + 64;                    // octets per stream region
+    constexpr int NB = 8 * D;                            // inputs per lane and frame
+    constexpr int TAIL_LANES = SSDR_HIST / NB;           // lanes of a frame whose inputs form the 128-sample raw tail
+    const uint32_t mode = kc.mode;
+    const uint32_t nblk = kc.ntap8 >> 3;                 // per stream
+    const uint32_t dphi1 = kc.dphi1, dphi2 = kc.dphi2;
+    const AgcK agc = {kc.agc_c0, kc.agc_c1, kc.agc_knee, kc.agc_delta8, kc.hang_frames};
+    const float cal = kc.smeter_cal_db;
+    Nco n1, n2;
+    nco_setup(n1, dphi1, l, NB);
+    nco_setup(n2, dphi2, l);
+    const float cs1 = n1.cs, ss1 = n1.ss, cs2 = n2.cs, ss2 = n2.ss;
+
+    ssdr_chan_state st = a.state[ch];
+    uint32_t phi1 = st.phi1, phi2 = st.phi2;
+    float dc = st.dc, agc_d = st.agc_d, prev_re = st.prev_re, prev_im = st.prev_im;
+    float agc_m[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) agc_m[i] = st.agc_m[i];
+    {
+        const float2 t = reinterpret_cast<const float2 *>(a.taps + (size_t)ch * SSDR_NTAP_MAX)[l];
+        s_taps[2 * l] = t.x;
+        s_taps[2 * l + 1] = t.y;
+        if (l < 8) s_taps[SSDR_NTAP_MAX + l] = 0.0f;
+    }
+    uint32_t *hist = a.hist + (size_t)ch * SSDR_HIST;
+    // history: the raw tail is the input of the previous frame's last TAIL_LANES lanes; lane l re-mixes the block of lane
+    // 64 - TAIL_LANES + l exactly as that frame did and files it in front of each stream
+    if (l < TAIL_LANES) {
+        uint32_t rw[NB];
+        const uint4 *hp = reinterpret_cast<const uint4 *>(hist + NB * l);
+#pragma unroll
+        for (int i = 0; i < NB / 4; i++) { const uint4 v = hp[i]; rw[4 * i] = v.x; rw[4 * i + 1] = v.y; rw[4 * i + 2] = v.z; rw[4 * i + 3] = v.w; }
+        float2 Z[NB];
+        float unused = 0.0f, fc, fs, qc, qs, bc, bs;
+        ssdr_phasor32(phi1 - (uint32_t)(SSDR_FRAME * D) * dphi1, fc, fs);
+        ssdr_phasor32((uint32_t)(NB * (64 - TAIL_LANES + l)) * dphi1, qc, qs);
+        phasor_mul(fc, fs, qc, qs, bc, bs);
+        mix8<false, NB>(rw, bc, bs, cs1, ss1, Z, unused);
+#pragma unroll
+        for (int q = 0; q < D; q++) {
+            float2 V[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) V[j] = Z[D * j + q];
+            store_oct(s_z + q * ROCT * OCT, l, V);
+        }
+    }
+
+    const uint32_t *src = a.iq + (uint64_t)ch * a.ch_stride + NB * l;
+    int16_t *dst = a.pcm + (uint64_t)ch * a.n_frames * SSDR_FRAME + 8 * l;
+    float *rssi_row = a.rssi + (uint64_t)ch * a.n_frames;
+    uint8_t *flag_row = a.flags + (uint64_t)ch * a.n_frames;
+    uint32_t rw[NB];
+    float rssi_sum = 0.0f;
+    uint32_t flag_keep = 0;
+
+    for (uint32_t f = 0; f < a.n_frames; f++, src += SSDR_FRAME * D, dst += SSDR_FRAME) {
+        if ((f & 63u) == 0) {
+            nco_frame_table(n1, phi1, l, SSDR_FRAME * D);
+            if (mode >= SSDR_MODE_LSB && mode <= SSDR_MODE_CW) nco_frame_table(n2, phi2, l);
+        }
+#pragma unroll
+        for (int i = 0; i < NB / 4; i++) {
+            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src) + i);
+            rw[4 * i] = v.x; rw[4 * i + 1] = v.y; rw[4 * i + 2] = v.z; rw[4 * i + 3] = v.w;
+        }
+        float p[8], aud[8], yr[8], yi[8];
+        {
+            float2 Z[NB];
+            float amax = 0.0f, bc, bs;
+            nco_block(n1, f, bc, bs);
+            mix8<true, NB>(rw, bc, bs, cs1, ss1, Z, amax);
+#pragma unroll
+            for (int q = 0; q < D; q++) {
+                float2 V[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) V[j] = Z[D * j + q];
+                store_oct(s_z + q * ROCT * OCT, HOCT_S + l, V);
+            }
+            lds_sync();
+            const bool clip = wave_any(amax >= 32767.0f);
+#pragma unroll
+            for (int j = 0; j < 8; j++) { yr[j] = 0.0f; yi[j] = 0.0f; }
+            // the D stream filters, one after the other into the same accumulators: stream 0 first, taps ascending
+            for (int q = 0; q < D; q++) {
+                const float2 *zq = s_z + q * ROCT * OCT;
+                const float *gq = s_taps + q * SLOTS;
+                float2 A[8], B[8];
+                for (uint32_t b = 0; b < nblk; b += 2) {
+                    const float4 *hq = reinterpret_cast<const float4 *>(gq + 8 * b);
+                    load_oct(zq, HOCT_S + l - (int)b, A);
+                    load_oct(zq, HOCT_S + l - 1 - (int)b, B);
+                    {
+                        const float4 h0 = hq[0], h1 = hq[1];
+                        const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                        fir_taps<0, 8>(h, A, B, yr, yi);
+                    }
+                    if (b + 1 < nblk) {                          // (an odd block count: the next slots are the next stream's)
+                        load_oct(zq, HOCT_S + l - 2 - (int)b, A);
+                        const float4 h0 = hq[2], h1 = hq[3];
+                        const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                        fir_taps<0, 8>(h, B, A, yr, yi);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) p[j] = fmaf(yr[j], yr[j], yi[j] * yi[j]);
+            if (mode == SSDR_MODE_AM) demod_am<false>(p, dc, aud);
+            else if (mode <= SSDR_MODE_CW) {
+                float b2c, b2s;
+                nco_block(n2, f, b2c, b2s);
+                demod_ssb(yr, yi, b2c, b2s, cs2, ss2, aud);
+            } else demod_fm(yr, yi, prev_re, prev_im, aud);
+            prev_re = lane63(yr[7]);
+            prev_im = lane63(yi[7]);
+            agc_pack_store(p, aud, l, agc, agc_d, agc_m, dst);
+            rssi_flag_step(p, clip, f, a.n_frames, l, cal, rssi_sum, flag_keep, rssi_row, flag_row);
+        }
+        phi1 += (uint32_t)(SSDR_FRAME * D) * dphi1;
+        phi2 += (uint32_t)SSDR_FRAME * dphi2;
+        lds_sync();
+        if (l < HOCT_S * D) {                                    // each stream's tail becomes its history
+            const int q = l / HOCT_S, o = l - q * HOCT_S;
+            float2 T[8];
+            load_oct(s_z + q * ROCT * OCT, 64 + o, T);
+            store_oct(s_z + q * ROCT * OCT, o, T);
+        }
+        lds_sync();
+    }
+
+    if (a.n_frames) {
+        if (l >= 64 - TAIL_LANES) {                              // raw tail of the last frame: 128 input samples
+            u32x4 *hp = reinterpret_cast<u32x4 *>(hist + NB * (l - (64 - TAIL_LANES)));
+#pragma unroll
+            for (int i = 0; i < NB / 4; i++) hp[i] = u32x4{rw[4 * i], rw[4 * i + 1], rw[4 * i + 2], rw[4 * i + 3]};
+        }
+        if (l == 0) {
+            st.phi1 = phi1; st.phi2 = phi2; st.dc = dc; st.agc_d = agc_d;
+#pragma unroll
+            for (int i = 0; i < 8; i++) st.agc_m[i] = agc_m[i];
+            st.prev_re = prev_re; st.prev_im = prev_im;
+            a.state[ch] = st;
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_dec_kernel(SsdrAudioArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float2 s_z[D * (SSDR_HIST / D / 8 + 64) * OCT];      // 11.5 KB (D = 2), 21.8 KB (D = 4)
+    __shared__ __attribute__((aligned(16))) float s_taps[SSDR_NTAP_MAX + 8];
+    const int l = threadIdx.x;
+    const uint32_t ch = blockIdx.x;
+    if (ch >= a.n_ch) return;
+    channel_frames_dec<D>(a, ch, l, a.consts[ch], s_z, s_taps);
+}
+
 // One kernel per frame path: the paths differ by a factor of two in registers (the general path holds a 16-sample FIR
 // window, the AM shift path fits 64 VGPRs and needs no LDS), and a wave's register file share is fixed per kernel.  The
 // host keeps the channels of a ctx sorted by path (chan_list) and launches each non-empty group.
@@ -669,6 +839,14 @@ hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, int path, hipStream_t strea
     case SSDR_PATH_AM_RAW: hipLaunchKernelGGL(ssdr_audio_kernel<PATH_AM_RAW>, dim3(a.list_n), dim3(SSDR_AUDIO_BLOCK), 0, stream, a); break;
     default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t ssdr_launch_audio_dec(const SsdrAudioArgs &a, uint32_t decim, hipStream_t stream)
+{
+    if (decim == 2) hipLaunchKernelGGL(ssdr_audio_dec_kernel<2>, dim3(a.n_ch), dim3(SSDR_AUDIO_BLOCK), 0, stream, a);
+    else if (decim == 4) hipLaunchKernelGGL(ssdr_audio_dec_kernel<4>, dim3(a.n_ch), dim3(SSDR_AUDIO_BLOCK), 0, stream, a);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -127,6 +127,7 @@ hipError_t ssdr_launch_adpcm(const uint8_t *data, uint32_t n_streams, uint32_t n
 hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream);
 hipError_t ssdr_wf_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, int path, hipStream_t stream);
+hipError_t ssdr_launch_audio_dec(const SsdrAudioArgs &a, uint32_t decim, hipStream_t stream);
 hipError_t ssdr_launch_synth(const SsdrSynthArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_sqrt_selftest(unsigned long long *mismatch, hipStream_t stream);
 hipError_t ssdr_launch_quant_selftest(const float *thr, const uint2 *lut, unsigned long long *mismatch, hipStream_t stream);
@@ -137,5 +138,5 @@ void ssdr_make_twiddles(float *wr, float *wi);        // [512] each
 void ssdr_make_tw_stage(float2 *tw);                  // [992]
 void ssdr_make_thresholds(float *thr);                // [256]
 int ssdr_make_quant_lut(uint2 *lut);                  // [SSDR_LUT_N]; returns 0, or -1 if a segment held two thresholds
-int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps);
+int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps, uint32_t decim);
 int ssdr_design_lowpass(double fl, double fs, int n_max, double *h);   // utils_supersdr.py:334-344; returns tap count

@@ -101,13 +101,24 @@ static uint32_t dphi_of(double f_hz)
     return (uint32_t)v;
 }
 
-int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps)
+static uint32_t dphi_at(double f_hz, double fs)
+{
+    const double x = std::nearbyint(f_hz / fs * 4294967296.0);
+    long long v = (long long)x % 4294967296ll;
+    if (v < 0) v += 4294967296ll;
+    return (uint32_t)v;
+}
+
+// decim = D in {1, 2, 4}: the IQ arrives at D * 12 kHz and the channel filter decimates to 12 kHz.
+int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps, uint32_t decim)
 {
     if (!p || !c || !taps) return SSDR_EINVAL;
     if (p->mode < SSDR_MODE_AM || p->mode > SSDR_MODE_NBFM) return SSDR_EINVAL;
-    // the tuning offset must lie inside the IQ band: beyond +-RATE/2 the NCO step wraps mod 2^32 and the channel would
+    if (decim != 1 && decim != 2 && decim != 4) return SSDR_EINVAL;
+    const double fs_in = (double)SSDR_RATE * decim;
+    // the tuning offset must lie inside the IQ band: beyond +-fs/2 the NCO step wraps mod 2^32 and the channel would
     // silently demodulate an alias
-    if (!(std::fabs(p->f_shift_hz) <= SSDR_RATE / 2.0)) return SSDR_EINVAL;
+    if (!(std::fabs(p->f_shift_hz) <= fs_in / 2.0)) return SSDR_EINVAL;
     std::memset(c, 0, sizeof *c);
     double f_bc, fl;
     if (p->mode >= SSDR_MODE_LSB && p->mode <= SSDR_MODE_CW) {
@@ -117,9 +128,11 @@ int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, flo
         f_bc = 0.0;
         fl = std::max(std::fabs(p->low_cut), std::fabs(p->high_cut));
     }
-    fl = std::min(std::max(fl, 50.0), SSDR_RATE / 2.0);
+    fl = std::min(std::max(fl, 50.0), SSDR_RATE / 2.0);          // the OUTPUT rate bounds the passband: this is the anti-alias filter too
     double h[SSDR_NTAP_MAX];
-    const int ntap = ssdr_design_lowpass(fl, (double)SSDR_RATE, SSDR_NTAP_MAX - 1, h);
+    // the reference's tap formula at the input rate (N = ceil(4 fs / fl) grows with D); the slots hold 127 taps (125 at D = 4,
+    // where each of the four polyphase streams gets 32 slots, one of them the stream's leading delay tap)
+    const int ntap = ssdr_design_lowpass(fl, fs_in, decim == 4 ? 125 : SSDR_NTAP_MAX - 1, h);
     for (int i = 0; i < SSDR_NTAP_MAX; i++) taps[i] = (i < ntap) ? (float)h[i] : 0.0f;
     // The windowed-sinc formula leaves numerical dust where a tap is mathematically zero (sinc at integers,
     // Blackman end points: 1e-17 .. 1e-34 against a peak of ~1).  Taps below 2^-40 of the largest are set to
@@ -142,8 +155,29 @@ int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, flo
         for (int i = 0; i < ntap; i++) nz += (taps[i] != 0.0f);
         c->fir_flags = (nz == 1 && ntap > 4 && taps[4] == 1.0f) ? SSDR_FIR_DELAY4 : 0u;
     }
-    c->dphi1 = dphi_of(p->f_shift_hz + f_bc);
-    c->dphi2 = dphi_of(f_bc);
+    c->dphi1 = dphi_at(p->f_shift_hz + f_bc, fs_in);            // the mixer runs at the input rate,
+    c->dphi2 = dphi_of(f_bc);                                   // the SSB re-mixer at the output rate
+    c->decim = decim;
+    if (decim > 1) {
+        // Polyphase streams v_q[m] = z[D m + q], q = 0..D-1 (what a lane's D*8 consecutive inputs de-interleave into):
+        //   y[m] = sum_k h[k] z[D m - k] = sum_i h[D i] v_0[m - i] + sum_{q>=1} sum_i h[D i + (D - q)] v_q[m - 1 - i]
+        // so stream q >= 1 carries its taps behind one zero tap.  Layout: stream q at taps[q * 128/D ...].
+        float g[SSDR_NTAP_MAX];
+        std::memset(g, 0, sizeof g);
+        const int slots = SSDR_NTAP_MAX / (int)decim;
+        int longest = 0;
+        for (int k = 0; k < ntap; k++) {
+            const int pph = k % (int)decim, i = k / (int)decim;
+            const int q = pph ? (int)decim - pph : 0, pos = pph ? i + 1 : i;
+            if (pos >= slots) return SSDR_EINVAL;
+            g[q * slots + pos] = taps[k];
+            longest = std::max(longest, pos + 1);
+        }
+        std::memcpy(taps, g, sizeof g);
+        c->ntap8 = (uint32_t)((longest + 7) & ~7);              // per stream
+        c->fir_flags = 0;
+        c->tap_groups = 0;
+    }
     c->wf_cal_lin = (float)std::pow(10.0, p->wf_cal_db / 10.0);
     c->smeter_cal_db = (float)p->smeter_cal_db;
     const double log2_10 = std::log2(10.0);

@@ -13,7 +13,7 @@ from ._lib import SmeterChan, ChanParams, ChanConsts, ChanState, Db2colChan, Pla
 CONSTS_DTYPE = np.dtype([("mode", "<u4"), ("ntap8", "<u4"), ("dphi1", "<u4"), ("dphi2", "<u4"),
                          ("wf_cal_lin", "<f4"), ("smeter_cal_db", "<f4"), ("agc_c0", "<f4"), ("agc_c1", "<f4"),
                          ("agc_knee", "<f4"), ("agc_delta8", "<f4"), ("hang_frames", "<u4"), ("ntap", "<u4"),
-                         ("tap_groups", "<u4"), ("fir_flags", "<u4"), ("pad", "<u4", (2,))])
+                         ("tap_groups", "<u4"), ("fir_flags", "<u4"), ("decim", "<u4"), ("pad", "<u4", (1,))])
 STATE_DTYPE = np.dtype([("phi1", "<u4"), ("phi2", "<u4"), ("dc", "<f4"), ("agc_d", "<f4"), ("agc_m", "<f4", (8,)),
                         ("prev_re", "<f4"), ("prev_im", "<f4"), ("pad", "<u4", (2,))])
 assert CONSTS_DTYPE.itemsize == 64 and STATE_DTYPE.itemsize == 64
@@ -31,11 +31,11 @@ def default_params(mode="am", **over):
     return p
 
 
-def compile_params(p):
-    """ChanParams -> (consts record, float32[128] taps), computed by the library's host code."""
+def compile_params(p, decim=1):
+    """ChanParams -> (consts record, float32[128] taps), computed by the library's host code (decim: ssdr_set_decimation)."""
     k = ChanConsts()
     taps = np.zeros(L.NTAP_MAX, np.float32)
-    check(lib.ssdr_compile_params(C.byref(p), C.byref(k), taps.ctypes.data), "ssdr_compile_params")
+    check(lib.ssdr_compile_params_decim(C.byref(p), int(decim), C.byref(k), taps.ctypes.data), "ssdr_compile_params")
     rec = np.frombuffer(bytes(k), dtype=CONSTS_DTYPE)[0]
     return rec, taps
 
@@ -54,6 +54,7 @@ class SsdrEngine:
         check(lib.ssdr_create(int(device), self.n_ch, L.NFFT, L.FRAME, C.byref(self._ctx)), "ssdr_create")
         self.in_frames = 0
         self.hop = L.NFFT
+        self.decim = 1
         self.audio_frames = 0          # frames of the last run_audio / set_pcm (extent of the device PCM / RSSI / flags)
 
     def close(self):
@@ -86,6 +87,11 @@ class SsdrEngine:
     def set_averaging(self, n):
         check(lib.ssdr_set_averaging(self._ctx, int(n)), "ssdr_set_averaging")
 
+    def set_decimation(self, decim):
+        """D in {1, 2, 4}: the IQ arrives at D * 12 kHz (push_iq then takes [n_ch, n_frames*512*D, 2]); resets the streams"""
+        check(lib.ssdr_set_decimation(self._ctx, int(decim)), "ssdr_set_decimation")
+        self.decim = int(decim)
+
     def set_hop(self, hop):
         """samples between waterfall lines: 1024 (default) or 512 (lines overlap by half: 23.4 lines/s, the reference's rate)"""
         check(lib.ssdr_set_hop(self._ctx, int(hop)), "ssdr_set_hop")
@@ -95,9 +101,9 @@ class SsdrEngine:
     def push_iq(self, iq):
         """iq: int16 [n_ch, n_frames*512, 2] host array (copied to the GPU)."""
         iq = np.ascontiguousarray(iq, dtype=np.int16)
-        if iq.ndim != 3 or iq.shape[0] != self.n_ch or iq.shape[2] != 2 or iq.shape[1] % L.FRAME:
-            raise ValueError("iq must be int16[n_ch=%d, k*512, 2], got %r" % (self.n_ch, iq.shape))
-        self.in_frames = iq.shape[1] // L.FRAME
+        if iq.ndim != 3 or iq.shape[0] != self.n_ch or iq.shape[2] != 2 or iq.shape[1] % (L.FRAME * self.decim):
+            raise ValueError("iq must be int16[n_ch=%d, k*%d, 2], got %r" % (self.n_ch, L.FRAME * self.decim, iq.shape))
+        self.in_frames = iq.shape[1] // (L.FRAME * self.decim)
         check(lib.ssdr_push_iq(self._ctx, iq.ctypes.data, self.in_frames, 0), "ssdr_push_iq")
         self.sync()             # the host buffer may be released by the caller after this returns
 
@@ -111,7 +117,7 @@ class SsdrEngine:
 
     def read_input(self, first=0, count=None):
         count = self.n_ch - first if count is None else int(count)
-        out = np.empty((count, self.in_frames * L.FRAME, 2), np.int16)
+        out = np.empty((count, self.in_frames * L.FRAME * self.decim, 2), np.int16)
         check(lib.ssdr_read_input(self._ctx, int(first), count, out.ctypes.data), "ssdr_read_input")
         return out
 
@@ -121,7 +127,8 @@ class SsdrEngine:
         if not fetch:
             check(lib.ssdr_run_wf(self._ctx, None, C.byref(n), 0), "ssdr_run_wf")
             return n.value
-        total_lines = (self.in_frames if self.hop == L.NFFT // 2 else self.in_frames // 2) + 1    # upper bound incl. a carried partial group
+        halves = self.in_frames * self.decim
+        total_lines = (halves if self.hop == L.NFFT // 2 else halves // 2) + 1    # upper bound incl. a carried partial group
         out = np.empty((total_lines, self.n_ch, L.NFFT), np.int16)
         check(lib.ssdr_run_wf(self._ctx, out.ctypes.data, C.byref(n), 0), "ssdr_run_wf")
         return out[: n.value]

@@ -738,3 +738,58 @@ def test_wf_hop_512_bit_exact_vs_twin_and_oracle(S, twin, n_ch, n_avg):
         with S.SsdrEngine(2) as eng:
             with pytest.raises(S.SsdrError):
                 eng.set_hop(256)
+
+
+@pytest.mark.parametrize("decim", [2, 4])
+def test_decimating_front_end_bit_exact_vs_twin_and_oracle(S, twin, decim):
+    """ssdr_set_decimation(D): IQ at D * 12 kHz, decimating polyphase FIR in the audio kernel, waterfall
+    lines from the wide stream.  Random parameter sets over all modes (up to the 127 / 125-tap cap), several calls with
+    the state crossing them: PCM, RSSI, flags, carried state bit-exact vs the twin; vs the float64 oracle (plain
+    convolve-and-take-every-D-th) within the PCM tolerance."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import random_params as RP
+    rng = np.random.default_rng(200 + decim)
+    n_ch, n_frames = 40, 6
+    kw = [RP.draw(rng) for _ in range(n_ch)]
+    for k in kw:
+        k["f_shift_hz"] *= decim
+    iq = RP.signal(rng, n_ch, n_frames * 512 * decim)
+    ps = [S.default_params(k["mode"], f_shift_hz=k["f_shift_hz"], low_cut=k["low_cut"], high_cut=k["high_cut"],
+                           agc_on=k["agc_on"], agc_hang=k["hang"], agc_thresh=k["thresh"], agc_slope=k["slope"],
+                           agc_decay=k["decay"], agc_man_gain=k["man_gain"], wf_cal_db=k["wf_cal_db"],
+                           smeter_cal_db=k["smeter_cal_db"]) for k in kw]
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_decimation(decim)
+        eng.set_params(0, ps)
+        pcms, rssis, flags, wfs, pos = [], [], [], [], 0
+        for nf in (1, 3, 2):
+            eng.push_iq(iq[:, pos * 512 * decim:(pos + nf) * 512 * decim])
+            if (nf * decim) % 2 == 0:
+                wfs.append((pos, nf, eng.run_wf()))
+            p, r = eng.run_audio()
+            pcms.append(p)
+            rssis.append(r)
+            flags.append(eng.audio_flags())
+            pos += nf
+        consts, taps = eng.get_consts()
+        st_g, hist_g = eng.get_state()
+    assert (consts["decim"] == decim).all() and (consts["fir_flags"] == 0).all()
+    st, hist = twinlib.fresh_state(consts)
+    pcm_t, rssi_t, flags_t = twin.audio(iq, consts, taps, st, hist, want_flags=True)
+    pcm = np.concatenate(pcms, axis=1)
+    assert pcm.shape == (n_ch, n_frames * 512) and np.array_equal(pcm, pcm_t)
+    assert np.array_equal(np.concatenate(rssis, axis=1), rssi_t) and np.array_equal(np.concatenate(flags, axis=1), flags_t)
+    assert st_g.tobytes() == st.tobytes() and np.array_equal(hist_g, hist)
+    for pos0, nf, wf in wfs:                                           # the waterfall sees the wide stream, 1024 samples per line
+        seg = iq[:, pos0 * 512 * decim:(pos0 + nf) * 512 * decim]
+        assert np.array_equal(wf, twin.wf(seg, 1, consts["wf_cal_lin"]))
+    pcm_o, _ = O.audio_chain(iq, [O.ChanParams(**k) for k in kw], decim)
+    ok = np.array([k["mode"] != "nbfm" for k in kw])                  # (an FM discriminator on a silent channel is noise on noise)
+    rms = np.sqrt(((pcm.astype(np.float64) - pcm_o) ** 2).mean(axis=1)) / 32768.0
+    assert np.sort(rms[ok])[: int(0.9 * ok.sum())].max() < PCM_RMS_TOL, np.sort(rms[ok])
+    with S.SsdrEngine(2) as eng:
+        with pytest.raises(S.SsdrError):
+            eng.set_decimation(3)
+        eng.set_decimation(2)
+        with pytest.raises(S.SsdrError):
+            eng.feed_open(2, 3)                                        # the pipelined feed is 12 kHz only

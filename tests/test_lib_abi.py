@@ -137,3 +137,38 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
                 txt = open(os.path.join(dp, f)).read()
                 assert not bad.search(txt), os.path.join(dp, f)
+
+
+@pytest.mark.parametrize("decim", [2, 4])
+def test_param_compile_for_a_decimating_front_end_equals_oracle(S, decim):
+    """ssdr_set_decimation(D): the reference's tap formula at D * 12 kHz (capped at 127 / 125 taps), NCO step at the input
+    rate, taps laid out as D polyphase streams -- the library's host code and the oracle agree on 150 random sets, and
+    the stream layout is a permutation of the filter (stream q >= 1 behind one zero tap)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import random_params as RP
+    rng = np.random.default_rng(50 + decim)
+    for i in range(150):
+        kw = RP.draw(rng)
+        kw["f_shift_hz"] *= decim                                   # the band is D times as wide
+        p = S.default_params(kw["mode"], f_shift_hz=kw["f_shift_hz"], low_cut=kw["low_cut"], high_cut=kw["high_cut"],
+                             agc_on=kw["agc_on"], agc_hang=kw["hang"], agc_thresh=kw["thresh"], agc_slope=kw["slope"],
+                             agc_decay=kw["decay"], agc_man_gain=kw["man_gain"], wf_cal_db=kw["wf_cal_db"],
+                             smeter_cal_db=kw["smeter_cal_db"])
+        k, taps = S.compile_params(p, decim)
+        ok = O.compile_params(O.ChanParams(**kw), decim)
+        for f in ("mode", "ntap", "ntap8", "dphi1", "dphi2", "hang_frames", "tap_groups", "fir_flags", "decim"):
+            assert int(k[f]) == int(ok[f]), (i, f, kw)
+        assert np.array_equal(taps, ok["taps_streams"]), (i, kw)
+        h, slots = ok["taps"][: ok["ntap"]], 128 // decim
+        back = np.zeros(int(ok["ntap"]), np.float32)
+        for kk in range(int(ok["ntap"])):
+            pph, ii = kk % decim, kk // decim
+            q, pos = (decim - pph, ii + 1) if pph else (0, ii)
+            back[kk] = taps[q * slots + pos]
+        assert np.array_equal(back, h) and np.count_nonzero(taps) == np.count_nonzero(h)
+        assert int(ok["ntap"]) <= (125 if decim == 4 else 127) and int(k["ntap8"]) <= slots
+    with pytest.raises(S.SsdrError):
+        S.compile_params(S.default_params("am"), 3)
+    assert S.compile_params(S.default_params("usb", f_shift_hz=11000.0), 2)[0]["decim"] == 2      # inside +-12 kHz
+    with pytest.raises(S.SsdrError):
+        S.compile_params(S.default_params("usb", f_shift_hz=12000.5), 2)

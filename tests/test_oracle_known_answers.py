@@ -290,3 +290,46 @@ def test_twin_tracks_float64_oracle_over_random_parameters(seed, n_frames):
         ref = O.wf_sum_lines(lines, 1, kw[c]["wf_cal_db"])
         guard = O.wf_guard_band(lines, kw[c]["wf_cal_db"])
         assert not ((wf_t[:, c] != ref) & ~guard).any(), c
+
+
+@pytest.mark.parametrize("decim", [2, 4])
+def test_decimating_front_end_twin_vs_oracle(twin, decim):
+    """IQ at D * 12 kHz: the twin's polyphase-stream FIR (fp32, the kernels' order) against the oracle's plain
+    np.convolve(z, h)[::D] (float64), all modes; and the filter does what a decimator must -- a carrier outside the
+    12 kHz output band but inside the wide input band is gone from the AM output."""
+    n_ch, n_frames = 6, 5
+    rng = np.random.default_rng(decim)
+    iq = O.synth_iq(n_ch, n_frames * 512 * decim, seed=80 + decim)
+    modes = ["am", "usb", "lsb", "cw", "nbfm", "am"]
+    prm = [O.ChanParams(mode=m, f_shift_hz=float(rng.integers(-5000, 5000)) * decim,
+                        **({"low_cut": -3000.0, "high_cut": 3000.0} if m in ("am", "nbfm") else
+                           {"low_cut": 300.0, "high_cut": 2700.0} if m == "usb" else
+                           {"low_cut": -2700.0, "high_cut": -300.0} if m == "lsb" else {"low_cut": 400.0, "high_cut": 800.0}))
+           for m in modes]
+    consts = np.zeros(n_ch, twinlib.CONSTS_DTYPE)
+    taps = np.zeros((n_ch, 128), np.float32)
+    for c, p in enumerate(prm):
+        k = O.compile_params(p, decim)
+        for f in ("mode", "ntap", "ntap8", "dphi1", "dphi2", "wf_cal_lin", "smeter_cal_db", "agc_c0", "agc_c1", "agc_knee",
+                  "agc_delta8", "hang_frames", "fir_flags", "decim"):
+            consts[f][c] = k[f]
+        taps[c] = k["taps_streams"]
+    st, hist = twinlib.fresh_state(consts)
+    pcm_t, rssi_t = twin.audio(iq, consts, taps, st, hist)
+    pcm_o, rssi_o = O.audio_chain(iq, prm, decim)
+    assert pcm_t.shape == (n_ch, n_frames * 512)
+    rms = np.sqrt(((pcm_t.astype(np.float64) - pcm_o) ** 2).mean(axis=1)) / 32768.0
+    assert rms.max() < 1e-5, rms
+    assert np.abs(rssi_t - rssi_o).max() < 1e-3
+    # frame by frame == all at once (history of 128 inputs, phases advancing by 512 D steps)
+    st2, hist2 = twinlib.fresh_state(consts)
+    parts = [twin.audio(iq[:, f * 512 * decim:(f + 1) * 512 * decim], consts, taps, st2, hist2)[0] for f in range(n_frames)]
+    assert np.array_equal(np.concatenate(parts, axis=1), pcm_t) and st2.tobytes() == st.tobytes()
+    # anti-aliasing: AM, passband +-3 kHz, tuned to 0; a strong carrier at 0.4 fs_in (outside +-6 kHz for every D) with 1 kHz AM
+    n = np.arange(8 * 512 * decim)
+    fs_in = 12000.0 * decim
+    z = 12000.0 * (1 + 0.8 * np.sin(2 * np.pi * 1000.0 * n / fs_in)) * np.exp(2j * np.pi * 0.4 * fs_in * n / fs_in)
+    x = np.stack([np.rint(z.real), np.rint(z.imag)], axis=-1).astype(np.int16)[None]
+    p = O.ChanParams(mode="am", f_shift_hz=0.0, low_cut=-3000.0, high_cut=3000.0, agc_on=0, man_gain=50)
+    out, rssi = O.audio_chain(x, [p], decim)
+    assert np.abs(out[0, 2048:]).max() <= 2 and rssi[0, -1] < -70.0       # >= 70 dB down: the Blackman stop band

@@ -12,7 +12,7 @@ SO = os.path.join(ORACLE, "libssdr_twin.so")
 CONSTS_DTYPE = np.dtype([("mode", "<u4"), ("ntap8", "<u4"), ("dphi1", "<u4"), ("dphi2", "<u4"),
                          ("wf_cal_lin", "<f4"), ("smeter_cal_db", "<f4"), ("agc_c0", "<f4"), ("agc_c1", "<f4"),
                          ("agc_knee", "<f4"), ("agc_delta8", "<f4"), ("hang_frames", "<u4"), ("ntap", "<u4"),
-                         ("tap_groups", "<u4"), ("fir_flags", "<u4"), ("pad", "<u4", (2,))])
+                         ("tap_groups", "<u4"), ("fir_flags", "<u4"), ("decim", "<u4"), ("pad", "<u4", (1,))])
 STATE_DTYPE = np.dtype([("phi1", "<u4"), ("phi2", "<u4"), ("dc", "<f4"), ("agc_d", "<f4"), ("agc_m", "<f4", (8,)),
                         ("prev_re", "<f4"), ("prev_im", "<f4"), ("pad", "<u4", (2,))])
 
@@ -69,8 +69,8 @@ class Twin:
     def audio(self, iq, consts, taps, state, hist, want_flags=False):
         """iq int16[n_ch, n_frames*512, 2]; state/hist updated in place -> (pcm, rssi[, adc-overflow flags uint8])"""
         iq = np.ascontiguousarray(iq, np.int16)
-        n_ch, n_frames = iq.shape[0], iq.shape[1] // 512
         consts = np.ascontiguousarray(consts, CONSTS_DTYPE)
+        n_ch, n_frames = iq.shape[0], iq.shape[1] // (512 * max(1, int(consts["decim"][0])))
         taps = np.ascontiguousarray(taps, np.float32)
         assert state.dtype == STATE_DTYPE and state.flags.c_contiguous and hist.flags.c_contiguous
         pcm = np.zeros((n_ch, n_frames * 512), np.int16)
