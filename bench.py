@@ -272,7 +272,7 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
             "n_avg": n_avg}
 
 
-def pmc_traffic(workload, channels, sframes):
+def pmc_traffic(workload, channels, sframes, hop=1024):
     """HBM bytes per launch from the PMC passes committed under profiles/ (collected with rocprofv3 in separate
     runs, corrected as MI355X_MICROARCH.md prescribes; tools/profile_round.sh + tools/traffic_json.py).
     Only used when it was measured on exactly this workload shape; the newest round wins."""
@@ -283,9 +283,17 @@ def pmc_traffic(workload, channels, sframes):
             t = json.load(open(path))
         except Exception:
             continue
-        if (t.get("workload"), t.get("channels_per_gpu"), t.get("superframes_per_step")) == (workload, channels, sframes):
+        if (t.get("workload"), t.get("channels_per_gpu"), t.get("superframes_per_step"), t.get("wf_hop", 1024)) == (workload, channels, sframes, hop):
             found, src = {k: v["hbm_bytes_per_launch"] for k, v in t["kernels"].items()}, os.path.basename(path)
     return found, src
+
+
+def stage_traffic(traffic, stage):
+    """PMC bytes of a stage: its kernel's, or the sum over the kernels a multi-kernel audio stage names"""
+    import re
+    names = re.findall(r"ssdr_\w+_kernel<[^>]*>", stage["kernel"])
+    vals = [traffic.get(n) for n in names]
+    return sum(vals) if vals and all(v is not None for v in vals) else None
 
 
 def roofline(stage, traffic=None, src=None):
@@ -362,7 +370,7 @@ def main():
                 args.spinup, args.concurrent, args.host_feed, args.hop)
     stages = m["stages"]
     dom = max(stages, key=lambda k: stages[k]["avg_ms"])
-    traffic, src = pmc_traffic(args.workload, channels, sframes)
+    traffic, src = pmc_traffic(args.workload, channels, sframes, args.hop)
 
     out = {
         "metric": "real-time IQ channels sustained (WF+demod)", "value": m["value"], "unit": "rt_channels",
@@ -374,11 +382,11 @@ def main():
                    "clock_spinup_s": args.spinup,
                    "input": "pinned host memory, pipelined H2D / kernels / D2H (PCIe-inclusive)" if args.host_feed else "resident in HBM",
                    "sharding": "channel blocks per GPU, no collectives", "rendezvous": rdv.backend if world > 1 else "none"},
-        "roofline": roofline(stages[dom], traffic.get(stages[dom]["kernel"]), src),
+        "roofline": roofline(stages[dom], stage_traffic(traffic, stages[dom]), src),
     }
     for k, label in (("wf", "roofline_fft"), ("audio", "roofline_audio")):
         if k in stages and k != dom:
-            out[label] = roofline(stages[k], traffic.get(stages[k]["kernel"]), src)
+            out[label] = roofline(stages[k], stage_traffic(traffic, stages[k]), src)
     if "wf" in stages and "audio" in stages:
         # the chain as one unit (fused budget): the input counted once, 4096 + 2048/N + 2048 B per channel-superframe
         b = channels * sframes * (4096.0 + (2 if args.hop == 512 else 1) * 2048.0 / n_avg + 2048.0)
@@ -396,7 +404,7 @@ def main():
             tr, tsrc = pmc_traffic(wl, ch, sf)
             extra[wl] = {"workload": WORKLOAD_TEXT[wl], "value": e["value"], "unit": "rt_channels", "ms_per_step": e["ms_per_step"],
                          "steps": max(20, args.steps // 2), "channels_per_gpu": ch, "superframes_per_step": sf, "averaging_n": e["n_avg"],
-                         "rooflines": [roofline(s, tr.get(s["kernel"]), tsrc) for s in e["stages"].values()]}
+                         "rooflines": [roofline(s, stage_traffic(tr, s), tsrc) for s in e["stages"].values()]}
         out["extra"] = extra
 
     if rank == 0:

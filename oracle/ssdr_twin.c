@@ -111,29 +111,34 @@ static float exp2p(float y)
     return u2f(f2u(r) + ((uint32_t)(int32_t)n << 23));
 }
 
-/* atan2(y, x), cephes atanf reduction; the two quotients through rcp_1to2p42. */
+/* atan2(y, x): t = min/max through rcp_1to2p42, atan(t) = t + t^3 Q(t^2) on [0, 1], octant by sign bits; -0 counts as +0. */
 static float atan2p(float y, float x)
 {
-    const float A0 = -3.33329491539e-1f, A1 = 1.99777106478e-1f,
-                A2 = -1.38776856032e-1f, A3 = 8.05374449538e-2f;
-    const float PI_4 = 0.78539816339744831f, PI_2 = 1.5707963267948966f, PI_1 = 3.14159265358979323f;
+    const float Q0 = -3.3331659436e-01f, Q1 = 1.9962704182e-01f, Q2 = -1.3976582885e-01f, Q3 = 9.7942389548e-02f,
+                Q4 = -5.7773657143e-02f, Q5 = 2.3040184751e-02f, Q6 = -4.3554198928e-03f;
+    const float PI_2 = 1.5707963267948966f, PI_1 = 3.14159265358979323f;
+    x = x + 0.0f;
+    y = y + 0.0f;
     float ax = fabsf(x), ay = fabsf(y);
     float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    if (mx == 0.0f) return 0.0f;
     const float mxc = fmaxf(mx, 1e-30f);
     const float sc = u2f(0x7F000000u - (f2u(mxc) & 0x7F800000u));       /* 2^-exponent(mx): mx*sc in [1, 2) */
     float t = (mn * sc) * rcp_1to2p42(mxc * sc);
-    float u = t, off = 0.0f;
-    if (t > 0.41421356237f) { u = (t - 1.0f) * rcp_1to2p42(t + 1.0f); off = PI_4; }
-    float z = u * u;
-    float q = fmaf(A3, z, A2);
-    q = fmaf(q, z, A1);
-    q = fmaf(q, z, A0);
-    float r = off + fmaf(u * z, q, u);
-    if (ay > ax) r = PI_2 - r;
-    if (x < 0.0f) r = PI_1 - r;
-    if (y < 0.0f) r = -r;
-    return r;
+    float z = t * t;
+    float q = fmaf(Q6, z, Q5);
+    q = fmaf(q, z, Q4);
+    q = fmaf(q, z, Q3);
+    q = fmaf(q, z, Q2);
+    q = fmaf(q, z, Q1);
+    q = fmaf(q, z, Q0);
+    float r = fmaf(t * z, q, t);
+    float d = ax - ay;
+    uint32_t flip = (f2u(d) ^ f2u(x)) & 0x80000000u;
+    float rs = u2f(f2u(r) ^ flip);
+    float base = (x < 0.0f) ? PI_1 : 0.0f;
+    base = (d < 0.0f) ? PI_2 : base;
+    float a = rs + base;
+    return u2f(f2u(a) | (f2u(y) & 0x80000000u));
 }
 
 /* byte = #{k in 1..255 : T[k] <= p} */

@@ -93,29 +93,38 @@ SSDR_DEV float ssdr_exp2p(float y)
     return __uint_as_float(__float_as_uint(r) + ((uint32_t)(int32_t)n << 23));
 }
 
-// atan2(y, x): cephes atanf reduction
+// atan2(y, x).  One division-free quotient t = min/max in [0, 1] (exact power-of-two scaling of the larger magnitude into
+// [1, 2), then the seven-FMA reciprocal above), atan(t) = t + t^3 Q(t^2) with a degree-6 minimax Q on the whole of [0, 1]
+// (|error| < 1e-7, no second range reduction), and the octant put back with sign-bit arithmetic:
+//     |y| > |x|: pi/2 - r     x < 0: pi - (.)     y < 0: -(.)      ==  copysign(base +- r, y)
+// Signed zeros carry no phase: -0 counts as +0 (atan2(0, 0) = 0, atan2(-0, x < 0) = +pi).
 SSDR_DEV float ssdr_atan2p(float y, float x)
 {
-    const float A0 = -3.33329491539e-1f, A1 = 1.99777106478e-1f,
-                A2 = -1.38776856032e-1f, A3 = 8.05374449538e-2f;
-    const float PI_4 = 0.78539816339744831f, PI_2 = 1.5707963267948966f, PI_1 = 3.14159265358979323f;
-    float ax = fabsf(x), ay = fabsf(y);
-    float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
-    // t = mn / mx without a divide: both scaled by the power of two that brings mx into [1, 2) (exact), then 1/mx
-    const float mxc = fmaxf(mx, 1e-30f);         // no 0/0: mx == 0 returns 0 below
+    const float Q0 = -3.3331659436e-01f, Q1 = 1.9962704182e-01f, Q2 = -1.3976582885e-01f, Q3 = 9.7942389548e-02f,
+                Q4 = -5.7773657143e-02f, Q5 = 2.3040184751e-02f, Q6 = -4.3554198928e-03f;
+    const float PI_2 = 1.5707963267948966f, PI_1 = 3.14159265358979323f;
+    x = x + 0.0f;                                 // -0 -> +0
+    y = y + 0.0f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    const float mxc = fmaxf(mx, 1e-30f);         // no 0/0: both zero gives t = 0, r = 0, base 0
     const float sc = __uint_as_float(0x7F000000u - (__float_as_uint(mxc) & 0x7F800000u));
-    float t = (mn * sc) * ssdr_rcp_1to2p42(mxc * sc);
-    float u = t, off = 0.0f;
-    if (t > 0.41421356237f) { u = (t - 1.0f) * ssdr_rcp_1to2p42(t + 1.0f); off = PI_4; }     // t + 1 in (1.41, 2]
-    float z = u * u;
-    float q = fmaf(A3, z, A2);
-    q = fmaf(q, z, A1);
-    q = fmaf(q, z, A0);
-    float r = off + fmaf(u * z, q, u);
-    if (ay > ax) r = PI_2 - r;
-    if (x < 0.0f) r = PI_1 - r;
-    if (y < 0.0f) r = -r;
-    return (mx == 0.0f) ? 0.0f : r;
+    const float t = (mn * sc) * ssdr_rcp_1to2p42(mxc * sc);
+    const float z = t * t;
+    float q = fmaf(Q6, z, Q5);
+    q = fmaf(q, z, Q4);
+    q = fmaf(q, z, Q3);
+    q = fmaf(q, z, Q2);
+    q = fmaf(q, z, Q1);
+    q = fmaf(q, z, Q0);
+    const float r = fmaf(t * z, q, t);            // atan(t) in [0, pi/4]
+    const float d = ax - ay;                      // sign bit set <=> |y| > |x|
+    const uint32_t flip = (__float_as_uint(d) ^ __float_as_uint(x)) & 0x80000000u;
+    const float rs = __uint_as_float(__float_as_uint(r) ^ flip);
+    float base = (x < 0.0f) ? PI_1 : 0.0f;
+    base = (d < 0.0f) ? PI_2 : base;
+    const float a = rs + base;                    // >= 0
+    return __uint_as_float(__float_as_uint(a) | (__float_as_uint(y) & 0x80000000u));
 }
 
 // Correctly rounded sqrt for 0 <= p < 2^62 (what |z|^2 can be): the hardware estimate (v_sqrt_f32,
