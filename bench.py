@@ -175,7 +175,7 @@ def spawn_ranks(gpus, argv):
 # one measurement
 # ---------------------------------------------------------------------------------------------------------------
 def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sframes, steps, warmup, spinup,
-            concurrent=0, host_feed=0, hop=1024):
+            concurrent=0, host_feed=0, hop=1024, fused=0):
     """Spin the clocks up, W warm-up steps, then exactly `steps` timed steps between barrier + synchronize pairs.
     -> dict(value, ms_per_step, stages)."""
     _, _, n_avg, modes, do_wf, do_audio = WORKLOADS[workload]
@@ -187,6 +187,7 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
         eng.set_params(first, params[: min(len(params), channels - first)])
     eng.reset_state()
     eng.set_hop(hop)
+    eng.set_fused(fused)
     eng.set_averaging(n_avg)
     eng.set_concurrent(concurrent)
     eng.synth_iq(n_frames, seed=0x5D5D, first_channel_id=rank * channels)    # resident in HBM from here on
@@ -197,6 +198,10 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
             eng.run_wf(fetch=False)
         if do_audio:
             eng.run_audio(fetch=False)
+
+    if fused and do_wf and do_audio:
+        def step():                                       # noqa: F811  (one kernel when the configuration allows it)
+            eng.run_chain()
 
     inflight = [0]
     if host_feed:
@@ -232,7 +237,7 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
         step()
     eng.sync()
     eng.set_profiling(True)                 # HIP-event pair around every launch, on the launch stream, no host sync
-    for k in (L.K_WF, L.K_AUDIO):
+    for k in (L.K_WF, L.K_AUDIO, L.K_FUSED):
         eng.kernel_stats(k, reset=True)
     rdv.barrier()
     torch.cuda.synchronize()
@@ -249,6 +254,7 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
 
     wf_ms, wf_n = eng.kernel_stats(L.K_WF)
     au_ms, au_n = eng.kernel_stats(L.K_AUDIO)
+    fu_ms, fu_n = eng.kernel_stats(L.K_FUSED)
     paths = eng.audio_paths()
     eng.close()
     units = channels * sframes * steps * world                 # channel-superframes, whole job
@@ -270,6 +276,10 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
                "audio stage: " + " + ".join("ssdr_audio_kernel<%d> (%s, %d ch)" % (p, PATH_NAMES[p], paths[p]) for p in live) + \
                (" one after the other" if concurrent & 2 else " side by side")
         stages["audio"] = {"kernel": name, "avg_ms": avg, "launches": au_n, "bytes": b, "GBps": b / avg / 1e6}
+    if fu_n:
+        avg = fu_ms / fu_n
+        b = channels * sframes * 8192.0                 # SURVEY.md 8d, fused budget at N = 1: 4096 in + 2048 + 2048 out
+        stages["fused"] = {"kernel": "ssdr_fused_am_kernel", "avg_ms": avg, "launches": fu_n, "bytes": b, "GBps": b / avg / 1e6}
     return {"value": units / wall / RT_SUPERFRAMES_PER_S, "ms_per_step": wall / steps * 1e3, "stages": stages,
             "n_avg": n_avg}
 
@@ -324,6 +334,8 @@ def main():
                     help="1: inputs come from (pinned) host memory (2: as SND wire bodies, unpacked on the device) and results go back to it through the pipelined feed "
                          "(ssdr_feed_*): the PCIe-inclusive rate of DESIGN.md, never the headline value")
     ap.add_argument("--concurrent", type=int, default=0, help="bit 0: audio stage on a second stream beside the waterfall kernel; bit 1: the audio stage's per-path kernels one after the other")
+    ap.add_argument("--fused", type=int, default=0,
+                    help="1: ssdr_run_chain with the fused superframe kernel where the configuration allows it (full-band AM, N = 1)")
     ap.add_argument("--hop", type=int, default=1024, choices=[512, 1024],
                     help="samples between waterfall lines: 512 = 23.4 lines/s, the reference's waterfall rate (utils_supersdr.py:597)")
     ap.add_argument("--dry-run", action="store_true",
@@ -369,7 +381,7 @@ def main():
     from supersdr_amd import _lib as L
 
     m = measure(S, L, torch, rdv, rank, world, local_rank, args.workload, channels, sframes, args.steps, args.warmup,
-                args.spinup, args.concurrent, args.host_feed, args.hop)
+                args.spinup, args.concurrent, args.host_feed, args.hop, args.fused)
     stages = m["stages"]
     dom = max(stages, key=lambda k: stages[k]["avg_ms"])
     traffic, src = pmc_traffic(args.workload, channels, sframes, args.hop)
@@ -386,7 +398,7 @@ def main():
                    "sharding": "channel blocks per GPU, no collectives", "rendezvous": rdv.backend if world > 1 else "none"},
         "roofline": roofline(stages[dom], stage_traffic(traffic, stages[dom]), src),
     }
-    for k, label in (("wf", "roofline_fft"), ("audio", "roofline_audio")):
+    for k, label in (("wf", "roofline_fft"), ("audio", "roofline_audio"), ("fused", "roofline_fused")):
         if k in stages and k != dom:
             out[label] = roofline(stages[k], stage_traffic(traffic, stages[k]), src)
     if "wf" in stages and "audio" in stages:

@@ -146,6 +146,13 @@ int ssdr_run_audio(ssdr_ctx *ctx, int16_t *pcm_out, float *rssi_out, int out_is_
 /* SND header flags, bit 1 "ADC overflow" (kiwi_sound.adc_overflow_flag, utils_supersdr.py:1066-1067) for every frame of the
  * last ssdr_run_audio: flags_out uint8 [n_ch][n_frames], 1 where a sample of that frame has |I| or |Q| >= 32767. */
 int ssdr_audio_flags(ssdr_ctx *ctx, uint8_t *flags_out, int out_is_device);
+/* Both stages on the current batch, results kept on the device (ssdr_wf_device / ssdr_audio_device / ssdr_audio_flags): what
+ * ssdr_run_wf followed by ssdr_run_audio do.  With ssdr_set_fused(ctx, 1), and when every channel is on the reference's
+ * full-band AM passband, N = 1, hop 1024, 12 kHz IQ, an even frame count (the configuration of the metric), ONE kernel
+ * does both: each 4 KB line is read once for its FFT and its two audio frames; results are bit-identical to the two
+ * kernels'.  *fused (may be NULL) tells which way it went. */
+int ssdr_run_chain(ssdr_ctx *ctx, uint32_t *lines_ready, int *fused);
+int ssdr_set_fused(ssdr_ctx *ctx, int on);
 int ssdr_sync(ssdr_ctx *ctx);
 
 /* -- the reference's own post-processing of the two streams, on the GPU.
@@ -256,6 +263,7 @@ int ssdr_feed_close(ssdr_ctx *ctx);
 
 /* -- device-resident results of the last run_* (for zero-copy consumers and bench) */
 int ssdr_wf_device(ssdr_ctx *ctx, int16_t **ptr, uint32_t *lines);
+int ssdr_copy_from_device(ssdr_ctx *ctx, void *host_dst, const void *device_src, uint64_t bytes);   /* ordered behind the ctx's work */
 int ssdr_audio_device(ssdr_ctx *ctx, int16_t **pcm, float **rssi);
 
 /* -- measurement */
@@ -264,7 +272,7 @@ int ssdr_set_profiling(ssdr_ctx *ctx, int on);                  /* HIP-event pai
 /* bit 0: run the audio stage on a second stream beside the waterfall kernel (which then takes one workgroup per CU);
  * bit 1: run the audio stage's per-path kernels one after the other instead of side by side (measurement only) */
 int ssdr_set_concurrent(ssdr_ctx *ctx, int on);
-enum { SSDR_K_WF = 0, SSDR_K_AUDIO = 1, SSDR_K_SYNTH = 2, SSDR_K_DB2COL = 3, SSDR_K_PLAY = 4, SSDR_K_WIRE = 5, SSDR_K_TRACE = 6, SSDR_K_SMETER = 7, SSDR_K_COUNT = 8 };
+enum { SSDR_K_WF = 0, SSDR_K_AUDIO = 1, SSDR_K_SYNTH = 2, SSDR_K_DB2COL = 3, SSDR_K_PLAY = 4, SSDR_K_WIRE = 5, SSDR_K_TRACE = 6, SSDR_K_SMETER = 7, SSDR_K_FUSED = 8, SSDR_K_COUNT = 9 };
 int ssdr_kernel_stats(ssdr_ctx *ctx, int which, float *total_ms, uint32_t *launches, int reset);
 /* channels per frame path of the audio stage (one kernel each, timed together as SSDR_K_AUDIO): counts[0] general
  * (NCO -> FIR), counts[1] full-band lane shift, counts[2] full-band AM (no NCO, no FIR) */

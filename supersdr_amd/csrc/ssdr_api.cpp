@@ -47,6 +47,10 @@ struct ssdr_ctx {
     bool chan_list_dirty = true;
     hipStream_t path_stream[SSDR_PATH_COUNT - 1] = {};  // the audio kernels of different paths run side by side
     hipEvent_t ev_fork = nullptr, ev_path[SSDR_PATH_COUNT - 1] = {};
+    bool fused_enabled = false;                         // ssdr_set_fused
+    bool fuse_next = false;                             // ssdr_run_chain: run_wf parks its arguments, run_audio launches the fused kernel
+    SsdrWfArgs fused_wf;
+    uint32_t fused_grid = 0;
     bool audio_serial = false;                          // measurement: one path kernel after the other on one stream
     int16_t *d_wf_acc[2] = {nullptr, nullptr};          // ping-pong: carry-in / carry-out of partial groups
     int wf_acc_cur = 0;
@@ -383,6 +387,9 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         // persistent grid == exactly the resident workgroups (a larger grid would run a ragged second round)
         c->wf_grid = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
         c->wf_grid_1 = (uint32_t)prop.multiProcessorCount;        // one workgroup per CU (concurrent mode)
+        int fused_per_cu = 0;
+        HIP_TRY(ssdr_fused_blocks_per_cu(&fused_per_cu));
+        c->fused_grid = (uint32_t)prop.multiProcessorCount * (uint32_t)(fused_per_cu < 1 ? 1 : fused_per_cu);
         return SSDR_OK;
     }();
     if (rc == SSDR_OK) {
@@ -621,9 +628,13 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
     const uint32_t wf_grid = c->concurrent ? c->wf_grid_1 : c->wf_grid;
     const uint32_t grid = (uint32_t)(need < wf_grid ? need : wf_grid);
     int rc;
-    if ((rc = timed_begin(c)) != SSDR_OK) return rc;
-    HIP_TRY(ssdr_launch_wf(a, grid ? grid : 1, c->stream));
-    if ((rc = timed_end(c, SSDR_K_WF)) != SSDR_OK) return rc;
+    if (c->fuse_next) {                      // the fused superframe kernel does this stage's work: ssdr_run_audio launches it
+        c->fused_wf = a;
+    } else {
+        if ((rc = timed_begin(c)) != SSDR_OK) return rc;
+        HIP_TRY(ssdr_launch_wf(a, grid ? grid : 1, c->stream));
+        if ((rc = timed_end(c, SSDR_K_WF)) != SSDR_OK) return rc;
+    }
     if (hop512)                  // the batch's last half-line is the next batch's first: [n_ch] rows of 2 KB out of the input
         HIP_TRY(hipMemcpy2DAsync(c->d_wf_tail, (SSDR_NFFT / 2) * 4, c->d_iq + (size_t)(halves - 1) * SSDR_FRAME,
                                  in_len(c, c->in_frames) * 4, (SSDR_NFFT / 2) * 4, c->n_ch, hipMemcpyDeviceToDevice, c->stream));
@@ -696,6 +707,18 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         HIP_TRY(hipStreamSynchronize(s));    // `list` goes out of scope
         c->chan_list_dirty = false;
     }
+    if (c->fuse_next) {                      // waterfall + full-band AM audio in one kernel: one read of the input
+        SsdrFusedArgs fa;
+        fa.wf = c->fused_wf;
+        fa.au = a;
+        const uint64_t pairs = (c->n_ch + 1) / 2;
+        const uint64_t need = (pairs + SSDR_WF_BLOCK / 64 - 1) / (SSDR_WF_BLOCK / 64);
+        const uint32_t grid = (uint32_t)(need < c->fused_grid ? need : c->fused_grid);
+        if ((rc = timed_begin(c, s)) != SSDR_OK) return rc;
+        HIP_TRY(ssdr_launch_fused_am(fa, grid ? grid : 1, s));
+        if ((rc = timed_end(c, SSDR_K_FUSED, s)) != SSDR_OK) return rc;
+        return SSDR_OK;
+    }
     // one kernel per non-empty path: the first on the stream itself, the others beside it on their own streams
     // (fork and join by events); the stage is timed between two events on `s`
     if ((rc = timed_begin(c, s)) != SSDR_OK) return rc;
@@ -733,6 +756,30 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         HIP_TRY(hipEventRecord(c->ev_a, s));
         c->audio_pending = true;
     }
+    return SSDR_OK;
+}
+
+int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
+{
+    if (!c) return SSDR_EINVAL;
+    if (!c->have_input) return SSDR_ESTATE;
+    uint32_t n_am = 0;
+    for (uint32_t ch = 0; ch < c->n_ch; ch++) n_am += ssdr_audio_path(c->h_consts[ch]) == SSDR_PATH_AM_RAW;
+    // the fused kernel covers the metric's configuration: every channel on the full-band AM path, N = 1, hop 1024, 12 kHz IQ
+    const bool eligible = n_am == c->n_ch && c->n_avg == 1 && c->hop == SSDR_NFFT && c->decim == 1 && !(c->in_frames & 1u) &&
+                          !c->concurrent && c->fused_grid != 0 && c->fused_enabled;
+    if (fused) *fused = eligible ? 1 : 0;
+    c->fuse_next = eligible;
+    int rc = ssdr_run_wf(c, nullptr, lines_ready, 0);
+    if (rc == SSDR_OK) rc = ssdr_run_audio(c, nullptr, nullptr, 0);
+    c->fuse_next = false;
+    return rc;
+}
+
+int ssdr_set_fused(ssdr_ctx *c, int on)
+{
+    if (!c) return SSDR_EINVAL;
+    c->fused_enabled = on != 0;
     return SSDR_OK;
 }
 
@@ -907,6 +954,16 @@ int ssdr_wf_device(ssdr_ctx *c, int16_t **ptr, uint32_t *lines)
     if (!c || !ptr) return SSDR_EINVAL;
     *ptr = c->d_wf_out;
     if (lines) *lines = c->wf_lines_ready;
+    return SSDR_OK;
+}
+
+int ssdr_copy_from_device(ssdr_ctx *c, void *host_dst, const void *device_src, uint64_t bytes)
+{
+    if (!c || !host_dst || !device_src) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
+    HIP_TRY(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
 }
 

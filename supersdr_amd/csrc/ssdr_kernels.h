@@ -124,6 +124,9 @@ hipError_t ssdr_launch_trace(const SsdrTraceArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_smeter(const SsdrSmeterArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_adpcm(const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state, int16_t *out,
                              hipStream_t stream);
+struct SsdrFusedArgs { SsdrWfArgs wf; SsdrAudioArgs au; };
+hipError_t ssdr_launch_fused_am(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream);
+hipError_t ssdr_fused_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream);
 hipError_t ssdr_wf_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, int path, hipStream_t stream);

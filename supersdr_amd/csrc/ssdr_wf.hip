@@ -27,6 +27,7 @@
 // that share the 160 KB of LDS.
 #include "ssdr_math.h"
 #include "ssdr_kernels.h"
+#include "ssdr_audio_dev.h"
 
 namespace {
 
@@ -458,6 +459,208 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused superframe kernel for the metric's configuration (N = 1, hop 1024, every channel on the full-band AM path):
+// one read of a channel's 4 KB line feeds the FFT and both 512-sample audio frames.
+//
+// A wave owns a channel pair for the whole call (the audio chain is sequential in time).  Per superframe: the line is
+// loaded once in the FFT's layout (lane l of a half: samples 32 r + l); each lane turns its 32 samples into integer
+// powers I*I + Q*Q (all the full-band AM chain needs, ssdr_audio.hip) and parks them in the wave's transpose buffer,
+// which the FFT does not need yet; then the whole wave runs the audio chain of channel A, then of channel B -- 64 lanes
+// x 8 consecutive samples per frame read back from LDS, i.e. exactly the stand-alone kernel's layout and code (bit-identical
+// results, the same scan orders); then the FFT proceeds on the raw samples it still holds.  The vector ALU work is the
+// sum of the two kernels'; what is saved is the second read of the input.
+__global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fused_am_kernel(SsdrFusedArgs fa)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];
+    const SsdrWfArgs &a = fa.wf;
+    const SsdrAudioArgs &u = fa.au;
+    load_tables(smem, a.win, a.tw_stage, a.lut);
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, l = lane & 31;
+    float *xch_wave = reinterpret_cast<float *>(smem + LDS_XCH) + wave * 2 * XCH_FLOATS;
+    uint32_t *qbuf = reinterpret_cast<uint32_t *>(xch_wave);                 // [2][XCH_FLOATS]: powers of the two channels' line
+    const uint32_t lut_mask = ~7u;
+    const unsigned char *lut0 = smem;
+    const uint32_t n_pairs = (a.n_ch + 1) >> 1;
+    const uint32_t wave_stride = gridDim.x * WAVES;
+    const uint32_t n_frames = u.n_frames;
+
+    for (uint32_t pair = blockIdx.x * WAVES + wave; pair < n_pairs; pair += wave_stride) {
+        const uint32_t ch_raw = 2 * pair + h;
+        const bool ch_ok = ch_raw < a.n_ch;
+        const uint32_t ch = ch_ok ? ch_raw : a.n_ch - 1;
+        const float cal_wf = a.consts[ch].wf_cal_lin;
+        const uint32_t n_sub = (2 * pair + 1 < a.n_ch) ? 2u : 1u;           // channels of this pair that exist
+
+        // The audio chain's carried state of both channels (wave-uniform: 14 words per channel) does not stay in registers
+        // across the FFT, which needs nearly all of them: between two audio phases it rests in the pad column of the wave's
+        // transpose buffer (index 33 i + 32, i >= 16: written by neither the transpose nor the line staging).  Only the two per-lane
+        // keepers (RSSI sum, flag of frame f mod 64) stay in registers.
+        float rssi_sum[2] = {0.0f, 0.0f};
+        uint32_t flag_keep[2] = {0u, 0u};
+        // (rows 16..31 of the pad column: the line staging reuses the first 2 KB of the buffer)
+        auto pad = [&](int c, int i) -> float & { return xch_wave[c * XCH_FLOATS + 33 * (i + 16) + 32]; };
+        if (lane < 2) {
+            const uint32_t cc = min(2 * pair + (uint32_t)lane, a.n_ch - 1);
+            const ssdr_chan_state st = u.state[cc];
+            pad(lane, 0) = st.dc;
+            pad(lane, 1) = st.agc_d;
+#pragma unroll
+            for (int i = 0; i < 8; i++) pad(lane, 2 + i) = st.agc_m[i];
+            const uint4 t = *reinterpret_cast<const uint4 *>(u.hist + (size_t)cc * SSDR_HIST + SSDR_HIST - 4);
+            pad(lane, 10) = __uint_as_float(iq_power(t.x)); pad(lane, 11) = __uint_as_float(iq_power(t.y));
+            pad(lane, 12) = __uint_as_float(iq_power(t.z)); pad(lane, 13) = __uint_as_float(iq_power(t.w));
+        }
+        wave_lds_sync();
+
+        const uint32_t *src = a.iq + (uint64_t)ch * a.ch_stride + l;
+        uint32_t last_raw31 = 0;
+        for (uint32_t line = 0; line < a.n_lines; line++, src += SSDR_NFFT) {
+            // ---- the carried state out of its resting place (the powers below overwrite it)
+            float dc[2], agc_d[2], agc_m[2][8];
+            uint32_t tail_q[2][4];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                dc[c] = pad(c, 0); agc_d[c] = pad(c, 1);
+#pragma unroll
+                for (int i = 0; i < 8; i++) agc_m[c][i] = pad(c, 2 + i);
+#pragma unroll
+                for (int i = 0; i < 4; i++) tail_q[c][i] = __float_as_uint(pad(c, 10 + i));
+            }
+            wave_lds_sync();
+            // ---- audio, phase 1: integer powers of this half's channel into the (still unused) transpose buffer.  The
+            // samples themselves are not kept: the FFT fetches the line again below, out of the L2 it was just pulled into
+            // (plain loads here for that reason) -- one read from HBM, and no 32 registers held across the audio chain.
+            {
+                uint32_t *q = qbuf + opaque(h) * XCH_FLOATS + opaque(l);
+#pragma unroll
+                for (int r = 0; r < 32; r++) q[32 * r] = iq_power(src[32 * r]);
+            }
+            wave_lds_sync();
+            // ---- audio, phase 2: channel A, then channel B, two frames each, all 64 lanes on one channel
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                if ((uint32_t)c >= n_sub) continue;                           // wave-uniform
+                const uint32_t cc = 2 * pair + c;
+                const ssdr_chan_consts &kc = u.consts[cc];
+                const AgcK agc_c = {kc.agc_c0, kc.agc_c1, kc.agc_knee, kc.agc_delta8, kc.hang_frames};
+                const float cal_c = kc.smeter_cal_db;
+#pragma unroll
+                for (int f = 0; f < 2; f++) {
+                    const uint32_t frame = 2 * line + f;
+                    const u32x4 *qp = reinterpret_cast<const u32x4 *>(qbuf + c * XCH_FLOATS + SSDR_FRAME * f) + 2 * opaque(lane);
+                    const u32x4 q0 = qp[0], q1 = qp[1];
+                    const uint32_t qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                    uint32_t d[8];
+                    float p[8], aud[8];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { d[j] = from_prev_lane_u(tail_q[c][j], qv[4 + j]); d[4 + j] = qv[j]; }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) tail_q[c][j] = lane63_u(qv[4 + j]);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) p[j] = (float)d[j];
+                    const float pmx = vmax3(vmax3(vmax3(p[0], p[1], p[2]), p[3], p[4]), vmax3(p[5], p[6], p[7]), 0.0f);
+                    const bool trig = wave_any(pmx >= 1073676160.0f) || tail_q[c][0] >= 0x3FFF0001u || tail_q[c][1] >= 0x3FFF0001u ||
+                                      tail_q[c][2] >= 0x3FFF0001u || tail_q[c][3] >= 0x3FFF0001u;
+                    bool clip = false;
+                    if (trig) {                                                // the exact check, on the raw samples in the FFT's layout
+                        bool mine = false;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const uint32_t w = src[32 * (16 * f + r)];
+                            const int lo = (int16_t)(w & 0xFFFFu), hi = (int32_t)w >> 16;
+                            mine = mine || lo >= 32767 || lo <= -32767 || hi >= 32767 || hi <= -32767;
+                        }
+                        clip = wave_any(mine && h == c);
+                    }
+                    demod_am<true>(p, dc[c], aud);
+                    agc_pack_store(p, aud, lane, agc_c, agc_d[c], agc_m[c], u.pcm + ((uint64_t)cc * n_frames + frame) * SSDR_FRAME + 8 * lane);
+                    rssi_flag_step(p, clip, frame, n_frames, lane, cal_c, rssi_sum[c], flag_keep[c],
+                                   u.rssi + (uint64_t)cc * n_frames, u.flags + (uint64_t)cc * n_frames);
+                }
+            }
+            wave_lds_sync();
+            if (lane < 2) {                                                    // ... and back to rest
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    if (lane != c) continue;
+                    pad(c, 0) = dc[c]; pad(c, 1) = agc_d[c];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) pad(c, 2 + i) = agc_m[c][i];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) pad(c, 10 + i) = __uint_as_float(tail_q[c][i]);
+                }
+            }
+            wave_lds_sync();
+            SCHED_FENCE();
+            // ---- waterfall: exactly as ssdr_wf_kernel<false, false>
+            uint32_t raw[32];
+            load_line(src, raw);
+            // the raw tail of the call's last frame (its samples 384..511 = this line's 896..1023) is the next call's history
+            if (line + 1 == a.n_lines && ch_ok) {
+#pragma unroll
+                for (int r = 28; r < 32; r++) u.hist[(size_t)ch * SSDR_HIST + 32 * (r - 28) + l] = raw[r];
+            }
+            last_raw31 = raw[31];
+            f32x2 z[32];
+            window_line(raw, smem, l, z);
+            SCHED_FENCE();
+            fft_line<false>(z, smem, xch_wave, h, l);
+            uint32_t qn[16];
+            quantise32(z, cal_wf, lut0, lut_mask, [&](int j, uint32_t q0, uint32_t q1) { qn[j] = q0 | (q1 << 16); });
+            float *xch = xch_wave + opaque(h) * XCH_FLOATS;
+            int16_t *x16 = reinterpret_cast<int16_t *>(xch) + opaque(l);
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                x16[32 * (j + 16)] = (int16_t)(qn[j] & 0xFFFFu);
+                x16[32 * j] = (int16_t)(qn[j] >> 16);
+            }
+            wave_lds_sync();
+            const u32x4 *x128 = reinterpret_cast<const u32x4 *>(xch);
+            int16_t *dst = a.out + ((uint64_t)line * a.n_ch + ch) * SSDR_NFFT;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32x4 v = x128[q * 32 + l];
+                if (ch_ok) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst) + q * 32 + l);
+            }
+            wave_lds_sync();
+        }
+
+        // ---- state back to HBM
+        if (a.n_lines) {
+            // the discriminator memory an AM channel leaves behind: y[511] = z1[507] of the last frame, mixed as the twin does
+            // (block 63 of the frame, element 3).  Sample 507 of that frame is the line's sample 1019 = raw[31] of lane 27.
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                if ((uint32_t)c >= n_sub) continue;
+                const uint32_t cc = 2 * pair + c;
+                const ssdr_chan_consts &kc = u.consts[cc];
+                ssdr_chan_state st = u.state[cc];
+                const uint32_t phi_last = st.phi1 + (uint32_t)(SSDR_FRAME * (n_frames - 1)) * kc.dphi1;
+                float fc, fs, qc, qs, bc, bs, cs, ss;
+                ssdr_phasor32(phi_last, fc, fs);
+                ssdr_phasor32((uint32_t)(8 * 63) * kc.dphi1, qc, qs);
+                ssdr_phasor32(kc.dphi1, cs, ss);
+                phasor_mul(fc, fs, qc, qs, bc, bs);
+#pragma unroll
+                for (int j = 0; j < 3; j++) { const float cn = fmaf(bc, cs, -(bs * ss)), sn = fmaf(bs, cs, bc * ss); bc = cn; bs = sn; }
+                const float xr = (float)(int16_t)(last_raw31 & 0xFFFFu), xi = (float)((int32_t)last_raw31 >> 16);
+                const float zr = fmaf(xr, bc, xi * bs) + 0.0f, zi = fmaf(xi, bc, -(xr * bs)) + 0.0f;
+                st.prev_re = lane_f(zr, 32 * c + 27);
+                st.prev_im = lane_f(zi, 32 * c + 27);
+                st.phi1 += (uint32_t)(SSDR_FRAME * n_frames) * kc.dphi1;
+                st.phi2 += (uint32_t)(SSDR_FRAME * n_frames) * kc.dphi2;
+                st.dc = pad(c, 0); st.agc_d = pad(c, 1);
+#pragma unroll
+                for (int i = 0; i < 8; i++) st.agc_m[i] = pad(c, 2 + i);
+                if (lane == 0) u.state[cc] = st;
+            }
+        }
+    }
+}
+
 // exhaustive quantiser self-test: every positive finite float against a binary search over T[]
 __global__ __launch_bounds__(256) void ssdr_quant_selftest_kernel(const float *thr_g, const uint2 *lut,
                                                                     unsigned long long *mismatch)
@@ -496,6 +699,17 @@ hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream
         else hipLaunchKernelGGL((ssdr_wf_kernel<false, false>), g, b, 0, stream, a);
     }
     return hipGetLastError();
+}
+
+hipError_t ssdr_launch_fused_am(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ssdr_fused_am_kernel, dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t ssdr_fused_blocks_per_cu(int *blocks)
+{
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, ssdr_fused_am_kernel, SSDR_WF_BLOCK, 0);
 }
 
 // workgroups of the waterfall kernel that are resident per CU (min over both instances)

@@ -144,6 +144,34 @@ class SsdrEngine:
         check(lib.ssdr_run_audio(self._ctx, pcm.ctypes.data, rssi.ctypes.data, 0), "ssdr_run_audio")
         return pcm, rssi
 
+    def set_fused(self, on):
+        check(lib.ssdr_set_fused(self._ctx, int(bool(on))), "ssdr_set_fused")
+
+    def run_chain(self):
+        """both stages on the current batch, results left on the device -> (lines ready, fused?)"""
+        n, fused = C.c_uint32(0), C.c_int(0)
+        self.audio_frames = self.in_frames
+        check(lib.ssdr_run_chain(self._ctx, C.byref(n), C.byref(fused)), "ssdr_run_chain")
+        return n.value, bool(fused.value)
+
+    def fetch_wf(self, lines):
+        """device results of the last waterfall run -> int16 [lines, n_ch, 1024]"""
+        out = np.empty((lines, self.n_ch, L.NFFT), np.int16)
+        ptr, n = L._P(), C.c_uint32(0)
+        check(lib.ssdr_wf_device(self._ctx, C.byref(ptr), C.byref(n)), "ssdr_wf_device")
+        check(lib.ssdr_copy_from_device(self._ctx, out.ctypes.data, ptr, out.nbytes), "ssdr_copy_from_device")
+        return out
+
+    def fetch_audio(self):
+        """device results of the last audio run -> (int16 [n_ch, n_frames*512], float32 [n_ch, n_frames])"""
+        pcm = np.empty((self.n_ch, self.audio_frames * L.FRAME), np.int16)
+        rssi = np.empty((self.n_ch, self.audio_frames), np.float32)
+        p, r = L._P(), L._P()
+        check(lib.ssdr_audio_device(self._ctx, C.byref(p), C.byref(r)), "ssdr_audio_device")
+        check(lib.ssdr_copy_from_device(self._ctx, pcm.ctypes.data, p, pcm.nbytes), "ssdr_copy_from_device")
+        check(lib.ssdr_copy_from_device(self._ctx, rssi.ctypes.data, r, rssi.nbytes), "ssdr_copy_from_device")
+        return pcm, rssi
+
     def audio_flags(self):
         """-> uint8 [n_ch, n_frames]: the SND header's ADC-overflow bit (utils_supersdr.py:1066-1067) for every frame of the
         last run_audio."""

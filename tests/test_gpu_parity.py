@@ -793,3 +793,58 @@ def test_decimating_front_end_bit_exact_vs_twin_and_oracle(S, twin, decim):
         eng.set_decimation(2)
         with pytest.raises(S.SsdrError):
             eng.feed_open(2, 3)                                        # the pipelined feed is 12 kHz only
+
+
+@pytest.mark.parametrize("n_ch", [1, 6, 7, 300])
+def test_fused_superframe_kernel_equals_the_two_kernels(S, twin, n_ch):
+    """ssdr_run_chain with ssdr_set_fused: one kernel reads each 4 KB line once for its FFT and its two audio frames (the
+    metric's configuration: full-band AM, N = 1, hop 1024).  Waterfall, PCM, RSSI, flags, carried state and FIR history
+    are bit-identical to the two-kernel path and to the twin, over several calls (state crossing them, > 64 frames in
+    one of them), odd channel counts (a half-empty wave), clipping samples; a configuration the fused kernel does not
+    cover goes through the two kernels."""
+    rng = np.random.default_rng(n_ch)
+    calls = [2, 6, 130] if n_ch <= 7 else [2, 4]
+    n_frames = sum(calls)
+    iq = O.synth_iq(n_ch, n_frames * 512, seed=500 + n_ch)
+    iq[0, 3 * 512 + 511, 1] = -32768                                  # last sample of a frame
+    if n_ch > 5:
+        iq[5, 5 * 512, 0] = 32767                                     # first sample of a frame
+    ps = [S.default_params("am", f_shift_hz=float(rng.integers(-5900, 5900)), agc_hang=int(c % 3 == 0),
+                           agc_decay=float(rng.choice([400.0, 4000.0])), wf_cal_db=float(rng.integers(-6, 7))) for c in range(n_ch)]
+    outs = {}
+    for fused in (False, True):
+        with S.SsdrEngine(n_ch) as eng:
+            eng.set_params(0, ps)
+            eng.set_fused(fused)
+            wfs, pcms, rssis, flags, pos = [], [], [], [], 0
+            for nf in calls:
+                eng.push_iq(iq[:, pos * 512:(pos + nf) * 512])
+                lines, was_fused = eng.run_chain()
+                assert was_fused == fused and lines == nf // 2
+                wfs.append(eng.fetch_wf(lines))
+                p, r = eng.fetch_audio()
+                pcms.append(p)
+                rssis.append(r)
+                flags.append(eng.audio_flags())
+                pos += nf
+            consts, taps = eng.get_consts()
+            st, hist = eng.get_state()
+        outs[fused] = (np.concatenate(wfs), np.concatenate(pcms, axis=1), np.concatenate(rssis, axis=1),
+                       np.concatenate(flags, axis=1), st.tobytes(), hist)
+    for a, b in zip(outs[False], outs[True]):
+        assert (a == b) if isinstance(a, bytes) else np.array_equal(a, b)
+    st, hist = twinlib.fresh_state(consts)
+    pcm_t, rssi_t, flags_t = twin.audio(iq, consts, taps, st, hist, want_flags=True)
+    assert np.array_equal(outs[True][1], pcm_t) and np.array_equal(outs[True][2], rssi_t) and np.array_equal(outs[True][3], flags_t)
+    assert outs[True][4] == st.tobytes() and np.array_equal(outs[True][5], hist)
+    assert np.array_equal(outs[True][0], twin.wf(iq, 1, consts["wf_cal_lin"]))
+    assert outs[True][3].sum() == (2 if n_ch > 5 else 1)
+    # not the fused kernel's configuration: a USB channel among them, or N = 3
+    with S.SsdrEngine(2) as eng:
+        eng.set_fused(True)
+        eng.set_params(0, [S.default_params("am"), S.default_params("usb")])
+        eng.push_iq(O.synth_iq(2, 1024, seed=1))
+        assert eng.run_chain() == (1, False)
+        eng.set_params(1, [S.default_params("am")])
+        eng.set_averaging(3)
+        assert eng.run_chain() == (0, False)
