@@ -303,7 +303,10 @@ int ssdr_checkpoint_load(ssdr_ctx *ctx, const void *blob);
 int ssdr_set_wf_lines(ssdr_ctx *ctx, const int16_t *wf_sum /*[lines][n_ch][1024]*/, uint32_t lines);
 int ssdr_set_pcm(ssdr_ctx *ctx, const int16_t *pcm /*[n_ch][n_frames*512]*/, uint32_t n_frames);
 int ssdr_selftest_quantiser(ssdr_ctx *ctx, uint64_t *mismatches);   /* all positive floats vs binary search */
-int ssdr_selftest_sqrt(ssdr_ctx *ctx, uint64_t *mismatches);        /* AM envelope sqrt vs IEEE sqrtf, all normal floats */
+int ssdr_selftest_sqrt(ssdr_ctx *ctx, uint64_t *mismatches);        /* AM envelope sqrt vs the device's IEEE sqrtf, exhaustively */
+/* the same two square roots (scaled form; integer-power form, valid for 0 and [1, 2^33)) on n caller-chosen arguments, for
+ * a check against an IEEE sqrt that is not the device's own */
+int ssdr_selftest_sqrt_values(ssdr_ctx *ctx, const float *in, float *out_scaled, float *out_int, uint32_t n);
 
 const char *ssdr_strerror(int code);
 const char *ssdr_last_hip_error(void);

@@ -124,6 +124,7 @@ _SIGS = {
     "ssdr_set_pcm": (C.c_int, [_P, _P, C.c_uint32]),
     "ssdr_selftest_quantiser": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ssdr_selftest_sqrt": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
+    "ssdr_selftest_sqrt_values": (C.c_int, [_P, _P, _P, _P, C.c_uint32]),
     "ssdr_strerror": (C.c_char_p, [C.c_int]),
     "ssdr_last_hip_error": (C.c_char_p, []),
     "ssdr_version": (C.c_char_p, []),

@@ -1472,6 +1472,24 @@ int ssdr_set_pcm(ssdr_ctx *c, const int16_t *pcm, uint32_t n_frames)
     return SSDR_OK;
 }
 
+int ssdr_selftest_sqrt_values(ssdr_ctx *c, const float *in, float *out_scaled, float *out_int, uint32_t n)
+{
+    if (!c || !in || !out_scaled || !out_int || n == 0) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    float *d = nullptr;
+    HIP_TRY(hipMalloc(&d, (size_t)n * 3 * sizeof(float)));
+    int rc = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(d, in, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(ssdr_launch_sqrt_values(d, d + n, d + 2 * (size_t)n, n, c->stream));
+        HIP_TRY(hipMemcpyAsync(out_scaled, d + n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(out_int, d + 2 * (size_t)n, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        return SSDR_OK;
+    }();
+    (void)hipFree(d);
+    return rc;
+}
+
 int ssdr_selftest_sqrt(ssdr_ctx *c, uint64_t *mismatches)
 {
     if (!c || !mismatches) return SSDR_EINVAL;

@@ -520,7 +520,22 @@ __global__ void ssdr_sqrt_selftest_kernel(unsigned long long *mismatch)
     if (bad) atomicAdd(mismatch, bad);
 }
 
+// the two envelope square roots on caller-chosen arguments (checked on the host against an independent IEEE sqrt)
+__global__ void ssdr_sqrt_values_kernel(const float *in, float *out_scaled, float *out_int, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_scaled[i] = ssdr_sqrt_rn(in[i]);
+    out_int[i] = ssdr_sqrt_rn_int(in[i]);
+}
+
 } // namespace
+
+hipError_t ssdr_launch_sqrt_values(const float *in, float *out_scaled, float *out_int, uint32_t n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(ssdr_sqrt_values_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, in, out_scaled, out_int, n);
+    return hipGetLastError();
+}
 
 hipError_t ssdr_launch_sqrt_selftest(unsigned long long *mismatch, hipStream_t stream)
 {

@@ -133,6 +133,7 @@ hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, int path, hipStream_t strea
 hipError_t ssdr_launch_audio_dec(const SsdrAudioArgs &a, uint32_t decim, hipStream_t stream);
 hipError_t ssdr_launch_synth(const SsdrSynthArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_sqrt_selftest(unsigned long long *mismatch, hipStream_t stream);
+hipError_t ssdr_launch_sqrt_values(const float *in, float *out_scaled, float *out_int, uint32_t n, hipStream_t stream);
 hipError_t ssdr_launch_quant_selftest(const float *thr, const uint2 *lut, unsigned long long *mismatch, hipStream_t stream);
 
 // host-side tables and parameter compilation (ssdr_tables.cpp)

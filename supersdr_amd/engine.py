@@ -390,6 +390,13 @@ class SsdrEngine:
         check(lib.ssdr_selftest_sqrt(self._ctx, C.byref(n)), "ssdr_selftest_sqrt")
         return n.value
 
+    def sqrt_values(self, x):
+        """float32[n] -> (ssdr_sqrt_rn(x), ssdr_sqrt_rn_int(x)) as the device computes them"""
+        x = np.ascontiguousarray(x, np.float32)
+        a, b = np.empty_like(x), np.empty_like(x)
+        check(lib.ssdr_selftest_sqrt_values(self._ctx, x.ctypes.data, a.ctypes.data, b.ctypes.data, len(x)), "ssdr_selftest_sqrt_values")
+        return a, b
+
     def selftest_quantiser(self):
         n = C.c_uint64(0)
         check(lib.ssdr_selftest_quantiser(self._ctx, C.byref(n)), "ssdr_selftest_quantiser")

@@ -67,6 +67,27 @@ def test_sqrt_exhaustive(S):
         assert eng.selftest_sqrt() == 0
 
 
+def test_sqrt_against_an_independent_ieee_sqrt(S):
+    """the exhaustive self-test compares with the device's own sqrtf; here 4 M arguments -- random floats over the whole
+    domain, every integer power I*I + Q*Q of a dense set of (I, Q), perfect squares and their neighbours -- against NumPy's
+    correctly rounded float32 sqrt on the host"""
+    rng = np.random.default_rng(7)
+    bits = rng.integers(1, 0x5E800000, 1 << 21, dtype=np.uint32)             # positive floats below 2^62, denormals included
+    x = bits.view(np.float32)
+    i, q = rng.integers(-32768, 32768, (2, 1 << 20))
+    pw = (i.astype(np.int64) ** 2 + q.astype(np.int64) ** 2).astype(np.float32)
+    k = rng.integers(1, 46340, 1 << 18).astype(np.int64)
+    sq = np.concatenate([(k * k).astype(np.float32), (k * k + 1).astype(np.float32), (k * k - 1).clip(1).astype(np.float32),
+                         np.array([0.0, 1.0, 2.0, 2.0 ** 31, 2.0 ** 32], np.float32)])
+    with S.SsdrEngine(1) as eng:
+        a, _ = eng.sqrt_values(x)
+        assert np.array_equal(a.view(np.uint32), np.sqrt(x).view(np.uint32))
+        for arg in (pw, sq):
+            a, b = eng.sqrt_values(arg)
+            ref = np.sqrt(arg).view(np.uint32)
+            assert np.array_equal(a.view(np.uint32), ref) and np.array_equal(b.view(np.uint32), ref)
+
+
 def test_tables_match_oracle(S, twin):
     assert np.array_equal(S.table(0), O.hann_window())
     wr, wi = O.twiddles()
