@@ -29,6 +29,10 @@
 #include "ssdr_kernels.h"
 #include "ssdr_audio_dev.h"
 
+#ifndef SSDR_WF_PAIR_MAJOR
+#define SSDR_WF_PAIR_MAJOR 0
+#endif
+
 namespace {
 
 constexpr int XPAD = 33;                       // row stride (floats) of the transpose buffer
@@ -342,7 +346,7 @@ SSDR_DEV WfItem wf_item(const SsdrWfArgs &a, uint32_t item, uint32_t n_pairs, in
 {
     WfItem it;
     uint32_t pair;
-    if (HOP) {                      // groups of a channel pair side by side: neighbouring waves share a half-line
+    if (HOP || SSDR_WF_PAIR_MAJOR) { // groups of a channel pair side by side: neighbouring waves share a half-line
         pair = item / a.n_groups;
         it.grp = item - pair * a.n_groups;
     } else {
