@@ -17,7 +17,8 @@
  *     (np.mean of float32 byte values == int sum / N; golden: tests/golden/binning.npz)
  *   - byte semantics dBm = byte - 255: utils_supersdr.py:788-789
  *   - FIR tap formula: utils_supersdr.py:334-344 (taps arrive pre-designed)
- *   - FFT / log-mag / NCO / demod / AGC arithmetic: ABSENT from the reference
+ *   - FFT / log-mag / NCO / demod / AGC arithmetic (incl. the decimating channel filter of twin_consts.decim > 1 and the
+ *     overlapping lines of twin_wf_lines): ABSENT from the reference
  *     (server-side) -> PARITY UNPINNED, defined by
  *     ssdr_oracle.py and checked against it with the guard-band / 1e-5 RMS rule.
  */

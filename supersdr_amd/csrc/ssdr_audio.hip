@@ -1,4 +1,4 @@
-// ssdr_audio.hip -- 12 kHz IQ audio chain K2 for gfx950 (MI355X), one fused kernel:
+// ssdr_audio.hip -- 12 kHz IQ audio chain K2 for gfx950 (MI355X), every stage in one kernel per frame path:
 //   int16 IQ -> NCO frequency shift -> FIR low-pass (reference tap formula,
 //   utils_supersdr.py:334-344) -> AM envelope / SSB-CW product / NBFM discriminator ->
 //   AGC -> int16 PCM + per-frame RSSI
@@ -16,7 +16,9 @@
 //   * the mixed samples go to LDS once (80 B lane stride: ds_write_b128/ds_read_b128
 //     conflict-free); the FIR walks a 16-sample register window per 8-tap block, taps
 //     are staged in LDS once per call and read back as broadcasts, 128 FMAs per 6 LDS reads
-//   * the NCO is a block NCO: one polynomial sincos per 8 samples, complex rotations in between
+//   * the NCO is a product of three full-precision phasors (frame, lane block, sample): no polynomial in the frame loop
+//     (ssdr_audio_dev.h); full-band channels skip the FIR (lane shift) and, in AM, the NCO as well (channel_frames)
+//   * ssdr_set_decimation: IQ at D * 12 kHz, the FIR decimates as D polyphase stream filters (channel_frames_dec)
 //   * the recurrences along time are exact or order-defined scans across lanes, done with DPP
 //     (row_shr / row_bcast / wave_shr: no LDS, no address arithmetic): AM DC block = affine scan,
 //     AGC envelope = (max,+) prefix max (exact), RSSI = sum scan
