@@ -443,8 +443,11 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_dec_kernel(SsdrAu
 // One kernel per frame path: the paths differ by a factor of two in registers (the general path holds a 16-sample FIR
 // window, the AM shift path fits 64 VGPRs and needs no LDS), and a wave's register file share is fixed per kernel.  The
 // host keeps the channels of a ctx sorted by path (chan_list) and launches each non-empty group.
+#ifndef SSDR_AUDIO_WAVES
+#define SSDR_AUDIO_WAVES 1
+#endif
 template <int PATH>
-__global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_kernel(SsdrAudioArgs a)
+__global__ __launch_bounds__(SSDR_AUDIO_BLOCK) __attribute__((amdgpu_waves_per_eu(SSDR_AUDIO_WAVES, 8))) void ssdr_audio_kernel(SsdrAudioArgs a)
 {
     constexpr bool FIR = PATH == PATH_GENERAL;
     __shared__ __attribute__((aligned(16))) float2 s_z[FIR ? NOCT * OCT : 1];            // 6400 B
