@@ -1013,7 +1013,7 @@ int ssdr_set_state(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan_
 struct SsdrCkptHeader {
     uint32_t magic, version, n_ch, n_avg, wf_phase, audio_started, kiwi_rate, has_play;
     uint64_t synth_sample0;
-    uint32_t hop, pad;
+    uint32_t hop, decim;
 };
 static const uint32_t kCkptMagic = 0x52445353u;          // "SSDR"
 
@@ -1022,7 +1022,8 @@ int ssdr_checkpoint_size(ssdr_ctx *c, uint64_t *bytes)
     if (!c || !bytes) return SSDR_EINVAL;
     const uint64_t n = c->n_ch;
     *bytes = sizeof(SsdrCkptHeader) + n * (sizeof(ssdr_chan_consts) + SSDR_NTAP_MAX * sizeof(float) + sizeof(ssdr_chan_state) +
-                                           SSDR_HIST * 4 + SSDR_NFFT * 2 + 8 * sizeof(double) + (SSDR_NFFT / 2) * 4);
+                                           SSDR_HIST * 4 + SSDR_NFFT * 2 + 8 * sizeof(double) + (SSDR_NFFT / 2) * 4 +
+                                           sizeof(ssdr_chan_params));
     return SSDR_OK;
 }
 
@@ -1032,8 +1033,8 @@ int ssdr_checkpoint_save(ssdr_ctx *c, void *blob)
     HIP_TRY(hipSetDevice(c->device));
     { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     const size_t n = c->n_ch;
-    SsdrCkptHeader h = {kCkptMagic, 2, c->n_ch, c->n_avg, c->wf_phase, c->audio_started ? 1u : 0u, c->kiwi_rate,
-                        c->d_play_hist ? 1u : 0u, c->synth_sample0, c->hop, 0u};
+    SsdrCkptHeader h = {kCkptMagic, 3, c->n_ch, c->n_avg, c->wf_phase, c->audio_started ? 1u : 0u, c->kiwi_rate,
+                        c->d_play_hist ? 1u : 0u, c->synth_sample0, c->hop, c->decim};
     char *p = static_cast<char *>(blob);
     memcpy(p, &h, sizeof h); p += sizeof h;
     const hipMemcpyKind d2h = hipMemcpyDeviceToHost;
@@ -1047,6 +1048,8 @@ int ssdr_checkpoint_save(ssdr_ctx *c, void *blob)
     p += n * 8 * sizeof(double);
     if (c->hop == SSDR_NFFT / 2) HIP_TRY(hipMemcpyAsync(p, c->d_wf_tail, n * (SSDR_NFFT / 2) * 4, d2h, c->stream));
     else memset(p, 0, n * (SSDR_NFFT / 2) * 4);
+    p += n * (SSDR_NFFT / 2) * 4;
+    memcpy(p, c->h_params.data(), n * sizeof(ssdr_chan_params));          // what the constants were compiled from
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
 }
@@ -1056,8 +1059,8 @@ int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob)
     if (!c || !blob) return SSDR_EINVAL;
     SsdrCkptHeader h;
     memcpy(&h, blob, sizeof h);
-    if (h.magic != kCkptMagic || h.version != 2 || h.n_ch != c->n_ch || h.n_avg < 1 || h.n_avg > 100 || h.wf_phase >= h.n_avg ||
-        (h.hop != SSDR_NFFT && h.hop != SSDR_NFFT / 2))
+    if (h.magic != kCkptMagic || h.version != 3 || h.n_ch != c->n_ch || h.n_avg < 1 || h.n_avg > 100 || h.wf_phase >= h.n_avg ||
+        (h.hop != SSDR_NFFT && h.hop != SSDR_NFFT / 2) || (h.decim != 1 && h.decim != 2 && h.decim != 4))
         return SSDR_EINVAL;
     if (!c->feed.empty()) return SSDR_ESTATE;
     HIP_TRY(hipSetDevice(c->device));
@@ -1075,6 +1078,9 @@ int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob)
     if (h.has_play && c->d_play_hist) HIP_TRY(hipMemcpyAsync(c->d_play_hist, p, n * 8 * sizeof(double), h2d, c->stream));
     if (h.hop == SSDR_NFFT / 2)
         HIP_TRY(hipMemcpyAsync(c->d_wf_tail, p + n * 8 * sizeof(double), n * (SSDR_NFFT / 2) * 4, h2d, c->stream));
+    memcpy(c->h_params.data(), p + n * 8 * sizeof(double) + n * (SSDR_NFFT / 2) * 4, n * sizeof(ssdr_chan_params));
+    c->decim = h.decim;
+    c->have_input = false;                                  // a batch pushed before the load belongs to the old streams
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->n_avg = h.n_avg;
     c->wf_phase = h.wf_phase;

@@ -719,6 +719,24 @@ def test_checkpoint_restore_continues_bit_exactly(S):
     with S.SsdrEngine(n_ch + 1) as eng:
         with pytest.raises(S.SsdrError):
             eng.restore(blob)                      # channel count mismatch
+    # the input rate and the waterfall framing travel with the blob
+    iq2 = O.synth_iq(3, 4 * 1024, seed=72)
+    with S.SsdrEngine(3) as eng:
+        eng.set_decimation(2)
+        eng.set_hop(512)
+        eng.set_params(0, [S.default_params("usb", f_shift_hz=9000.0)] * 3)
+        eng.push_iq(iq2[:, :2048])
+        eng.run_wf(), eng.run_audio()
+        blob2 = eng.checkpoint()
+        eng.push_iq(iq2[:, 2048:])
+        want2 = (eng.run_wf().copy(), eng.run_audio()[0].copy())
+    with S.SsdrEngine(3) as eng:
+        eng.restore(blob2)
+        eng.decim, eng.hop = 2, 512                # (the Python wrapper's own bookkeeping of buffer shapes)
+        eng.push_iq(iq2[:, 2048:])
+        got2 = (eng.run_wf().copy(), eng.run_audio()[0].copy())
+        assert int(eng.get_consts()[0]["decim"][0]) == 2
+    assert np.array_equal(want2[0], got2[0]) and np.array_equal(want2[1], got2[1]) and want2[0].shape[0] == 4
 
 
 @pytest.mark.parametrize("n_ch,n_avg", [(1, 1), (5, 1), (6, 3), (33, 10)])
