@@ -419,6 +419,23 @@ def main():
             extra[wl] = {"workload": WORKLOAD_TEXT[wl], "value": e["value"], "unit": "rt_channels", "ms_per_step": e["ms_per_step"],
                          "steps": max(20, args.steps // 2), "channels_per_gpu": ch, "superframes_per_step": sf, "averaging_n": e["n_avg"],
                          "rooflines": [roofline(s, stage_traffic(tr, s), tsrc) for s in e["stages"].values()]}
+        # variants of the default workload that the design discusses, timed by the same run:
+        # both stages side by side on two streams; the fused superframe kernel; the waterfall at the reference's line rate
+        nst = max(20, args.steps // 3)
+        ch, sf = WORKLOADS["full"][0], WORKLOADS["full"][1]
+        for key, kw in (("full_concurrent", dict(concurrent=1)), ("full_fused", dict(fused=1))):
+            e = measure(S, L, torch, rdv, rank, world, local_rank, "full", ch, sf, nst, 2, 0.5, **kw)
+            b = ch * sf * 8192.0
+            extra[key] = {"workload": WORKLOAD_TEXT["full"] + (", waterfall and audio stage side by side (--concurrent 1)" if "concurrent" in kw
+                                                             else ", one fused kernel (--fused 1)"),
+                          "value": e["value"], "unit": "rt_channels", "ms_per_step": e["ms_per_step"], "steps": nst,
+                          "chain_GBps": b / e["ms_per_step"] / 1e6, "chain_frac": b / e["ms_per_step"] / 1e6 / HBM_PEAK_GBPS}
+        ch, sf = WORKLOADS["wf"][0], WORKLOADS["wf"][1]
+        e = measure(S, L, torch, rdv, rank, world, local_rank, "wf", ch, sf, nst, 2, 0.5, hop=512)
+        tr, tsrc = pmc_traffic("wf", ch, sf, 512)
+        extra["wf_hop512"] = {"workload": WORKLOAD_TEXT["wf"] + ", hop 512 (23.4 lines/s)", "value": e["value"], "unit": "rt_channels",
+                              "ms_per_step": e["ms_per_step"], "steps": nst, "lines_per_s": e["stages"]["wf"]["lines_per_launch"] / e["ms_per_step"] * 1e3,
+                              "rooflines": [roofline(s, stage_traffic(tr, s), tsrc) for s in e["stages"].values()]}
         out["extra"] = extra
 
     if rank == 0:
