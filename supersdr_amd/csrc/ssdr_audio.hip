@@ -62,6 +62,7 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
 #pragma unroll
     for (int i = 0; i < 8; i++) agc_m[i] = st.agc_m[i];
 
+    const bool untuned = dphi1 == 0 && phi1 == 0;         // wave-uniform; stays true for the whole call (phi1 += 512 * 0)
     const uint32_t *hist = a.hist + (size_t)ch * SSDR_HIST;
     float2 tail_z[4];                                   // PATH_DELAY4: mixed samples -4..-1 (wave-uniform)
     uint32_t tail_q[4];                                 // PATH_AM_RAW: I*I + Q*Q of samples -4..-1 (wave-uniform)
@@ -162,9 +163,20 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
             float yr[8], yi[8];
             float amax = 0.0f;
             float2 A[8], B[8];
-            float bc, bs;
-            nco_block(n1, f, bc, bs);
-            mix8<true>(rw, bc, bs, cs1, ss1, A, amax);
+            if (untuned) {
+                // the channel sits at the centre of its IQ band and its phase never left zero: every phasor of the NCO is
+                // exactly (1, 0) and x * (1 - j0) == x bit for bit -- convert, do not mix
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const float xr = (float)(int16_t)(rw[j] & 0xFFFFu), xi = (float)((int32_t)rw[j] >> 16);
+                    amax = vmax3_abs(amax, xr, xi);
+                    A[j] = make_float2(xr, xi);
+                }
+            } else {
+                float bc, bs;
+                nco_block(n1, f, bc, bs);
+                mix8<true>(rw, bc, bs, cs1, ss1, A, amax);
+            }
             clip = wave_any(amax >= 32767.0f);
             if constexpr (PATH == PATH_DELAY4) {
                 // y[n] = z1[n - 4]: the previous lane's last four samples, then this lane's first four

@@ -234,6 +234,43 @@ def test_full_band_paths_mode_switch_and_adc_overflow_flags(S, twin):
     assert rms.max() < PCM_RMS_TOL
 
 
+def test_untuned_channels_skip_the_mixer_bit_exactly(S, twin):
+    """f_shift = 0 (and, for SSB, a passband centred on 0): the NCO's phasors are exactly (1, 0), the kernel converts
+    instead of mixing -- same bits as the twin, which mixes; a retune mid-stream leaves the path, a retune back with
+    a phase that is no longer zero does not re-enter it."""
+    n_ch, n_frames = 6, 6
+    iq = O.synth_iq(n_ch, n_frames * 512, seed=66)
+    iq[2, 700, 1] = 32767
+    ps = [S.default_params("am", f_shift_hz=0.0, low_cut=-3000.0, high_cut=3000.0),
+          S.default_params("nbfm", f_shift_hz=0.0, low_cut=-4000.0, high_cut=4000.0),
+          S.default_params("nbfm", f_shift_hz=0.0),                                  # full band: the lane-shift path
+          S.default_params("usb", f_shift_hz=0.0, low_cut=-1500.0, high_cut=1500.0),  # centred passband: both NCOs idle
+          S.default_params("am", f_shift_hz=100.0, low_cut=-3000.0, high_cut=3000.0),
+          S.default_params("cw", f_shift_hz=-600.0)]                                 # f_shift + f_bc = 0, the re-mixer runs
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.push_iq(iq[:, : 2 * 512])
+        p1, r1 = eng.run_audio()
+        f1 = eng.audio_flags()
+        c1, t1 = eng.get_consts()
+        eng.set_params(0, [S.default_params("am", f_shift_hz=250.0, low_cut=-3000.0, high_cut=3000.0)])
+        eng.push_iq(iq[:, 2 * 512: 4 * 512])
+        p2, r2 = eng.run_audio()
+        c2, t2 = eng.get_consts()
+        eng.set_params(0, [ps[0]])                                                   # back to 0 Hz, phase now non-zero
+        eng.push_iq(iq[:, 4 * 512:])
+        p3, r3 = eng.run_audio()
+        st_g, hist_g = eng.get_state()
+    assert [int(x) for x in c1["dphi1"]][:4] == [0, 0, 0, 0] and int(c1["dphi1"][5]) == 0 and int(c1["dphi1"][4]) != 0
+    st, hist = twinlib.fresh_state(c1)
+    q1, s1, g1 = twin.audio(iq[:, : 2 * 512], c1, t1, st, hist, want_flags=True)
+    q2, s2 = twin.audio(iq[:, 2 * 512: 4 * 512], c2, t2, st, hist)
+    q3, s3 = twin.audio(iq[:, 4 * 512:], c1, t1, st, hist)
+    assert np.array_equal(p1, q1) and np.array_equal(r1, s1) and np.array_equal(f1, g1) and f1[2, 1] == 1
+    assert np.array_equal(p2, q2) and np.array_equal(p3, q3) and np.array_equal(r3, s3)
+    assert st_g.tobytes() == st.tobytes() and np.array_equal(hist_g, hist) and int(st["phi1"][0]) != 0
+
+
 def test_audio_state_carry_across_calls(S, twin):
     """frame-by-frame pushes == one multi-frame push (FIR history, NCO phase, DC, AGC all carried)"""
     n_ch, n_frames = 8, 6
