@@ -189,7 +189,42 @@ static uint32_t bitrev10(uint32_t v)
  *     a = (fma( wr, vr, sr), fma(wr, vi, si))        = u + w v
  *     b = (fma(  2, ur, -ar), fma(2, ui, -ai))       = 2u - a
  * Stages 1..5 use the exact forms a = u + v, b = u - v for w = 1 and a = u + (vi, -vr), b = u - (vi, -vr)
- * for w = -j; stages 6..10 always use the general form (table values (1,0) and (0,-1) are exact). */
+ * for w = -j; stages 6..10 always use the general form (table values (1,0) and (0,-1) are exact).
+ * Stage 1 comes fused with the window: it pairs sample n with sample n + 512, and with x, x' the raw samples and w, w'
+ * their window values  a = fma(x', w', x w),  b = fma(-x', w', x w)  (the second product is not rounded on its own). */
+static void fft1024_windowed(const int16_t *iq, const float *win, float *re, float *im, const float *wr, const float *wi)
+{
+    for (uint32_t i = 0; i < NFFT; i += 2) {           /* bit-reversed order: positions i, i+1 hold samples n, n + 512 */
+        const uint32_t n = bitrev10(i);
+        const float tr = (float)iq[2 * n] * win[n], ti = (float)iq[2 * n + 1] * win[n];
+        const float xr = (float)iq[2 * (n + 512)], xi = (float)iq[2 * (n + 512) + 1], w2 = win[n + 512];
+        re[i] = fmaf(xr, w2, tr);      im[i] = fmaf(xi, w2, ti);
+        re[i + 1] = fmaf(-xr, w2, tr); im[i + 1] = fmaf(-xi, w2, ti);
+    }
+    for (int s = 2; s <= 10; s++) {
+        int half = 1 << (s - 1), step = NFFT >> s;
+        for (int blk = 0; blk < NFFT; blk += 2 * half) {
+            for (int k = 0; k < half; k++) {
+                int m = k * step, i = blk + k, j = i + half;
+                float ur = re[i], ui = im[i], vr = re[j], vi = im[j];
+                if (s <= 5 && m == 0) {
+                    re[i] = ur + vr; im[i] = ui + vi;
+                    re[j] = ur - vr; im[j] = ui - vi;
+                } else if (s <= 5 && m == 256) {
+                    re[i] = ur + vi; im[i] = ui - vr;
+                    re[j] = ur - vi; im[j] = ui + vr;
+                } else {
+                    float a = wr[m], b = wi[m];
+                    float sr = fmaf(-b, vi, ur), si = fmaf(b, vr, ui);
+                    float ar = fmaf(a, vr, sr), ai = fmaf(a, vi, si);
+                    re[i] = ar; im[i] = ai;
+                    re[j] = fmaf(2.0f, ur, -ar); im[j] = fmaf(2.0f, ui, -ai);
+                }
+            }
+        }
+    }
+}
+/* the plain transform of already windowed data (kept for reference: twin_fft_plain) */
 static void fft1024(float *re, float *im, const float *wr, const float *wi)
 {
     for (uint32_t i = 0; i < NFFT; i++) {
@@ -223,16 +258,15 @@ static void fft1024(float *re, float *im, const float *wr, const float *wi)
     }
 }
 
+/* the plain radix-2 transform of caller-supplied (already windowed) data, in place */
+void twin_fft_plain(float *re, float *im, const float *wr, const float *wi) { fft1024(re, im, wr, wi); }
+
 /* one line: int16 IQ[1024][2] -> bytes[1024], ascending frequency (fftshift) */
 void twin_wf_line(const int16_t *iq, const float *win, const float *wr, const float *wi,
                   const float *thr, float cal_lin, uint8_t *out)
 {
     float re[NFFT], im[NFFT];
-    for (int n = 0; n < NFFT; n++) {
-        re[n] = (float)iq[2 * n] * win[n];
-        im[n] = (float)iq[2 * n + 1] * win[n];
-    }
-    fft1024(re, im, wr, wi);
+    fft1024_windowed(iq, win, re, im, wr, wi);
     for (int k = 0; k < NFFT; k++) {
         float p = fmaf(re[k], re[k], im[k] * im[k]) * cal_lin;
         out[(k + 512) & 1023] = (uint8_t)quantise(p, thr);
@@ -243,11 +277,7 @@ void twin_wf_line(const int16_t *iq, const float *win, const float *wr, const fl
 void twin_wf_power(const int16_t *iq, const float *win, const float *wr, const float *wi, float cal_lin, float *p_out)
 {
     float re[NFFT], im[NFFT];
-    for (int n = 0; n < NFFT; n++) {
-        re[n] = (float)iq[2 * n] * win[n];
-        im[n] = (float)iq[2 * n + 1] * win[n];
-    }
-    fft1024(re, im, wr, wi);
+    fft1024_windowed(iq, win, re, im, wr, wi);
     for (int k = 0; k < NFFT; k++) p_out[k] = fmaf(re[k], re[k], im[k] * im[k]) * cal_lin;
 }
 

@@ -225,9 +225,12 @@ SSDR_DEV void load_line_halves(const uint32_t *__restrict__ older, const uint32_
     for (int r = 0; r < 16; r++) raw[16 + r] = newer[32 * r];
 }
 
-// raw int16 IQ dwords of one line -> windowed complex samples in a-index (bit-reversed) order.
+// raw int16 IQ dwords of one line -> windowed complex samples in a-index (bit-reversed) order, with FFT stage 1 folded in.
 // The window is symmetric, w[n] = w[1024-n]: samples of the second half read the same 513-entry table
 // backwards from a second per-lane base.
+// Stage 1 pairs sample n with sample n + 512 (registers r and r + 16 of a lane), twiddle 1: a = x w + x' w', b = x w - x' w'.
+// The second product is not rounded on its own: t = x w, a = fma(x', w', t), b = fma(-x', w', t) -- three operations per
+// pair and component instead of four (the twin states the same).
 SSDR_DEV void window_line(const uint32_t (&raw)[32], const unsigned char *smem, int l, f32x2 (&z)[32])
 {
     const int ll = opaque(l);
@@ -239,10 +242,14 @@ SSDR_DEV void window_line(const uint32_t (&raw)[32], const unsigned char *smem, 
     for (int r = 0; r < 32; r++) w[r] = (r < 16) ? win_up[32 * r] : win_dn[32 * (32 - r)];
     SCHED_FENCE();
 #pragma unroll
-    for (int r = 0; r < 32; r++) {
-        const f32x2 x = {(float)(int16_t)(raw[r] & 0xFFFFu), (float)((int32_t)raw[r] >> 16)};
-        z[brev5(r)] = x * w[r];
-        if ((r & 7) == 7) SCHED_FENCE();
+    for (int r = 0; r < 16; r++) {
+        const f32x2 xa = {(float)(int16_t)(raw[r] & 0xFFFFu), (float)((int32_t)raw[r] >> 16)};
+        const f32x2 xb = {(float)(int16_t)(raw[r + 16] & 0xFFFFu), (float)((int32_t)raw[r + 16] >> 16)};
+        const f32x2 t = xa * w[r];
+        const float wb = w[r + 16];
+        z[brev5(r)] = f32x2{fmaf(xb.x, wb, t.x), fmaf(xb.y, wb, t.y)};
+        z[brev5(r) + 1] = f32x2{fmaf(-xb.x, wb, t.x), fmaf(-xb.y, wb, t.y)};
+        if ((r & 3) == 3) SCHED_FENCE();
     }
 }
 
@@ -250,8 +257,7 @@ SSDR_DEV void window_line(const uint32_t (&raw)[32], const unsigned char *smem, 
 template <bool TIGHT>
 SSDR_DEV void fft_line(f32x2 (&z)[32], const unsigned char *smem, float *xch_wave, int h, int l)
 {
-    stage_const<1>(z);
-    stage_const<2>(z);
+    stage_const<2>(z);                             // stage 1 came with the window (window_line)
     stage_const<3>(z);
     stage_const<4>(z);
     stage_const<5>(z);
