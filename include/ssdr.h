@@ -168,6 +168,10 @@ typedef struct ssdr_db2col_chan {
 /* spectrum_db2col for every channel and every line produced by the last ssdr_run_wf:
  * color_out float32 [lines][n_ch][1024] in 0..254 (wf_color), chans[] updated in place (host memory). */
 int ssdr_run_db2col(ssdr_ctx *ctx, ssdr_db2col_chan *chans, float *color_out, int out_is_device);
+/* spectrum_db2col of ONE line of one receiver that did its own time binning (a client whose N differs from the hub's):
+ * wf_sum int16 [1024] = sum of n_avg byte lines, chan in/out, color_out float32 [1024] (all host memory).  Touches nothing
+ * the other channels see: not the lines of the last ssdr_run_wf, not the device copy of wf_data. */
+int ssdr_db2col_line(ssdr_ctx *ctx, const int16_t *wf_sum, uint32_t n_avg, ssdr_db2col_chan *chan, float *color_out);
 
 /* kiwi_sound.play_buffer (utils_supersdr.py:1106-1148) for every channel and every frame of the last
  * ssdr_run_audio: volume, x4 interpolation with filtering(KIWI_RATE/2, AUDIO_RATE) (:999), pan^2,
@@ -247,24 +251,46 @@ int ssdr_adpcm_decode(ssdr_ctx *ctx, const uint8_t *data, uint32_t n_streams, ui
  *                                          header strip / byte swap runs on the device
  *   ssdr_feed_slot(ctx, &in)               pinned int16 [n_ch][n_frames*512][2] (or bodies) to fill; SSDR_ESTATE if all slots are in flight
  *   ssdr_feed_submit(ctx)                  queue the slot: copy-in, both kernels, copy-out; returns at once
- *   ssdr_feed_collect(ctx, &wf, &lines, &pcm, &rssi, &wire_rssi)
+ *   ssdr_feed_collect(ctx, &wf, &lines, &pcm, &rssi, &wire_rssi, &flags, &n_avg)
  *                                          wait for the OLDEST submitted batch; pinned int16 [lines][n_ch][1024], int16
  *                                          [n_ch][n_frames*512], float [n_ch][n_frames]; wire_rssi float [n_ch][n_frames] =
- *                                          0.1*smeter - 127 of the SND headers (NULL without SSDR_FEED_WIRE); valid until
- *                                          that slot is handed out again
+ *                                          0.1*smeter - 127 of the SND headers (NULL without SSDR_FEED_WIRE); flags uint8
+ *                                          [n_ch][n_frames] ADC overflow per frame (ssdr_audio_flags); n_avg = the averaging N
+ *                                          that was in force when the batch was submitted; valid until that slot is handed
+ *                                          out again.  Any pointer may be NULL.
  *   ssdr_feed_close(ctx)
- * The post-processing entry points (db2col, playbuffer, trace) keep referring to the last ssdr_run_* batch, not to fed ones. */
+ * flags = SSDR_FEED_POST: every batch also goes through the reference's post-processing on the device, in the same slot
+ * pipeline -- spectrum_db2col of its waterfall lines and play_buffer of its PCM frames (what ssdr_run_db2col /
+ * ssdr_run_playbuffer do for an un-pipelined batch, state carried from batch to batch the same way):
+ *   ssdr_feed_post(ctx, chans, play)       display state for the batches submitted from now on: ssdr_db2col_chan [n_ch]
+ *                                          and ssdr_play_chan [n_ch] (host, copied; NULL keeps what was set before)
+ *   ssdr_feed_collect_post(ctx, &color, &chans, &play, &mono)
+ *                                          of the batch ssdr_feed_collect returned last: float32 [lines][n_ch][1024]
+ *                                          wf_color, ssdr_db2col_chan [n_ch] as spectrum_db2col left them, int16
+ *                                          [n_ch][n_frames*L][2] (L = ssdr_playbuffer_frame_len), int16 [n_ch][n_frames*L]
+ *                                          mono block (NULL unless ssdr_set_recording)
+ * Without SSDR_FEED_POST the post-processing entry points keep referring to the last ssdr_run_* batch, not to fed ones. */
 #define SSDR_FEED_WIRE 1u
+#define SSDR_FEED_POST 2u
 int ssdr_feed_open(ssdr_ctx *ctx, uint32_t n_frames, uint32_t depth, uint32_t flags);
 int ssdr_feed_slot(ssdr_ctx *ctx, void **host_in);
 int ssdr_feed_submit(ssdr_ctx *ctx);
-int ssdr_feed_collect(ssdr_ctx *ctx, int16_t **wf_sum, uint32_t *lines, int16_t **pcm, float **rssi, float **wire_rssi);
+int ssdr_feed_collect(ssdr_ctx *ctx, int16_t **wf_sum, uint32_t *lines, int16_t **pcm, float **rssi, float **wire_rssi,
+                      uint8_t **flags, uint32_t *n_avg);
+int ssdr_feed_post(ssdr_ctx *ctx, const ssdr_db2col_chan *chans, const ssdr_play_chan *play);
+int ssdr_feed_collect_post(ssdr_ctx *ctx, float **color, ssdr_db2col_chan **chans, int16_t **play, int16_t **mono);
 int ssdr_feed_close(ssdr_ctx *ctx);
 
 /* -- device-resident results of the last run_* (for zero-copy consumers and bench) */
 int ssdr_wf_device(ssdr_ctx *ctx, int16_t **ptr, uint32_t *lines);
 int ssdr_copy_from_device(ssdr_ctx *ctx, void *host_dst, const void *device_src, uint64_t bytes);   /* ordered behind the ctx's work */
 int ssdr_audio_device(ssdr_ctx *ctx, int16_t **pcm, float **rssi);
+
+/* Position-weighted 64-bit checksums of the device-resident results of the last ssdr_run_wf / ssdr_run_audio (or
+ * ssdr_run_chain): sums[0] waterfall sums, sums[1] PCM, sums[2] RSSI bit patterns.  Integer arithmetic only, so equal
+ * results give equal checksums on any GPU and in any launch shape -- the per-rank parity hash of the multi-GPU bench
+ * (SURVEY.md 8e): a rank's channel block must hash to what a one-rank run of the same block hashes to. */
+int ssdr_output_checksum(ssdr_ctx *ctx, uint64_t sums[3]);
 
 /* -- measurement */
 int ssdr_set_stream(ssdr_ctx *ctx, void *hip_stream);           /* NULL = ctx's own stream */
@@ -298,7 +324,13 @@ int ssdr_set_state(ssdr_ctx *ctx, uint32_t first, uint32_t count, const ssdr_cha
  * keeps its state. */
 int ssdr_checkpoint_size(ssdr_ctx *ctx, uint64_t *bytes);
 int ssdr_checkpoint_save(ssdr_ctx *ctx, void *blob);
-int ssdr_checkpoint_load(ssdr_ctx *ctx, const void *blob);
+/* bytes must equal ssdr_checkpoint_size; the header and every channel's compiled constants are validated before anything
+ * is touched (SSDR_EINVAL for a short, foreign or damaged blob).  The blob carries its own hop, decimation and N:
+ * read them back with ssdr_get_config. */
+int ssdr_checkpoint_load(ssdr_ctx *ctx, const void *blob, uint64_t bytes);
+/* what the ctx currently runs with (any pointer may be NULL): waterfall hop (ssdr_set_hop), input decimation
+ * (ssdr_set_decimation), averaging N (ssdr_set_averaging), play-back rate (ssdr_set_kiwi_rate) */
+int ssdr_get_config(ssdr_ctx *ctx, uint32_t *hop, uint32_t *decim, uint32_t *averaging, uint32_t *kiwi_rate);
 /* inject results as if ssdr_run_wf / ssdr_run_audio had produced them (golden-vector tests of the post-processing) */
 int ssdr_set_wf_lines(ssdr_ctx *ctx, const int16_t *wf_sum /*[lines][n_ch][1024]*/, uint32_t lines);
 int ssdr_set_pcm(ssdr_ctx *ctx, const int16_t *pcm /*[n_ch][n_frames*512]*/, uint32_t n_frames);

@@ -99,7 +99,10 @@ _SIGS = {
     "ssdr_feed_open": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "ssdr_feed_slot": (C.c_int, [_P, C.POINTER(_P)]),
     "ssdr_feed_submit": (C.c_int, [_P]),
-    "ssdr_feed_collect": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
+    "ssdr_feed_collect": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
+                                    C.POINTER(_P), C.POINTER(C.c_uint32)]),
+    "ssdr_feed_post": (C.c_int, [_P, C.POINTER(Db2colChan), C.POINTER(PlayChan)]),
+    "ssdr_feed_collect_post": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
     "ssdr_feed_close": (C.c_int, [_P]),
     "ssdr_copy_from_device": (C.c_int, [_P, _P, _P, C.c_uint64]),
     "ssdr_wf_device": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32)]),
@@ -119,7 +122,10 @@ _SIGS = {
     "ssdr_set_state": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, _P]),
     "ssdr_checkpoint_size": (C.c_int, [_P, C.POINTER(C.c_uint64)]),
     "ssdr_checkpoint_save": (C.c_int, [_P, _P]),
-    "ssdr_checkpoint_load": (C.c_int, [_P, _P]),
+    "ssdr_checkpoint_load": (C.c_int, [_P, _P, C.c_uint64]),
+    "ssdr_get_config": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "ssdr_db2col_line": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(Db2colChan), _P]),
+    "ssdr_output_checksum": (C.c_int, [_P, C.POINTER(C.c_uint64 * 3)]),
     "ssdr_set_wf_lines": (C.c_int, [_P, _P, C.c_uint32]),
     "ssdr_set_pcm": (C.c_int, [_P, _P, C.c_uint32]),
     "ssdr_selftest_quantiser": (C.c_int, [_P, C.POINTER(C.c_uint64)]),

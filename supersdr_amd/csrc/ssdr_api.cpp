@@ -84,11 +84,26 @@ struct ssdr_ctx {
         float *d_rssi = nullptr;
         hipEvent_t ev_in = nullptr, ev_run = nullptr, ev_out = nullptr;
         uint32_t lines = 0;
+        uint32_t n_avg = 1;                              // averaging N in force when the batch was submitted
+        uint8_t *d_flags = nullptr, *h_flags = nullptr;  // ADC-overflow flag per frame of this batch
+        // SSDR_FEED_POST: spectrum_db2col / play_buffer of this batch
+        float *d_color = nullptr, *h_color = nullptr;
+        ssdr_db2col_chan *d_dbchan = nullptr, *h_dbchan = nullptr;
+        ssdr_play_chan *h_playchan = nullptr;
+        int16_t *d_play = nullptr, *h_play = nullptr, *d_mono = nullptr, *h_mono = nullptr;
+        bool has_mono = false;
     };
     std::vector<FeedSlot> feed;
     uint32_t feed_frames = 0, feed_head = 0, feed_tail = 0, feed_inflight = 0;
     bool feed_taken = false;                             // slot at feed_head handed to the caller, not yet submitted
     bool feed_wire = false;                              // slots hold SND bodies (kiwi/client.py:443-454), unpacked on the device
+    bool feed_post = false;                              // SSDR_FEED_POST: db2col + play_buffer in the slot pipeline
+    std::vector<ssdr_db2col_chan> feed_dbchan;           // display state for the next submits (ssdr_feed_post)
+    std::vector<ssdr_play_chan> feed_playchan;
+    int feed_last = -1;                                  // slot ssdr_feed_collect returned last
+    int16_t *d_line1 = nullptr;                          // ssdr_db2col_line: one line, its display state, its colours
+    ssdr_db2col_chan *d_dbchan1 = nullptr;
+    float *d_color1 = nullptr;
     hipStream_t feed_s_in = nullptr, feed_s_out = nullptr;
     // measurement
     bool profiling = false;
@@ -202,7 +217,7 @@ void ssdr_destroy(ssdr_ctx *c)
     void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_wf_tail, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_flags, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
                     c->d_play_taps, c->d_play_hist, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
-                    c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono};
+                    c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -290,6 +305,8 @@ int ssdr_reset_state(ssdr_ctx *c, uint32_t first, uint32_t count)
     HIP_TRY(hipMemsetAsync(c->d_hist + (size_t)first * SSDR_HIST, 0, (size_t)count * SSDR_HIST * 4, c->stream));
     for (int i = 0; i < 2; i++)
         HIP_TRY(hipMemsetAsync(c->d_wf_acc[i] + (size_t)first * SSDR_NFFT, 0, (size_t)count * SSDR_NFFT * 2, c->stream));
+    if (c->d_wf_tail)        // hop 512: the half-line before the stream is silence again (also after a change of the input rate)
+        HIP_TRY(hipMemsetAsync(c->d_wf_tail + (size_t)first * (SSDR_NFFT / 2), 0, (size_t)count * (SSDR_NFFT / 2) * 4, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (first == 0 && count == c->n_ch) { c->wf_phase = 0; c->synth_sample0 = 0; c->audio_started = false; }
     return SSDR_OK;
@@ -451,6 +468,16 @@ int ssdr_set_hop(ssdr_ctx *c, uint32_t hop)
     }
     c->hop = hop;
     c->wf_phase = 0;                                          // a change of framing restarts the averaging group
+    return SSDR_OK;
+}
+
+int ssdr_get_config(ssdr_ctx *c, uint32_t *hop, uint32_t *decim, uint32_t *averaging, uint32_t *kiwi_rate)
+{
+    if (!c) return SSDR_EINVAL;
+    if (hop) *hop = c->hop;
+    if (decim) *decim = c->decim;
+    if (averaging) *averaging = c->n_avg;
+    if (kiwi_rate) *kiwi_rate = c->kiwi_rate;
     return SSDR_OK;
 }
 
@@ -721,8 +748,14 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
     }
     // one kernel per non-empty path: the first on the stream itself, the others beside it on their own streams
     // (fork and join by events); the stage is timed between two events on `s`
+    if (c->decim > 1 && (c->path_n[SSDR_PATH_DELAY4] || c->path_n[SSDR_PATH_AM_RAW]))
+        return SSDR_ESTATE;                   // the decimating kernel is the general path: no channel may be compiled for a shift path
     if ((rc = timed_begin(c, s)) != SSDR_OK) return rc;
-    {
+    if (c->decim > 1) {                       // ONE kernel over all channels (it takes no channel list)
+        a.chan_list = c->d_chan_list;
+        a.list_n = c->n_ch;
+        HIP_TRY(ssdr_launch_audio_dec(a, c->decim, s));
+    } else {
         int n_paths = 0, n_side = 0;
         for (int p = 0; p < SSDR_PATH_COUNT; p++) n_paths += c->path_n[p] != 0;
         const bool side = n_paths > 1 && !c->audio_serial;
@@ -732,9 +765,7 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
             if (!c->path_n[p]) continue;
             a.chan_list = c->d_chan_list + c->path_off[p];
             a.list_n = c->path_n[p];
-            if (c->decim > 1) {                     // one kernel: every channel takes the decimating FIR path
-                HIP_TRY(ssdr_launch_audio_dec(a, c->decim, s));
-            } else if (first || !side) {
+            if (first || !side) {
                 HIP_TRY(ssdr_launch_audio(a, p, s));
             } else {
                 hipStream_t ps = c->path_stream[n_side];
@@ -803,6 +834,31 @@ int ssdr_audio_flags(ssdr_ctx *c, uint8_t *flags_out, int out_is_device)
     return SSDR_OK;
 }
 
+// play_buffer's constant tables and carried history (utils_supersdr.py:999-1005), created at first use
+static int ensure_play(ssdr_ctx *c)
+{
+    if (!c->d_play) {
+        HIP_TRY(hipMalloc(&c->d_play, (size_t)c->n_ch * sizeof(ssdr_play_chan)));
+        HIP_TRY(hipMalloc(&c->d_play_taps, 33 * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_play_hist, (size_t)c->n_ch * 8 * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_play_rs_taps, sizeof(SSDR_RS_TAPS)));
+        HIP_TRY(hipMemsetAsync(c->d_play_hist, 0, (size_t)c->n_ch * 8 * sizeof(double), c->stream));   // old_buffer = zeros (:1005)
+        if (c->pending_play_hist.size() == (size_t)c->n_ch * 8) {
+            HIP_TRY(hipMemcpyAsync(c->d_play_hist, c->pending_play_hist.data(), (size_t)c->n_ch * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->pending_play_hist.clear();
+        }
+        double h[64];
+        if (ssdr_design_lowpass(SSDR_RATE / 2.0, 48000.0, 63, h) != 33) return SSDR_EINVAL;             // filtering(KIWI_RATE/2, AUDIO_RATE)
+        HIP_TRY(hipMemcpyAsync(c->d_play_taps, h, 33 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->d_play_rs_taps, SSDR_RS_TAPS, sizeof(SSDR_RS_TAPS), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return SSDR_OK;
+}
+
+static int wfdata_feed(ssdr_ctx *c, const float *color, uint32_t lines);
+
 // ---- pipelined host feed ------------------------------------------------------------------------------------
 // Three streams: host->device copy of batch k+1, the two kernels of batch k, device->host copy of batch k-1.
 // The kernels stay on the ctx stream, in batch order, so the per-channel state and the waterfall's partial sums
@@ -816,9 +872,9 @@ int ssdr_feed_close(ssdr_ctx *c)
     if (c->feed_s_in) (void)hipStreamSynchronize(c->feed_s_in);
     if (c->feed_s_out) (void)hipStreamSynchronize(c->feed_s_out);
     for (auto &s : c->feed) {
-        void *hp[] = {s.h_in, s.h_wf, s.h_pcm, s.h_rssi, s.h_wire_rssi};
+        void *hp[] = {s.h_in, s.h_wf, s.h_pcm, s.h_rssi, s.h_wire_rssi, s.h_flags, s.h_color, s.h_dbchan, s.h_playchan, s.h_play, s.h_mono};
         for (void *p : hp) if (p) (void)hipHostFree(p);
-        void *dp[] = {s.d_in, s.d_wf, s.d_pcm, s.d_rssi, s.d_wire, s.d_wire_rssi};
+        void *dp[] = {s.d_in, s.d_wf, s.d_pcm, s.d_rssi, s.d_wire, s.d_wire_rssi, s.d_flags, s.d_color, s.d_dbchan, s.d_play, s.d_mono};
         for (void *p : dp) if (p) (void)hipFree(p);
         hipEvent_t ev[] = {s.ev_in, s.ev_run, s.ev_out};
         for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
@@ -828,14 +884,27 @@ int ssdr_feed_close(ssdr_ctx *c)
     if (c->feed_s_out) { (void)hipStreamDestroy(c->feed_s_out); c->feed_s_out = nullptr; }
     c->feed_frames = c->feed_head = c->feed_tail = c->feed_inflight = 0;
     c->feed_taken = false;
+    c->feed_post = false;
+    c->feed_last = -1;
     return SSDR_OK;
 }
 
 int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth, uint32_t flags)
 {
-    if (!c || n_frames == 0 || (n_frames & 1u) || depth < 2 || depth > 16 || (flags & ~(uint32_t)SSDR_FEED_WIRE)) return SSDR_EINVAL;
+    if (!c || n_frames == 0 || (n_frames & 1u) || depth < 2 || depth > 16 || (flags & ~(uint32_t)(SSDR_FEED_WIRE | SSDR_FEED_POST))) return SSDR_EINVAL;
     if (!c->feed.empty() || c->concurrent || c->decim != 1) return SSDR_ESTATE;      // the feed's slots are sized for 12 kHz IQ
     HIP_TRY(hipSetDevice(c->device));
+    const bool post = (flags & SSDR_FEED_POST) != 0;
+    if (post) { int rcp = ensure_play(c); if (rcp != SSDR_OK) return rcp; }
+    c->feed_post = post;
+    if (post && c->feed_dbchan.size() != c->n_ch) {          // the reference's initial display state (utils_supersdr.py:599-603, 921, 945)
+        ssdr_db2col_chan d;
+        memset(&d, 0, sizeof d);
+        d.auto_scale = 1; d.low_clip_db = -120.0f; d.high_clip_db = -60.0f; d.dynamic_range = 40.0f;
+        c->feed_dbchan.assign(c->n_ch, d);
+        ssdr_play_chan pc = {100.0, 0.0};
+        c->feed_playchan.assign(c->n_ch, pc);
+    }
     const size_t in_b = (size_t)c->n_ch * n_frames * SSDR_FRAME * 4;
     const size_t wire_b = (size_t)c->n_ch * n_frames * SSDR_WIRE_BODY;
     const bool wire = (flags & SSDR_FEED_WIRE) != 0;
@@ -857,6 +926,19 @@ int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth, uint32_t flag
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_rssi), rssi_b, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipMalloc(&s.d_in, in_b) == hipSuccess && hipMalloc(&s.d_wf, wf_b) == hipSuccess;
         ok = ok && hipMalloc(&s.d_pcm, pcm_b) == hipSuccess && hipMalloc(&s.d_rssi, rssi_b) == hipSuccess;
+        ok = ok && hipMalloc(&s.d_flags, (size_t)c->n_ch * n_frames) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_flags), (size_t)c->n_ch * n_frames, hipHostMallocDefault) == hipSuccess;
+        if (post) {
+            const size_t color_b = wf_b * 2, db_b = (size_t)c->n_ch * sizeof(ssdr_db2col_chan);
+            const size_t play_b = (size_t)c->n_ch * n_frames * 2048 * 2 * sizeof(int16_t);       // sized for the x4 form, either rate fits
+            ok = ok && hipMalloc(&s.d_color, color_b) == hipSuccess && hipMalloc(&s.d_dbchan, db_b) == hipSuccess;
+            ok = ok && hipMalloc(&s.d_play, play_b) == hipSuccess && hipMalloc(&s.d_mono, play_b / 2) == hipSuccess;
+            ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_color), color_b, hipHostMallocDefault) == hipSuccess;
+            ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_dbchan), db_b, hipHostMallocDefault) == hipSuccess;
+            ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_playchan), (size_t)c->n_ch * sizeof(ssdr_play_chan), hipHostMallocDefault) == hipSuccess;
+            ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_play), play_b, hipHostMallocDefault) == hipSuccess;
+            ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_mono), play_b / 2, hipHostMallocDefault) == hipSuccess;
+        }
         ok = ok && hipEventCreateWithFlags(&s.ev_in, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&s.ev_run, hipEventDisableTiming) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming) == hipSuccess;
@@ -906,15 +988,44 @@ int ssdr_feed_submit(ssdr_ctx *c)
     const uint32_t *k_iq = c->d_iq; const uint32_t k_frames = c->in_frames; const bool k_have = c->have_input;
     int16_t *k_wf = c->d_wf_out; const size_t k_wf_lines = c->wf_out_lines; const uint32_t k_ready = c->wf_lines_ready;
     int16_t *k_pcm = c->d_pcm; float *k_rssi = c->d_rssi; const size_t k_af = c->audio_frames; const uint32_t k_arf = c->audio_run_frames;
+    uint8_t *k_flags = c->d_flags; const size_t k_ff = c->flags_frames;
     c->d_iq = s.d_in; c->in_frames = nf; c->have_input = true;
     c->d_wf_out = s.d_wf; c->wf_out_lines = c->hop == SSDR_NFFT / 2 ? nf : nf / 2;
     c->d_pcm = s.d_pcm; c->d_rssi = s.d_rssi; c->audio_frames = nf;
+    c->d_flags = s.d_flags; c->flags_frames = nf;
     uint32_t lines = 0;
+    s.n_avg = c->n_avg;
     int rc = ssdr_run_wf(c, nullptr, &lines, 0);
     if (rc == SSDR_OK) rc = ssdr_run_audio(c, nullptr, nullptr, 0);
+    if (rc == SSDR_OK && c->feed_post) rc = [&]() -> int {
+        // spectrum_db2col of this batch's lines and play_buffer of its frames, on the slot's buffers, in batch order
+        if (lines) {
+            memcpy(s.h_dbchan, c->feed_dbchan.data(), (size_t)c->n_ch * sizeof(ssdr_db2col_chan));
+            HIP_TRY(hipMemcpyAsync(s.d_dbchan, s.h_dbchan, (size_t)c->n_ch * sizeof(ssdr_db2col_chan), hipMemcpyHostToDevice, c->stream));
+            SsdrDb2colArgs d;
+            d.wf = s.d_wf; d.n_ch = c->n_ch; d.n_lines = lines; d.n_avg = c->n_avg; d.chans = s.d_dbchan; d.color = s.d_color;
+            int r2;
+            if ((r2 = timed_begin(c)) != SSDR_OK) return r2;
+            HIP_TRY(ssdr_launch_db2col(d, c->stream));
+            if ((r2 = timed_end(c, SSDR_K_DB2COL)) != SSDR_OK) return r2;
+            if (c->d_wfdata) { r2 = wfdata_feed(c, s.d_color, lines); if (r2 != SSDR_OK) return r2; }
+        }
+        memcpy(s.h_playchan, c->feed_playchan.data(), (size_t)c->n_ch * sizeof(ssdr_play_chan));
+        HIP_TRY(hipMemcpyAsync(c->d_play, s.h_playchan, (size_t)c->n_ch * sizeof(ssdr_play_chan), hipMemcpyHostToDevice, c->stream));
+        SsdrPlayArgs pa;
+        pa.pcm = s.d_pcm; pa.n_ch = c->n_ch; pa.n_frames = nf; pa.chans = c->d_play; pa.taps = c->d_play_taps; pa.hist = c->d_play_hist;
+        pa.out = s.d_play; pa.rs_taps = c->d_play_rs_taps; pa.mono = c->recording ? s.d_mono : nullptr;
+        s.has_mono = c->recording;
+        int r3;
+        if ((r3 = timed_begin(c)) != SSDR_OK) return r3;
+        HIP_TRY(c->kiwi_rate != SSDR_RATE ? ssdr_launch_play_rs(pa, c->stream) : ssdr_launch_play(pa, c->stream));
+        if ((r3 = timed_end(c, SSDR_K_PLAY)) != SSDR_OK) return r3;
+        return SSDR_OK;
+    }();
     c->d_iq = k_iq; c->in_frames = k_frames; c->have_input = k_have;
     c->d_wf_out = k_wf; c->wf_out_lines = k_wf_lines; c->wf_lines_ready = k_ready;
     c->d_pcm = k_pcm; c->d_rssi = k_rssi; c->audio_frames = k_af; c->audio_run_frames = k_arf;
+    c->d_flags = k_flags; c->flags_frames = k_ff;
     if (rc != SSDR_OK) return rc;
     s.lines = lines;
     HIP_TRY(hipEventRecord(s.ev_run, c->stream));
@@ -925,6 +1036,17 @@ int ssdr_feed_submit(ssdr_ctx *c)
     HIP_TRY(hipMemcpyAsync(s.h_rssi, s.d_rssi, (size_t)c->n_ch * nf * sizeof(float), hipMemcpyDeviceToHost, c->feed_s_out));
     if (c->feed_wire)
         HIP_TRY(hipMemcpyAsync(s.h_wire_rssi, s.d_wire_rssi, (size_t)c->n_ch * nf * sizeof(float), hipMemcpyDeviceToHost, c->feed_s_out));
+    HIP_TRY(hipMemcpyAsync(s.h_flags, s.d_flags, (size_t)c->n_ch * nf, hipMemcpyDeviceToHost, c->feed_s_out));
+    if (c->feed_post) {
+        const size_t per_frame = c->kiwi_rate != SSDR_RATE ? (size_t)SSDR_RS_OUT_PER_FRAME : 2048;
+        if (lines) {
+            HIP_TRY(hipMemcpyAsync(s.h_color, s.d_color, (size_t)lines * c->n_ch * SSDR_NFFT * sizeof(float), hipMemcpyDeviceToHost, c->feed_s_out));
+            HIP_TRY(hipMemcpyAsync(s.h_dbchan, s.d_dbchan, (size_t)c->n_ch * sizeof(ssdr_db2col_chan), hipMemcpyDeviceToHost, c->feed_s_out));
+        }
+        HIP_TRY(hipMemcpyAsync(s.h_play, s.d_play, (size_t)c->n_ch * nf * per_frame * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, c->feed_s_out));
+        if (s.has_mono)
+            HIP_TRY(hipMemcpyAsync(s.h_mono, s.d_mono, (size_t)c->n_ch * nf * per_frame * sizeof(int16_t), hipMemcpyDeviceToHost, c->feed_s_out));
+    }
     HIP_TRY(hipEventRecord(s.ev_out, c->feed_s_out));
     c->feed_head = (c->feed_head + 1) % (uint32_t)c->feed.size();
     c->feed_inflight++;
@@ -932,7 +1054,29 @@ int ssdr_feed_submit(ssdr_ctx *c)
     return SSDR_OK;
 }
 
-int ssdr_feed_collect(ssdr_ctx *c, int16_t **wf_sum, uint32_t *lines, int16_t **pcm, float **rssi, float **wire_rssi)
+int ssdr_feed_post(ssdr_ctx *c, const ssdr_db2col_chan *chans, const ssdr_play_chan *play)
+{
+    if (!c) return SSDR_EINVAL;
+    if (c->feed.empty() || !c->feed_post) return SSDR_ESTATE;
+    if (chans) c->feed_dbchan.assign(chans, chans + c->n_ch);
+    if (play) c->feed_playchan.assign(play, play + c->n_ch);
+    return SSDR_OK;
+}
+
+int ssdr_feed_collect_post(ssdr_ctx *c, float **color, ssdr_db2col_chan **chans, int16_t **play, int16_t **mono)
+{
+    if (!c) return SSDR_EINVAL;
+    if (c->feed.empty() || !c->feed_post || c->feed_last < 0) return SSDR_ESTATE;
+    auto &s = c->feed[c->feed_last];
+    if (color) *color = s.lines ? s.h_color : nullptr;
+    if (chans) *chans = s.lines ? s.h_dbchan : nullptr;
+    if (play) *play = s.h_play;
+    if (mono) *mono = s.has_mono ? s.h_mono : nullptr;
+    return SSDR_OK;
+}
+
+int ssdr_feed_collect(ssdr_ctx *c, int16_t **wf_sum, uint32_t *lines, int16_t **pcm, float **rssi, float **wire_rssi,
+                      uint8_t **flags, uint32_t *n_avg)
 {
     if (!c) return SSDR_EINVAL;
     if (c->feed.empty() || c->feed_inflight == 0) return SSDR_ESTATE;
@@ -944,6 +1088,9 @@ int ssdr_feed_collect(ssdr_ctx *c, int16_t **wf_sum, uint32_t *lines, int16_t **
     if (pcm) *pcm = s.h_pcm;
     if (rssi) *rssi = s.h_rssi;
     if (wire_rssi) *wire_rssi = s.h_wire_rssi;            // NULL unless the feed was opened with SSDR_FEED_WIRE
+    if (flags) *flags = s.h_flags;
+    if (n_avg) *n_avg = s.n_avg;
+    c->feed_last = (int)c->feed_tail;
     c->feed_tail = (c->feed_tail + 1) % (uint32_t)c->feed.size();
     c->feed_inflight--;
     return SSDR_OK;
@@ -1054,14 +1201,28 @@ int ssdr_checkpoint_save(ssdr_ctx *c, void *blob)
     return SSDR_OK;
 }
 
-int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob)
+int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob, uint64_t bytes)
 {
     if (!c || !blob) return SSDR_EINVAL;
+    uint64_t want = 0;
+    (void)ssdr_checkpoint_size(c, &want);
+    if (bytes != want) return SSDR_EINVAL;                    // a blob of another channel count, another version, or cut short
     SsdrCkptHeader h;
     memcpy(&h, blob, sizeof h);
     if (h.magic != kCkptMagic || h.version != 3 || h.n_ch != c->n_ch || h.n_avg < 1 || h.n_avg > 100 || h.wf_phase >= h.n_avg ||
-        (h.hop != SSDR_NFFT && h.hop != SSDR_NFFT / 2) || (h.decim != 1 && h.decim != 2 && h.decim != 4))
+        (h.hop != SSDR_NFFT && h.hop != SSDR_NFFT / 2) || (h.decim != 1 && h.decim != 2 && h.decim != 4) ||
+        (h.kiwi_rate != SSDR_RATE && h.kiwi_rate != SSDR_RATE_WIDE))
         return SSDR_EINVAL;
+    {   // the compiled constants go to the device as they are: nothing a kernel indexes with may be out of range
+        const ssdr_chan_consts *k = reinterpret_cast<const ssdr_chan_consts *>(static_cast<const char *>(blob) + sizeof h);
+        for (uint32_t i = 0; i < c->n_ch; i++) {
+            const uint32_t kd = k[i].decim > 1 ? k[i].decim : 1;
+            if (k[i].mode > SSDR_MODE_NBFM || k[i].ntap > SSDR_NTAP_MAX || k[i].ntap8 > SSDR_NTAP_MAX || (k[i].ntap8 & 7u) ||
+                k[i].ntap8 * kd > SSDR_NTAP_MAX || kd != h.decim || k[i].hang_frames > 8 ||
+                (h.decim > 1 && (k[i].fir_flags & SSDR_FIR_DELAY4)))
+                return SSDR_EINVAL;
+        }
+    }
     if (!c->feed.empty()) return SSDR_ESTATE;
     HIP_TRY(hipSetDevice(c->device));
     { int rch = ssdr_set_hop(c, h.hop); if (rch != SSDR_OK) return rch; }
@@ -1164,6 +1325,53 @@ int ssdr_run_db2col(ssdr_ctx *c, ssdr_db2col_chan *chans, float *color_out, int 
         HIP_TRY(hipMemcpyAsync(color_out, c->d_color, (size_t)lines * c->n_ch * SSDR_NFFT * sizeof(float),
                                out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_db2col_line(ssdr_ctx *c, const int16_t *wf_sum, uint32_t n_avg, ssdr_db2col_chan *chan, float *color_out)
+{
+    if (!c || !wf_sum || !chan || !color_out || n_avg < 1 || n_avg > 100) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->d_line1) {
+        HIP_TRY(hipMalloc(&c->d_line1, SSDR_NFFT * sizeof(int16_t)));
+        HIP_TRY(hipMalloc(&c->d_dbchan1, sizeof(ssdr_db2col_chan)));
+        HIP_TRY(hipMalloc(&c->d_color1, SSDR_NFFT * sizeof(float)));
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_line1, wf_sum, SSDR_NFFT * sizeof(int16_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->d_dbchan1, chan, sizeof(ssdr_db2col_chan), hipMemcpyHostToDevice, c->stream));
+    SsdrDb2colArgs a;
+    a.wf = c->d_line1;
+    a.n_ch = 1;
+    a.n_lines = 1;
+    a.n_avg = n_avg;
+    a.chans = c->d_dbchan1;
+    a.color = c->d_color1;
+    int rc;
+    if ((rc = timed_begin(c)) != SSDR_OK) return rc;
+    HIP_TRY(ssdr_launch_db2col(a, c->stream));
+    if ((rc = timed_end(c, SSDR_K_DB2COL)) != SSDR_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(chan, c->d_dbchan1, sizeof(ssdr_db2col_chan), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(color_out, c->d_color1, SSDR_NFFT * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return SSDR_OK;
+}
+
+int ssdr_output_checksum(ssdr_ctx *c, uint64_t sums[3])
+{
+    if (!c || !sums) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
+    HIP_TRY(hipMemsetAsync(c->d_scratch, 0, 24, c->stream));
+    if (c->d_wf_out && c->wf_lines_ready)
+        HIP_TRY(ssdr_launch_checksum(c->d_wf_out, (uint64_t)c->wf_lines_ready * c->n_ch * (SSDR_NFFT / 2), c->d_scratch, c->stream));
+    if (c->d_pcm && c->audio_run_frames) {
+        HIP_TRY(ssdr_launch_checksum(c->d_pcm, (uint64_t)c->n_ch * c->audio_run_frames * (SSDR_FRAME / 2), c->d_scratch + 1, c->stream));
+        HIP_TRY(ssdr_launch_checksum(c->d_rssi, (uint64_t)c->n_ch * c->audio_run_frames, c->d_scratch + 2, c->stream));
+    }
+    unsigned long long v[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(v, c->d_scratch, 24, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; i++) sums[i] = v[i];
     return SSDR_OK;
 }
 
@@ -1312,23 +1520,7 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
     const uint32_t nf = c->audio_run_frames;
     const bool wide = c->kiwi_rate != SSDR_RATE;                  // SAMPLE_RATIO % 1 != 0 (:1125)
     const size_t per_frame = wide ? (size_t)SSDR_RS_OUT_PER_FRAME : 2048;
-    if (!c->d_play) {
-        HIP_TRY(hipMalloc(&c->d_play, (size_t)c->n_ch * sizeof(ssdr_play_chan)));
-        HIP_TRY(hipMalloc(&c->d_play_taps, 33 * sizeof(double)));
-        HIP_TRY(hipMalloc(&c->d_play_hist, (size_t)c->n_ch * 8 * sizeof(double)));
-        HIP_TRY(hipMalloc(&c->d_play_rs_taps, sizeof(SSDR_RS_TAPS)));
-        HIP_TRY(hipMemsetAsync(c->d_play_hist, 0, (size_t)c->n_ch * 8 * sizeof(double), c->stream));   // old_buffer = zeros (:1005)
-        if (c->pending_play_hist.size() == (size_t)c->n_ch * 8) {
-            HIP_TRY(hipMemcpyAsync(c->d_play_hist, c->pending_play_hist.data(), (size_t)c->n_ch * 8 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            c->pending_play_hist.clear();
-        }
-        double h[64];
-        if (ssdr_design_lowpass(SSDR_RATE / 2.0, 48000.0, 63, h) != 33) return SSDR_EINVAL;             // filtering(KIWI_RATE/2, AUDIO_RATE)
-        HIP_TRY(hipMemcpyAsync(c->d_play_taps, h, 33 * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->d_play_rs_taps, SSDR_RS_TAPS, sizeof(SSDR_RS_TAPS), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    }
+    { int rcp = ensure_play(c); if (rcp != SSDR_OK) return rcp; }
     if (c->play_frames < nf) {          // sized for the longer (x4) form, either path fits
         if (c->d_play_out) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_play_out)); c->d_play_out = nullptr; c->play_frames = 0; }
         HIP_TRY(hipMalloc(&c->d_play_out, (size_t)c->n_ch * nf * 2048 * 2 * sizeof(int16_t)));

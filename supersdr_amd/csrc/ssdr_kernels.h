@@ -122,6 +122,7 @@ hipError_t ssdr_launch_play_rs(const SsdrPlayArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_iqwire(const SsdrWireArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_trace(const SsdrTraceArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_smeter(const SsdrSmeterArgs &a, hipStream_t stream);
+hipError_t ssdr_launch_checksum(const void *data, uint64_t n_words, unsigned long long *out, hipStream_t stream);
 hipError_t ssdr_launch_adpcm(const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state, int16_t *out,
                              hipStream_t stream);
 struct SsdrFusedArgs { SsdrWfArgs wf; SsdrAudioArgs au; };

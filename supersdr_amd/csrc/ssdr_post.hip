@@ -343,7 +343,33 @@ __global__ void ssdr_adpcm_kernel(const uint8_t *data, uint32_t n_streams, uint3
     state[2 * sidx + 1] = prev;
 }
 
+// position-weighted sum of 32-bit words mod 2^64 (ssdr_output_checksum): integer arithmetic only, so the value does not
+// depend on the grid, the order of the atomics or the GPU
+__global__ __launch_bounds__(256) void ssdr_checksum_kernel(const uint32_t *data, uint64_t n_words, unsigned long long *out)
+{
+    __shared__ unsigned long long part[256];
+    unsigned long long h = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += stride)
+        h += (unsigned long long)(data[i] + 0x9E3779B9u) * (2ull * i + 1ull);
+    part[threadIdx.x] = h;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, part[0]);
+}
+
 } // namespace
+
+hipError_t ssdr_launch_checksum(const void *data, uint64_t n_words, unsigned long long *out, hipStream_t stream)
+{
+    const uint64_t blocks = (n_words + 255) / 256;
+    hipLaunchKernelGGL(ssdr_checksum_kernel, dim3((uint32_t)(blocks < 4096 ? (blocks ? blocks : 1) : 4096)), dim3(256), 0, stream,
+                       static_cast<const uint32_t *>(data), n_words, out);
+    return hipGetLastError();
+}
 
 hipError_t ssdr_launch_adpcm(const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state, int16_t *out,
                              hipStream_t stream)

@@ -725,7 +725,6 @@ hipError_t ssdr_fused_blocks_per_cu(int *blocks)
 // workgroups of the waterfall kernel that are resident per CU (min over both instances)
 hipError_t ssdr_wf_blocks_per_cu(int *blocks)
 {
-    int b0 = 0, b1 = 0;
     int b[4] = {0, 0, 0, 0};
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b[0], ssdr_wf_kernel<false, false>, SSDR_WF_BLOCK, 0);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b[1], ssdr_wf_kernel<true, false>, SSDR_WF_BLOCK, 0);

@@ -55,6 +55,8 @@ class SsdrEngine:
         self.in_frames = 0
         self.hop = L.NFFT
         self.decim = 1
+        self.averaging = 1
+        self.kiwi_rate = L.RATE
         self.audio_frames = 0          # frames of the last run_audio / set_pcm (extent of the device PCM / RSSI / flags)
 
     def close(self):
@@ -86,6 +88,7 @@ class SsdrEngine:
 
     def set_averaging(self, n):
         check(lib.ssdr_set_averaging(self._ctx, int(n)), "ssdr_set_averaging")
+        self.averaging = int(n)
 
     def set_decimation(self, decim):
         """D in {1, 2, 4}: the IQ arrives at D * 12 kHz (push_iq then takes [n_ch, n_frames*512*D, 2]); resets the streams"""
@@ -194,10 +197,33 @@ class SsdrEngine:
         return out
 
     # ---- pipelined host feed (copy-in / kernels / copy-out of consecutive batches overlap)
-    def feed_open(self, n_frames, depth=3, wire=False):
-        """wire=True: slots take SND bodies uint8 [n_ch, n_frames, 2065] (kiwi/client.py:443-454), unpacked on the device."""
-        check(lib.ssdr_feed_open(self._ctx, int(n_frames), int(depth), 1 if wire else 0), "ssdr_feed_open")
-        self._feed_frames, self._feed_wire = int(n_frames), bool(wire)
+    def feed_open(self, n_frames, depth=3, wire=False, post=False):
+        """wire=True: slots take SND bodies uint8 [n_ch, n_frames, 2065] (kiwi/client.py:443-454), unpacked on the device.
+        post=True: every batch also goes through spectrum_db2col / play_buffer on the device (feed_post, feed_collect_post)."""
+        check(lib.ssdr_feed_open(self._ctx, int(n_frames), int(depth), (1 if wire else 0) | (2 if post else 0)), "ssdr_feed_open")
+        self._feed_frames, self._feed_wire, self._feed_post = int(n_frames), bool(wire), bool(post)
+        self._feed_lines = 0
+
+    def feed_post(self, chans=None, play=None):
+        """display state for the batches submitted from now on: lists of Db2colChan / PlayChan (None keeps the previous)"""
+        a = (Db2colChan * self.n_ch)(*chans) if chans is not None else None
+        b = (PlayChan * self.n_ch)(*play) if play is not None else None
+        check(lib.ssdr_feed_post(self._ctx, a, b), "ssdr_feed_post")
+
+    def feed_collect_post(self):
+        """of the batch feed_collect returned last -> (color float32 [lines, n_ch, 1024] or None, [Db2colChan] or None,
+        play int16 [n_ch, n_frames*L, 2], mono int16 [n_ch, n_frames*L] or None), views of pinned memory"""
+        col, ch, pl, mo = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib.ssdr_feed_collect_post(self._ctx, C.byref(col), C.byref(ch), C.byref(pl), C.byref(mo)), "ssdr_feed_collect_post")
+        nf, nl, P = self._feed_frames, self._feed_lines, self.playbuffer_frame_len()
+        color = chans = mono = None
+        if nl and col.value:
+            color = np.ctypeslib.as_array(C.cast(col, C.POINTER(C.c_float)), shape=(nl * self.n_ch * L.NFFT,)).reshape(nl, self.n_ch, L.NFFT)
+            chans = list((Db2colChan * self.n_ch).from_address(ch.value))
+        play = np.ctypeslib.as_array(C.cast(pl, C.POINTER(C.c_int16)), shape=(self.n_ch * nf * P * 2,)).reshape(self.n_ch, nf * P, 2)
+        if mo.value:
+            mono = np.ctypeslib.as_array(C.cast(mo, C.POINTER(C.c_int16)), shape=(self.n_ch * nf * P,)).reshape(self.n_ch, nf * P)
+        return color, chans, play, mono
 
     def feed_slot(self):
         """-> int16 [n_ch, n_frames*512, 2] (or uint8 [n_ch, n_frames, 2065]) view of the next pinned slot (fill it, then
@@ -218,9 +244,13 @@ class SsdrEngine:
         [n_ch, n_frames]) as views of pinned memory, valid until that slot is handed out again; in wire mode a fourth
         item: the SND headers' rssi float32 [n_ch, n_frames]."""
         wf, pcm, rssi, wr, lines = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint32()
-        check(lib.ssdr_feed_collect(self._ctx, C.byref(wf), C.byref(lines), C.byref(pcm), C.byref(rssi), C.byref(wr)),
-              "ssdr_feed_collect")
+        fl, navg = C.c_void_p(), C.c_uint32()
+        check(lib.ssdr_feed_collect(self._ctx, C.byref(wf), C.byref(lines), C.byref(pcm), C.byref(rssi), C.byref(wr),
+                                    C.byref(fl), C.byref(navg)), "ssdr_feed_collect")
         nf, nl = self._feed_frames, int(lines.value)
+        self._feed_lines = nl
+        self.feed_flags = np.ctypeslib.as_array(C.cast(fl, C.POINTER(C.c_uint8)), shape=(self.n_ch * nf,)).reshape(self.n_ch, nf)
+        self.feed_n_avg = int(navg.value)          # the N in force when this batch was submitted
         w = (np.ctypeslib.as_array(C.cast(wf, C.POINTER(C.c_int16)), shape=(nl * self.n_ch * L.NFFT,)).reshape(nl, self.n_ch, L.NFFT)
              if nl else np.zeros((0, self.n_ch, L.NFFT), np.int16))
         p = np.ctypeslib.as_array(C.cast(pcm, C.POINTER(C.c_int16)), shape=(self.n_ch * nf * L.FRAME,)).reshape(self.n_ch, -1)
@@ -269,6 +299,7 @@ class SsdrEngine:
     def set_kiwi_rate(self, kiwi_rate):
         """kiwi_sound.KIWI_RATE (utils_supersdr.py:991-994): 12000, or 20250 for play_buffer's resample_poly branch."""
         check(lib.ssdr_set_kiwi_rate(self._ctx, int(kiwi_rate)), "ssdr_set_kiwi_rate")
+        self.kiwi_rate = int(kiwi_rate)
 
     def playbuffer_frame_len(self):
         n = C.c_uint32()
@@ -382,8 +413,35 @@ class SsdrEngine:
         return bytes(buf)
 
     def restore(self, blob):
+        """Load a checkpoint() blob; the blob's own hop, decimation and averaging N become the ctx's (and this object's)."""
+        n = C.c_uint64(0)
+        check(lib.ssdr_checkpoint_size(self._ctx, C.byref(n)), "ssdr_checkpoint_size")
+        if len(blob) != n.value:
+            raise ValueError("checkpoint blob has %d bytes, this ctx (%d channels) takes %d" % (len(blob), self.n_ch, n.value))
         buf = (C.c_char * len(blob)).from_buffer_copy(blob)
-        check(lib.ssdr_checkpoint_load(self._ctx, buf), "ssdr_checkpoint_load")
+        check(lib.ssdr_checkpoint_load(self._ctx, buf, len(blob)), "ssdr_checkpoint_load")
+        self._refresh_config()
+        self.in_frames = 0                 # a batch pushed before the load belongs to the old streams
+
+    def _refresh_config(self):
+        hop, decim, navg, rate = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        check(lib.ssdr_get_config(self._ctx, C.byref(hop), C.byref(decim), C.byref(navg), C.byref(rate)), "ssdr_get_config")
+        self.hop, self.decim, self.averaging, self.kiwi_rate = hop.value, decim.value, navg.value, rate.value
+
+    def output_checksum(self):
+        """-> (wf, pcm, rssi) 64-bit position-weighted checksums of the device-resident results of the last run"""
+        v = (C.c_uint64 * 3)()
+        check(lib.ssdr_output_checksum(self._ctx, C.byref(v)), "ssdr_output_checksum")
+        return tuple(int(x) for x in v)
+
+    def db2col_line(self, wf_sum, n_avg, chan):
+        """spectrum_db2col of one int16[1024] line (a sum of n_avg byte lines) with display state `chan` (Db2colChan,
+        updated in place) -> float32[1024]; leaves the batch results and the device copy of wf_data alone."""
+        wf_sum = np.ascontiguousarray(wf_sum, np.int16)
+        assert wf_sum.shape == (L.NFFT,)
+        out = np.empty(L.NFFT, np.float32)
+        check(lib.ssdr_db2col_line(self._ctx, wf_sum.ctypes.data, int(n_avg), C.byref(chan), out.ctypes.data), "ssdr_db2col_line")
+        return out
 
     def selftest_sqrt(self):
         n = C.c_uint64(0)

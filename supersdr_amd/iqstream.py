@@ -4,33 +4,14 @@
                   _process_iq_samples(seq, samples, rssi, gps) (kiwi/client.py:493-494) and hands
                   every IQ frame to an IQHub, i.e. to ssdr_push_iq.  Use as
                       class Recorder(IQBatcher, KiwiSDRStream): pass
-  GpuKiwiWorker   the driver thread of kiwi/worker.py:10-79 (same constructor arguments, same
-                  exception -> action table), for recorders whose sink is the GPU.
+                  and drive it with the reference's own KiwiWorker(args=(recorder, options, run_event))
+                  (kiwi/worker.py:10-79) -- its connect / open / run loop and retry table need nothing from here.
   iq_body_to_int16 / int16_to_wire   the SND IQ frame payload (kiwi/client.py:443-454) <-> the
                   little-endian int16 [n,2] layout the kernels read.
 """
-import logging
 import struct
-import threading
-from traceback import print_exc
 
 import numpy as np
-
-
-class KiwiError(Exception):
-    pass
-
-
-class KiwiTooBusyError(KiwiError):
-    pass
-
-
-class KiwiTimeLimitError(KiwiError):
-    pass
-
-
-class KiwiServerTerminatedConnection(KiwiError):
-    pass
 
 
 def iq_body_to_int16(body):
@@ -105,69 +86,3 @@ class IQBatcher:
 
     def _process_waterfall_samples(self, seq, samples):
         pass
-
-
-class GpuKiwiWorker(threading.Thread):
-    """kiwi/worker.py:10-79 restated: connect / open / run loop with the reference's retry policy.
-
-    recorder needs connect(host, port), open(), run(), close(); options needs connect_retries,
-    connect_timeout, server_host, server_port, is_kiwi_tdoa, no_api (and `status` is written).
-    Reference exceptions are matched by class name so the real kiwi.client classes work too."""
-
-    def __init__(self, group=None, target=None, name=None, args=(), kwargs=None):
-        super().__init__(group=group, target=target, name=name)
-        self._recorder, self._options, self._run_event = args
-        self._recorder._reader = True
-        self._event = threading.Event()
-        self.connect_count = 0
-
-    def _do_run(self):
-        return self._run_event.is_set()
-
-    def run(self):
-        o = self._options
-        self.connect_count = o.connect_retries
-        while self._do_run():
-            try:
-                self._recorder.connect(o.server_host, o.server_port)
-            except Exception as e:
-                logging.info("Failed to connect, sleeping and reconnecting error='%s'" % e)
-                if o.is_kiwi_tdoa:
-                    o.status = 1
-                    break
-                self.connect_count -= 1
-                if o.connect_retries > 0 and self.connect_count == 0:
-                    break
-                if o.connect_timeout > 0:
-                    self._event.wait(timeout=o.connect_timeout)
-                continue
-            try:
-                self._recorder.open()
-                while self._do_run():
-                    self._recorder.run()
-            except Exception as e:
-                kind = type(e).__name__
-                if kind == "KiwiServerTerminatedConnection":
-                    logging.info("%s:%s %s.%s" % (o.server_host, o.server_port, e,
-                                                  "" if o.no_api else " Reconnecting after 5 seconds"))
-                    self._recorder.close()
-                    if o.no_api:
-                        break
-                    self._recorder._start_ts = None
-                    self._event.wait(timeout=5)
-                    continue
-                if kind == "KiwiTooBusyError":
-                    logging.info("%s:%d too busy now. Reconnecting after 15 seconds" % (o.server_host, o.server_port))
-                    if o.is_kiwi_tdoa:
-                        o.status = 2
-                        break
-                    self._event.wait(timeout=15)
-                    continue
-                if kind == "KiwiTimeLimitError":
-                    break
-                if o.is_kiwi_tdoa:
-                    o.status = 1
-                print_exc()
-                break
-        self._run_event.clear()
-        self._recorder.close()

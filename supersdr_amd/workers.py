@@ -1,38 +1,38 @@
-"""GPU-backed stand-ins for the reference's two receiver workers.
+"""The GPU path behind the reference's two receiver workers.
 
-`kiwi_waterfall` and `kiwi_sound` keep the class names, constructor signatures, class
-constants, methods and attributes that supersdr.py touches (usage
-census of supersdr.py: 37 kiwi_wf.* and 32 kiwi_snd.* names), so the UI runs unmodified
-when `utils_supersdr.kiwi_waterfall / kiwi_sound` are replaced by these.  What changes is
-the producer behind the two seams:
+The reference's `kiwi_waterfall` and `kiwi_sound` (utils_supersdr.py:592-898, 901-1186) are the boundary of this path
+(SURVEY.md section 8b).  Nothing of them is restated here.  This module supplies what stands on the other side of them:
 
-    kiwi_waterfall.receive_spectrum()      utils_supersdr.py:780-785
-        reference: one W/F websocket frame from the KiwiSDR server -> float32[1024] bytes
-        here:      the next waterfall line of this channel from the GPU (ssdr_run_wf)
-    kiwi_sound.process_audio_stream()      utils_supersdr.py:1044-1076
-        reference: one SND websocket frame -> int16[512] + rssi
-        here:      the next PCM frame of this channel from the GPU (ssdr_run_audio)
+    IQHub           one GPU context for a block of receiver channels: batches the channels' IQ into superframes
+                    (1024 samples = 1 waterfall line + 2 audio frames) and runs the kernels once per superframe
+    GpuStream       what the workers hold where the reference holds a websocket `Stream` (self.wf_stream / self.stream):
+                    send_message() takes the client's "SET ..." text commands and turns them into ssdr_set_params,
+                    receive_message() returns W/F and SND frames in the KiwiSDR wire format, built from GPU results --
+                    so even the maintainer's UNMODIFIED classes run on it
+    WaterfallSeams, SoundSeams
+                    mixins that go in front of the maintainer's own classes and replace exactly the seams:
+                        receive_spectrum()       utils_supersdr.py:780-785   the next waterfall line from the GPU
+                        spectrum_db2col()        :787-813                    result of ssdr_run_db2col, no host arithmetic
+                        run()                    :879-897                    time binning on the GPU (int16 sums / N)
+                        process_audio_stream()   :1044-1076                  the next PCM frame from the GPU
+                        play_buffer()            :1106-1148                  48 kHz block of ssdr_run_playbuffer
+                    and the socket part of the two constructors (:648-689, 946-994): while the maintainer's own
+                    __init__ runs, the names it dials out with (kiwi_sdr, socket, wsclient, Stream) resolve to the GPU
+                    stream.  Everything else -- frequency / zoom arithmetic, passband tables, the AGC stepper, the pacing
+                    loop, the recorder, every attribute supersdr.py reads -- is the maintainer's code, inherited.
+    bind(module)    -> namespace(kiwi_waterfall, kiwi_sound): the two mixins bound over `module`'s classes
 
-Both are fed by an `IQHub`, which owns one SsdrEngine (one GPU context) for a block of
-receiver channels, batches the channels' IQ frames and runs the two kernels once per
-superframe (1024 samples = 1 waterfall line + 2 audio frames).
-
-What the reference does on the host AFTER those seams and is pure control flow stays on the host, with
-citations (time binning by division of the GPU's integer sums, scrolling, pacing, TX mute); the parts that are
-statement-for-statement mirrors of the reference (constants, frequency / zoom arithmetic, passband tables, the pacing
-loop, the recorder) live in `ref_surface.py`, this file holds the product's own logic.  The two
-arithmetic steps -- spectrum_db2col (utils_supersdr.py:787-813) and the play_buffer interpolator
-(:1106-1148, both the x4 and the 64/27 resample_poly branch) -- are HIP kernels (ssdr_run_db2col /
-ssdr_run_playbuffer, bit-exact against golden vectors of the real reference): the hub runs them with every
-superframe and the workers hand out their results.  There is no host implementation of either step:
-`IQHub(gpu_post=False)` skips the two kernels for consumers that only want raw lines and PCM, and
-spectrum_db2col() then raises and play_buffer() (a PortAudio callback, which must not raise) plays silence, stops
-the worker and leaves the error in `kiwi_sound.error`.
+There is no host implementation of spectrum_db2col or of the play_buffer interpolator in this package:
+`IQHub(gpu_post=False)` skips the two kernels for consumers that only want raw lines and PCM; spectrum_db2col() then
+raises, and play_buffer() (a PortAudio callback, which must not raise) plays silence, stops the worker and leaves the
+error in `kiwi_sound.error`.
 """
+import contextlib
 import logging
 import queue
+import struct
 import threading
-import time
+import types
 from collections import deque
 
 import numpy as np
@@ -40,8 +40,6 @@ import numpy as np
 from . import _lib as L
 from ._lib import Db2colChan, PlayChan
 from .engine import SsdrEngine, default_params
-from .ref_surface import (WaterfallSurface, SoundSurface, audio_recording,            # noqa: F401  (re-exported names)
-                          CW_PITCH, LOW_CUT_SSB, HIGH_CUT_SSB, LOW_CUT_CW, HIGH_CUT_CW, HIGHLOW_CUT_AM)
 
 IQ_SPAN_KHZ = L.RATE / 1000.0          # what one channel's GPU waterfall covers: the 12 kHz IQ band around its centre
 
@@ -74,18 +72,20 @@ class IQHub:
         wf_queue[c]  : (int16[1024] sum of N byte lines, N, db2col result or None)
         snd_queue[c] : Frame (int16[512] pcm + rssi, ADC-overflow flag, 48 kHz blocks) per audio frame
 
-    A receiver that stalls or reconnects (GpuKiwiWorker sleeps 5-15 s on its retry paths) does not stop the others:
-    once a healthy channel is `stall_superframes` ahead, the hub runs anyway and the lagging channel's superframe is
-    zero-filled (`stalled[c]` counts them).  A ring holds `backlog_superframes`; beyond that the oldest samples of
-    that channel are dropped (`dropped[c]` counts samples).
+    A receiver that stalls or reconnects (KiwiWorker sleeps 5-15 s on its retry paths, kiwi/worker.py:58, 66) does not
+    stop the others: once a healthy channel is `stall_superframes` ahead, the hub runs anyway and the lagging channel's
+    superframe is zero-filled (`stalled[c]` counts them).  A ring holds `backlog_superframes`; beyond that the oldest
+    samples of that channel are dropped (`dropped[c]` counts samples).
 
     Time binning: every kiwi_waterfall asks for its own N (the reference keeps averaging_n per instance,
     utils_supersdr.py:881-886).  The GPU sums N lines when all clients agree; when they disagree it delivers single
     lines and the clients that want N > 1 take the reference's own mean of N of them (a group is never restarted by
     another client's call).
 
-    pipeline=True (gpu_post=False only) sends the superframes through ssdr_feed_*: pinned slots, copy-in / kernels /
-    copy-out of consecutive superframes overlapped; results then arrive `depth - 1` superframes late (flush() drains).
+    pipeline=True sends the superframes through ssdr_feed_*: pinned slots, copy-in / kernels / copy-out of consecutive
+    superframes overlapped, ONE C-ABI submit and one collect per superframe; with gpu_post the slot pipeline also runs
+    spectrum_db2col and play_buffer (SSDR_FEED_POST) with the display state latched at submit.  Results arrive
+    `depth - 1` superframes late (flush() drains) and are bit-identical to the synchronous hub's.
     """
 
     def __init__(self, n_channels, device=0, engine=None, max_queue=64, gpu_post=True, kiwi_rate=12000, trace_rows=0,
@@ -127,9 +127,7 @@ class IQHub:
         self.pipeline = bool(pipeline)
         self._inflight, self._depth = 0, int(depth)
         if self.pipeline:
-            if self.gpu_post:
-                raise ValueError("pipeline=True needs gpu_post=False: db2col / play_buffer refer to the last un-pipelined batch")
-            self.engine.feed_open(2, self._depth)
+            self.engine.feed_open(2, self._depth, post=self.gpu_post)
 
     # ---- control plane (forwarded SET commands)
     def params(self, channel):
@@ -200,6 +198,17 @@ class IQHub:
             else:
                 self._run_superframe()
 
+    def _play_chans(self):
+        return [PlayChan(float(s.volume), float(s.audio_balance)) if s is not None else PlayChan(100.0, 0.0)
+                for s in self.snd_clients]
+
+    def _sync_recording(self):
+        rec = any(s is not None and s.audio_rec.recording_flag for s in self.snd_clients)
+        if rec != self._recording:
+            self.engine.set_recording(rec)
+            self._recording = rec
+        return rec
+
     def _run_superframe(self):
         eng = self.engine
         eng.push_iq(self._batch)
@@ -213,15 +222,14 @@ class IQHub:
         flags = eng.audio_flags()                     # [n_ch, 2] SND header bit 1 (utils_supersdr.py:1066-1067)
         play = mono = None
         if self.gpu_post and any(s is not None for s in self.snd_clients):
-            rec = any(s is not None and s.audio_rec.recording_flag for s in self.snd_clients)
-            if rec != self._recording:
-                eng.set_recording(rec)
-                self._recording = rec
-            play = eng.run_playbuffer([PlayChan(float(s.volume), float(s.audio_balance)) if s is not None
-                                       else PlayChan(100.0, 0.0) for s in self.snd_clients])
+            rec = self._sync_recording()
+            play = eng.run_playbuffer(self._play_chans())
             if rec:
                 mono = eng.playbuffer_mono()
         self.superframes += 1
+        self._hand_out(wf, n_avg, color, chans, pcm, rssi, flags, play, mono)
+
+    def _hand_out(self, wf, n_avg, color, chans, pcm, rssi, flags, play, mono):
         P = self.play_len
         for c in range(self.n_ch):
             for i, line in enumerate(wf):
@@ -239,6 +247,9 @@ class IQHub:
     def _run_pipelined(self):
         eng = self.engine
         eng.feed_slot()[:] = self._batch
+        if self.gpu_post:                             # the display state this superframe is converted with, latched now
+            self._sync_recording()
+            eng.feed_post([self._db2col_chan(w) for w in self.wf_clients], self._play_chans())
         eng.feed_submit()
         self._inflight += 1
         self.superframes += 1
@@ -246,14 +257,18 @@ class IQHub:
             self._collect()
 
     def _collect(self):
-        wf, pcm, rssi = self.engine.feed_collect()[:3]
+        eng = self.engine
+        wf, pcm, rssi = eng.feed_collect()[:3]
         self._inflight -= 1
-        n_avg = self.averaging_n
-        for c in range(self.n_ch):
-            for line in wf:
-                _put_drop_oldest(self.wf_queue[c], (line[c].copy(), n_avg, None))
-            for f in range(2):
-                _put_drop_oldest(self.snd_queue[c], Frame.make(pcm[c, f * L.FRAME:(f + 1) * L.FRAME], rssi[c, f]))
+        n_avg, flags = eng.feed_n_avg, eng.feed_flags          # per slot: the N in force at submit, this batch's flags
+        color = chans = play = mono = None
+        if self.gpu_post:
+            color, chans, play, mono = eng.feed_collect_post()
+            if not any(w is not None for w in self.wf_clients):
+                color = None
+            if not any(s is not None for s in self.snd_clients):
+                play = mono = None
+        self._hand_out(wf, n_avg, color, chans, pcm, rssi, flags, play, mono)
 
     def flush(self):
         """pipeline mode: wait for the superframes still in flight and hand their results out"""
@@ -263,21 +278,13 @@ class IQHub:
 
     def db2col_line(self, channel, wf_sum, n):
         """spectrum_db2col (utils_supersdr.py:787-813) of ONE line of one client on the GPU -- for a client that binned N
-        single lines itself because the hub's clients disagree on N.  Returns the tuple run_db2col results travel in."""
+        single lines itself because the hub's clients disagree on N.  Returns the tuple run_db2col results travel in.
+        Only that client's line is converted (ssdr_db2col_line): the other channels' lines, the batch results and the
+        device copy of wf_data are not touched."""
         with self._lock:
-            if self.averaging_n != 1:
-                raise RuntimeError("db2col_line is for clients that bin single lines themselves (the GPU runs at N = 1 then)")
-            lines = np.zeros((1, self.n_ch, L.NFFT), np.int16)
-            lines[0, channel] = wf_sum
-            chans = [self._db2col_chan(w if c == channel else None) for c, w in enumerate(self.wf_clients)]
-            self.engine.set_averaging(n)                  # the divisor of this one line; at N = 1 no partial sums exist to lose
-            try:
-                self.engine.set_wf_lines(lines)
-                color = self.engine.run_db2col(chans, 1)
-            finally:
-                self.engine.set_averaging(1)
-            k = chans[channel]
-            return (color[0, channel].copy(), k.low_clip_db, k.high_clip_db, k.dynamic_range, k.wf_min_db, k.wf_max_db)
+            k = self._db2col_chan(self.wf_clients[channel])
+            color = self.engine.db2col_line(wf_sum, n, k)
+            return (color, k.low_clip_db, k.high_clip_db, k.dynamic_range, k.wf_min_db, k.wf_max_db)
 
     def spectrum_trace(self, t_avg=15, spectrum_height=0):
         """display_stuff.plot_spectrum's reduction for all channels (utils_supersdr.py:1678-1679): (float64 [n_ch, 1024]
@@ -327,57 +334,180 @@ def _put_drop_oldest(q, item):
         q.put_nowait(item)
 
 
-class kiwi_waterfall(WaterfallSurface):
-    """kiwi_waterfall (utils_supersdr.py:592-898) with the W/F websocket replaced by the GPU.
+# ---------------------------------------------------------------------------------------------------------------
+# the KiwiSDR end of the workers' websocket, played by the GPU
+# ---------------------------------------------------------------------------------------------------------------
+class GpuStream:
+    """The object a worker holds where the reference holds `Stream(request, options)` (utils_supersdr.py:733, 964).
+
+    send_message(text): the client -> server commands of SURVEY.md appendix A.  The two that select the DSP become the
+    channel's ssdr_chan_params (a13):
+        "SET mod=%s low_cut=%d high_cut=%d freq=%.3f"                    utils_supersdr.py:976, 1028
+        "SET agc=%d hang=%d thresh=%d slope=%d decay=%d manGain=%d"      :979, 1023
+    "SET zoom=%d start=%d" (:741, 839) is remembered (`zoom`, `start`); the rest (auth, keepalive, compression, ...)
+    has no meaning without a server and is accepted.  A modulation without a demodulator here, or a frequency outside
+    the channel's IQ band, raises ValueError instead of being demodulated as something else.
+
+    receive_message(): server -> client frames, byte for byte in the wire format the reference parses
+    (utils_supersdr.py:782-784, 1065-1074): first what the constructors wait for ("MSG audio_init audio_rate= sample_rate=",
+    then one empty W/F resp. SND frame), after that one frame per GPU result of this channel."""
+
+    def __init__(self, hub, channel, kind, center_khz, timeout=5.0):
+        self.hub, self.channel, self.kind, self.center_khz, self.timeout = hub, int(channel), kind, float(center_khz), timeout
+        self.zoom = self.start = None
+        self.seq = 0
+        self.closed = False
+        self._greeting = deque()
+        if kind == "SND":
+            rate = int(getattr(hub, "kiwi_rate", L.RATE))
+            # every server announces its rate first; the reference takes KIWI_RATE, KIWI_RATE_TRUE, SAMPLE_RATIO from it (:988-994)
+            self._greeting.append(bytearray(("MSG audio_init=0 audio_rate=%d sample_rate=%.6f" % (rate, float(rate))).encode()))
+            self._greeting.append(bytearray(b"SND" + bytes(7)))
+        else:
+            self._greeting.append(bytearray(b"W/F" + bytes(13)))
+
+    # ---- client -> server
+    def send_message(self, msg, *a, **k):
+        if isinstance(msg, (bytes, bytearray)):
+            msg = bytes(msg).decode()
+        words = msg.split()
+        if len(words) < 2 or words[0] != "SET":
+            return
+        kv = dict(w.split("=", 1) for w in words[1:] if "=" in w)
+        if "mod" in kv:
+            self._retune(kv)
+        elif "agc" in kv:
+            p = self.hub.params(self.channel)
+            q = _copy_params(p, agc_on=int(kv["agc"]), agc_hang=int(kv.get("hang", 0)), agc_thresh=float(kv.get("thresh", -80)),
+                             agc_slope=float(kv.get("slope", 0)), agc_decay=float(kv.get("decay", 4000)),
+                             agc_man_gain=float(kv.get("manGain", 50)))
+            self.hub.set_params(self.channel, q)
+        elif "zoom" in kv:
+            self.zoom, self.start = int(kv["zoom"]), int(kv.get("start", 0))
+
+    def _retune(self, kv):
+        mode = kv["mod"].lower()
+        if mode not in L.MODE_BY_NAME:               # "SET mod=iq" and friends have no demodulator here: say so
+            raise ValueError("radio_mode %r has no demodulator on the GPU path (am, lsb, usb, cw, nbfm)" % (kv["mod"],))
+        freq = float(kv.get("freq", self.center_khz))
+        f_shift = (freq - self.center_khz) * 1000.0
+        if abs(f_shift) > L.RATE / 2:
+            raise ValueError("tuning %.3f kHz is outside the %g kHz IQ band around %.3f kHz that channel %d receives"
+                             % (freq, IQ_SPAN_KHZ, self.center_khz, self.channel))
+        p = self.hub.params(self.channel)
+        q = _copy_params(p, mode=L.MODE_BY_NAME[mode], f_shift_hz=f_shift, low_cut=float(kv.get("low_cut", p.low_cut)),
+                         high_cut=float(kv.get("high_cut", p.high_cut)))
+        self.hub.set_params(self.channel, q)
+
+    # ---- server -> client
+    def receive_message(self):
+        if self._greeting:
+            return self._greeting.popleft()
+        if self.closed:
+            return None
+        try:
+            if self.kind == "SND":
+                f = self.hub.snd_queue[self.channel].get(timeout=self.timeout)
+                return snd_frame(f, f.rssi, self._next_seq(), adc_overflow=f.adc_overflow)
+            while True:                              # a line summed for some client's N > 1 is not a wire line: skip it
+                line, n, _ = self.hub.wf_queue[self.channel].get(timeout=self.timeout)
+                if n == 1:
+                    return wf_frame(line, self._next_seq())
+        except queue.Empty:
+            return None                              # what a cleanly closed connection returns (:1053-1058)
+
+    def _next_seq(self):
+        self.seq = (self.seq + 1) & 0xFFFFFFFF
+        return self.seq
+
+    def close_connection(self, *a, **k):
+        self.closed = True
+
+
+def wf_frame(byte_line, seq=0, x_bin=0, flags_zoom=0):
+    """One W/F message as the server sends it with "SET wf_comp=0": tag, skip, '<III' header, uint8[1024] (appendix A)"""
+    return bytearray(b"W/F\x00" + struct.pack("<III", x_bin, flags_zoom, seq) + np.asarray(byte_line).astype(np.uint8).tobytes())
+
+
+def snd_frame(pcm, rssi, seq=0, adc_overflow=False):
+    """One SND message with "SET compression=0": tag, flags (bit 1 = ADC overflow), '<I' seq, '>H' smeter with
+    rssi = 0.1 smeter - 127, big-endian int16[512] (utils_supersdr.py:1065-1074)"""
+    smeter = int(min(max(round((float(rssi) + 127.0) * 10.0), 0), 65535))
+    return bytearray(b"SND" + struct.pack("<BI", 2 if adc_overflow else 0, seq) + struct.pack(">H", smeter) +
+                     np.asarray(pcm, np.int16).astype(">i2").tobytes())
+
+
+def _copy_params(p, **over):
+    q = type(p)()
+    for name, _ in p._fields_:
+        setattr(q, name, getattr(p, name))
+    for k, v in over.items():
+        setattr(q, k, v)
+    return q
+
+
+class _Socket:                                       # socket.socket() of the constructors: nothing to dial
+    def connect(self, *a, **k):
+        pass
+
+    def close(self):
+        pass
+
+    def settimeout(self, *a):
+        pass
+
+
+@contextlib.contextmanager
+def _server_is_the_gpu(module, stream):
+    """While the maintainer's constructor runs, the four names it reaches a KiwiSDR with resolve to the GPU stream:
+    the /status probe `kiwi_sdr(host, port)` (utils_supersdr.py:648, 946), `socket.socket()` (:661, 957), the websocket
+    handshake `wsclient.ClientHandshakeProcessor / ClientRequest` (:722-731, 962-963) and `Stream(request, options)`
+    (:733, 964).  Constructors run on the thread that builds the UI, one at a time, as in supersdr.py:107-133, 774."""
+    status = types.SimpleNamespace(users=0, users_max=4, offline=False, active=True, freq_offset=0.0, gps={}, antenna="",
+                                   name="GPU hub", min_freq=0, max_freq=30000)
+    ws = types.SimpleNamespace(ClientHandshakeProcessor=lambda *a, **k: types.SimpleNamespace(handshake=lambda uri: None),
+                               ClientRequest=lambda *a, **k: types.SimpleNamespace(ws_version=None))
+    repl = {"kiwi_sdr": lambda *a, **k: status, "socket": types.SimpleNamespace(socket=_Socket, create_connection=lambda *a, **k: _Socket()),
+            "wsclient": ws, "Stream": lambda *a, **k: stream}
+    saved = {k: getattr(module, k) for k in repl if hasattr(module, k)}
+    try:
+        for k, v in repl.items():
+            setattr(module, k, v)
+        yield
+    finally:
+        for k in repl:
+            if k in saved:
+                setattr(module, k, saved[k])
+            else:
+                delattr(module, k)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the seams
+# ---------------------------------------------------------------------------------------------------------------
+class WaterfallSeams:
+    """In front of the maintainer's kiwi_waterfall: the seams of the module docstring, nothing else.
 
     What the GPU waterfall shows is the channel's 12 kHz IQ band (IQ_SPAN_KHZ around `iq_center_khz`, bin 512 = centre,
     11.72 Hz per bin), not a zoomable 0-30 MHz span: there is no server-side DDC behind it.  The reference's zoom / span
-    arithmetic (`zoom`, `span_khz`, `bins_to_khz`, `set_freq_zoom`, the +3*zoom dB of spectrum_db2col) is kept because
-    supersdr.py drives it, but it only labels the display; `iq_bin_to_khz` / `iq_khz_to_bin` are the true axis of
-    `spectrum` and `wf_data`, and `set_freq_zoom` does not retune anything."""
+    arithmetic keeps running because supersdr.py drives it, but it only labels the display; `iq_bin_to_khz` /
+    `iq_khz_to_bin` are the true axis of `spectrum` and `wf_data`, and `set_freq_zoom` does not retune anything."""
+    _ref_module = None                               # set by bind()
 
     def __init__(self, host_, port_, pass_, zoom_, freq_, eibi, disp, hub=None, channel=0, timeout=5.0):
-        # attribute set-up mirrors utils_supersdr.py:606-645, 692-695
-        self.eibi = eibi
-        self.host, self.port, self.password = host_, port_, pass_
-        self.zoom = zoom_
-        self.freq = freq_
-        self.averaging_n = 1
-        self.wf_auto_scaling = True
-        self.BINS2PIXEL_RATIO = disp.DISPLAY_WIDTH / self.WF_BINS
-        self.old_averaging_n = self.averaging_n
-        self.dynamic_range = self.MIN_DYN_RANGE
-        self.wf_white_flag = False
-        self.terminate = False
-        self.run_index = 0
-        if not self.freq:
-            self.freq = 14200
-        self.tune = self.freq
-        self.radio_mode = "USB"
-        self.span_khz = self.zoom_to_span()
-        self.start_f_khz = self.start_freq()
-        self.end_f_khz = self.end_freq()
-        self.div_list, self.subdiv_list = [], []
-        self.min_bin_spacing = 100
-        self.space_khz = 10
-        self.counter, self.actual_freq = self.start_frequency_to_counter(self.start_f_khz)
-        self.wf_color = None
-        self.freq_offset = 0
-        self.kiwi_wf_timestamp = int(time.time())
-        self.bins_per_khz = self.WF_BINS / self.span_khz
-        self.wf_data = np.zeros((disp.WF_HEIGHT, self.WF_BINS))
-        self.wf_data_tmp = deque([], self.wf_buffer_len)
-        self.avg_spectrum_deque = deque([], self.averaging_n)
-        self.spectrum = np.zeros(self.WF_BINS, np.float32)
-        # the GPU side
         if hub is None:
             raise ValueError("the GPU-backed kiwi_waterfall needs an IQHub (there is no server-side FFT to fall back to)")
-        self.hub, self.channel, self._timeout = hub, channel, timeout
-        self.iq_center_khz = float(self.freq)            # centre of the IQ band this channel receives
+        self.hub, self.channel, self._timeout = hub, int(channel), timeout
+        self.iq_center_khz = float(freq_ if freq_ else 14200)        # centre of the IQ band this channel receives
         self._gpu_post = None
-        self._own_binning = None                         # (sum int32[1024], lines) while binning single lines itself
+        self._own_binning = None                     # (sum int16[1024], lines) while binning single lines itself
+        self._gpu_stream = GpuStream(hub, channel, "W/F", self.iq_center_khz, timeout)
+        with _server_is_the_gpu(self._ref_module, self._gpu_stream):
+            # the maintainer's constructor and its start_stream() (:719-745) run as they are: their handshake lands on the
+            # stand-ins, their Stream(...) is the GPU stream, their "SET zoom= start=" ... commands go to send_message()
+            super().__init__(host_, port_, pass_, zoom_, freq_, eibi, disp)
         if hasattr(hub, "wf_clients"):
-            hub.wf_clients[channel] = self
+            hub.wf_clients[self.channel] = self
 
     # ---- the true frequency axis of the GPU waterfall
     def iq_bin_to_khz(self, bin_):
@@ -386,11 +516,9 @@ class kiwi_waterfall(WaterfallSurface):
     def iq_khz_to_bin(self, khz):
         return (khz - self.iq_center_khz) * self.WF_BINS / IQ_SPAN_KHZ + self.WF_BINS / 2
 
-    def keepalive(self):
-        pass                                             # no server to keep alive
-
     def close_connection(self):
         self.terminate = True
+        self._gpu_stream.close_connection()
 
     def _next_line(self):
         try:
@@ -399,7 +527,7 @@ class kiwi_waterfall(WaterfallSurface):
             self.terminate = True
             return None
 
-    # ---- the seam: utils_supersdr.py:780-785
+    # ---- seam: utils_supersdr.py:780-785
     def receive_spectrum(self):
         """Leaves self.spectrum = float32[WF_BINS] in byte units (dBm = byte - 255)."""
         self.hub.set_averaging(1, self.channel)          # this client bins nothing; others keep their N
@@ -436,7 +564,8 @@ class kiwi_waterfall(WaterfallSurface):
                     return
             # anything else was summed for another N during a change-over: stale
 
-    def spectrum_db2col(self):                           # utils_supersdr.py:787-813
+    # ---- seam: utils_supersdr.py:787-813
+    def spectrum_db2col(self):
         if self._gpu_post is None and self._own_binning is not None and getattr(self.hub, "gpu_post", False):
             wf_sum, n = self._own_binning                # a line this client binned itself: its own db2col run
             self._gpu_post = self.hub.db2col_line(self.channel, wf_sum, n)
@@ -449,12 +578,8 @@ class kiwi_waterfall(WaterfallSurface):
         raise RuntimeError("spectrum_db2col runs on the GPU (ssdr_run_db2col): no result came with this line -- "
                            "the hub was built with gpu_post=False or the line was already converted")
 
-    def set_white_flag(self):                            # utils_supersdr.py:875-877
-        self.wf_color = np.ones_like(self.wf_color) * 255
-        self.wf_data[0, :] = self.wf_color
-
+    # ---- seam: utils_supersdr.py:879-897 with the time binning on the GPU
     def step(self):
-        """One iteration of run() (utils_supersdr.py:879-897)."""
         if self.averaging_n > 1:
             self.receive_binned_spectrum(self.averaging_n)
         else:
@@ -473,84 +598,32 @@ class kiwi_waterfall(WaterfallSurface):
             self.step()
 
 
-class kiwi_sound(SoundSurface):
-    """kiwi_sound (utils_supersdr.py:901-1186) with the SND websocket replaced by the GPU."""
+class SoundSeams:
+    """In front of the maintainer's kiwi_sound: process_audio_stream, play_buffer and the constructor's socket part."""
+    _ref_module = None
 
     def __init__(self, freq_, mode_, lc_, hc_, password_, kiwi_wf, buffer_len, volume_=100, host_=None, port_=None,
                  subrx_=False, hub=None, channel=None, timeout=5.0):
-        self.subrx = subrx_
-        self.kiwi_wf = kiwi_wf
-        self.host = host_ if host_ else kiwi_wf.host
-        self.port = port_ if port_ else kiwi_wf.port
-        self.FULL_BUFF_LEN = max(1, buffer_len)
-        self.audio_buffer = queue.Queue(maxsize=self.FULL_BUFF_LEN)
-        self.terminate = False
-        self.volume = volume_
-        self.max_rssi_before_mute = -20
-        self.mute_counter = 0
-        self.muting_delay = 15
-        self.adc_overflow_flag = False
-        self.status = None
-        self.run_index = 0
-        self.delta_t = 0.0
-        self.rssi = -127
-        self.freq = freq_
-        self.radio_mode = mode_
-        self.lc, self.hc = lc_, hc_
-        # AGC parameter holders: utils_supersdr.py:936-945
-        self.on, self.hang, self.thresh, self.slope = True, False, -80, 0
-        self.decay_other, self.decay_cw, self.gain = 4000, 1000, 50
-        self.min_agc_delay, self.max_agc_delay = 400, 8000
-        self.decay = self.decay_other
-        self.audio_balance = 0.0
-        self.freq_offset = 0
-        self.KIWI_RATE_TRUE = float(self.KIWI_RATE)
-        self.late_flag = False
-        # playback interpolator (utils_supersdr.py:999-1005): taps and history live in the GPU context
-        self.n_tap = 33
-        self.audio_rec = audio_recording(self)           # utils_supersdr.py:1006
         self.hub = hub if hub is not None else kiwi_wf.hub
-        self.channel = kiwi_wf.channel if channel is None else channel
-        if getattr(self.hub, "kiwi_rate", self.KIWI_RATE) != self.KIWI_RATE:     # "audio_init audio_rate=" (:988-994)
-            self.KIWI_RATE = int(self.hub.kiwi_rate)
-            self.KIWI_RATE_TRUE = float(self.KIWI_RATE)
-            self.SAMPLE_RATIO = self.AUDIO_RATE / self.KIWI_RATE
+        self.channel = kiwi_wf.channel if channel is None else int(channel)
         self._timeout = timeout
         self.center_khz = float(getattr(kiwi_wf, "iq_center_khz", kiwi_wf.freq))   # the IQ band's centre: tuning is relative to it
         self.error = None                                # set by play_buffer when it has to give up
+        self.late_flag = False                           # (the reference creates it in run(); play_buffer reads it)
+        self._gpu_stream = GpuStream(self.hub, self.channel, "SND", self.center_khz, timeout)
+        if hasattr(self.hub, "snd_clients"):
+            self.hub.snd_clients[self.channel] = None
+        with _server_is_the_gpu(self._ref_module, self._gpu_stream):
+            # the maintainer's constructor sends "SET mod= ..." and "SET agc= ..." itself (:975-980): the channel is tuned by it
+            super().__init__(freq_, mode_, lc_, hc_, password_, kiwi_wf, buffer_len, volume_, host_, port_, subrx_)
         if hasattr(self.hub, "snd_clients"):
             self.hub.snd_clients[self.channel] = self
-        self.set_mode_freq_pb()
-        self.set_agc_params()
-
-    # ---- control plane: the SET commands become ssdr_set_params
-    def _push_params(self):
-        mode = str(self.radio_mode).lower()
-        if mode not in L.MODE_BY_NAME:                   # "SET mod=iq" and friends have no demodulator here: say so
-            raise ValueError("radio_mode %r has no demodulator on the GPU path (am, lsb, usb, cw, nbfm)" % (self.radio_mode,))
-        f_shift = (self.freq - self.center_khz) * 1000.0
-        if abs(f_shift) > L.RATE / 2:
-            raise ValueError("tuning %.3f kHz is outside the %g kHz IQ band around %.3f kHz that channel %d receives"
-                             % (self.freq, IQ_SPAN_KHZ, self.center_khz, self.channel))
-        p = default_params(mode, f_shift_hz=f_shift, low_cut=float(self.lc), high_cut=float(self.hc),
-                           agc_on=int(bool(self.on)), agc_hang=int(bool(self.hang)), agc_thresh=float(self.thresh),
-                           agc_slope=float(self.slope), agc_decay=float(self.decay), agc_man_gain=float(self.gain))
-        self.hub.set_params(self.channel, p)
-
-    def set_agc_params(self):                            # "SET agc=..." utils_supersdr.py:1022-1024
-        self._push_params()
-
-    def set_mode_freq_pb(self):                          # "SET mod=..." utils_supersdr.py:1026-1029
-        self.decay = self.decay_other if self.radio_mode != "CW" else self.decay_cw
-        self._push_params()
-
-    def keepalive(self):
-        pass
 
     def close_connection(self):
         self.terminate = True
+        self._gpu_stream.close_connection()
 
-    # ---- the seam: utils_supersdr.py:1044-1076
+    # ---- seam: utils_supersdr.py:1044-1076
     def _next_frame(self):
         try:
             return self.hub.snd_queue[self.channel].get(timeout=self._timeout)
@@ -570,28 +643,26 @@ class kiwi_sound(SoundSurface):
         self.rssi = frame.rssi                                              # :1068-1069
         return frame
 
-    def get_audio_chunk(self):                           # utils_supersdr.py:1031-1042
-        try:
-            return self.process_audio_stream()
-        except Exception:
-            self.terminate = True
-            return None
-
-    # ---- playback stage: blocks interpolated, panned and packed by ssdr_run_playbuffer
-    def play_buffer(self, outdata, frame_count, time_info, status):   # utils_supersdr.py:1106-1148
+    # ---- seam: utils_supersdr.py:1106-1148 -- blocks interpolated, panned and packed by ssdr_run_playbuffer
+    def play_buffer(self, outdata, frame_count, time_info, status):
         self.status = status
         if self.late_flag:
             outdata[:] = 0
             return
         frames = [self.audio_buffer.get() for _ in range(self.CHUNKS)]
         blocks = [getattr(f, "play_block", None) for f in frames]
-        if all(b is not None for b in blocks):           # interpolated, panned and packed on the GPU
+        if all(b is not None for b in blocks):
             outdata[:] = np.concatenate(blocks)
             if self.audio_rec.recording_flag:            # :1139-1140: the mono block before the pan, from the same kernel
                 rec = [getattr(f, "rec_block", None) for f in frames]
                 if all(r is not None for r in rec):      # (frames interpolated before start() carry none: skipped)
                     self.audio_rec.audio_buffer.append(np.concatenate(rec))
-            self._mute_logic(outdata)
+            if self.rssi > self.max_rssi_before_mute:    # TX mute, :1142-1147
+                self.mute_counter = self.muting_delay
+            elif self.mute_counter > 0:
+                self.mute_counter -= 1
+            if self.mute_counter > 0:
+                outdata *= 0
             return
         # No host implementation exists.  This is the PortAudio callback, which must not raise: as the
         # reference does for its own stream errors (utils_supersdr.py:1031-1036), play silence, stop the worker and keep
@@ -601,3 +672,21 @@ class kiwi_sound(SoundSurface):
                                   "block -- the hub was built with gpu_post=False")
         logging.error("%s", self.error)
         self.terminate = True
+
+
+def bind(module):
+    """-> namespace(kiwi_waterfall, kiwi_sound, module): the seams in front of `module`'s own two classes.
+
+        import utils_supersdr
+        gpu = supersdr_amd.workers.bind(utils_supersdr)
+        kiwi_wf = gpu.kiwi_waterfall(host, port, password, zoom, freq, eibi, disp, hub=hub, channel=0)
+    """
+    wf = type("kiwi_waterfall", (WaterfallSeams, module.kiwi_waterfall), {"_ref_module": module, "__doc__": WaterfallSeams.__doc__})
+    snd = type("kiwi_sound", (SoundSeams, module.kiwi_sound), {"_ref_module": module, "__doc__": SoundSeams.__doc__})
+    return types.SimpleNamespace(kiwi_waterfall=wf, kiwi_sound=snd, module=module)
+
+
+def bind_headless():
+    """bind() over supersdr_amd.headless: the seams on a bare pair of classes (no UI module needed)"""
+    from . import headless
+    return bind(headless)

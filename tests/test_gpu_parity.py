@@ -514,7 +514,8 @@ def test_error_codes(S):
 def test_workers_end_to_end_on_gpu(S, twin):
     """kiwi_waterfall / kiwi_sound stand-ins fed through IQBatcher -> IQHub -> libssdr: what the two
     seams deliver equals the oracle on the same IQ (waterfall bytes bit-exact, PCM bit-exact vs twin)."""
-    from supersdr_amd.workers import IQHub, kiwi_waterfall, kiwi_sound
+    from supersdr_amd.workers import IQHub, bind_headless
+    kiwi_waterfall, kiwi_sound = bind_headless().kiwi_waterfall, bind_headless().kiwi_sound
     from supersdr_amd.iqstream import IQBatcher
 
     class Disp:
@@ -552,7 +553,8 @@ def test_hub_pipelined_feed_equals_the_synchronous_hub_and_flags_reach_the_seam(
     """IQHub on ring buffers: pipeline=True (ssdr_feed_*: pinned slots, three streams) hands out the same lines and
     frames as the synchronous hub, `depth - 1` superframes later; on the synchronous hub a clipped sample sets
     kiwi_sound.adc_overflow_flag for exactly its frame (utils_supersdr.py:1066-1067)."""
-    from supersdr_amd.workers import IQHub, kiwi_waterfall, kiwi_sound
+    from supersdr_amd.workers import IQHub, bind_headless
+    kiwi_waterfall, kiwi_sound = bind_headless().kiwi_waterfall, bind_headless().kiwi_sound
     n_ch, n_sf = 3, 7
     iq = O.synth_iq(n_ch, n_sf * 1024, seed=61)
     iq[1, 2 * 1024 + 600, 1] = -32768                              # superframe 2, second audio frame, channel 1
@@ -754,8 +756,22 @@ def test_checkpoint_restore_continues_bit_exactly(S):
             assert a.shape == b.shape and np.array_equal(a, b), k
     assert want[0][0].shape[0] == 1 and want[1][0].shape[0] == 1    # 2 lines per batch, N = 3: a group closes in each of them
     with S.SsdrEngine(n_ch + 1) as eng:
+        with pytest.raises(ValueError):
+            eng.restore(blob)                      # channel count mismatch: the blob's size says so
+    with S.SsdrEngine(n_ch) as eng:                # short, foreign and damaged blobs are refused, nothing is read out of bounds
+        with pytest.raises(ValueError):
+            eng.restore(blob[:-8])
+        bad = bytearray(blob)
+        bad[0] ^= 0xFF                             # magic
         with pytest.raises(S.SsdrError):
-            eng.restore(blob)                      # channel count mismatch
+            eng.restore(bytes(bad))
+        bad = bytearray(blob)
+        off = 48 + 44                              # header (48 B), consts[0].ntap
+        bad[off:off + 4] = (4096).to_bytes(4, "little")
+        with pytest.raises(S.SsdrError):
+            eng.restore(bytes(bad))
+        eng.restore(blob)                          # and the ctx is still usable afterwards
+        assert eng.averaging == 3
     # the input rate and the waterfall framing travel with the blob
     iq2 = O.synth_iq(3, 4 * 1024, seed=72)
     with S.SsdrEngine(3) as eng:
@@ -769,7 +785,7 @@ def test_checkpoint_restore_continues_bit_exactly(S):
         want2 = (eng.run_wf().copy(), eng.run_audio()[0].copy())
     with S.SsdrEngine(3) as eng:
         eng.restore(blob2)
-        eng.decim, eng.hop = 2, 512                # (the Python wrapper's own bookkeeping of buffer shapes)
+        assert (eng.decim, eng.hop) == (2, 512)    # the wrapper's buffer bookkeeping follows the blob
         eng.push_iq(iq2[:, 2048:])
         got2 = (eng.run_wf().copy(), eng.run_audio()[0].copy())
         assert int(eng.get_consts()[0]["decim"][0]) == 2

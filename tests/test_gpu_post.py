@@ -324,7 +324,8 @@ def test_workers_use_gpu_db2col_and_play_buffer(S):
     the restated reference code (oracle) on the same line / frames, including N = 2 time binning, a zoom change,
     manual colour limits, volume and pan."""
     import queue
-    from supersdr_amd.workers import IQHub, kiwi_waterfall, kiwi_sound
+    from supersdr_amd.workers import IQHub, bind_headless
+    kiwi_waterfall, kiwi_sound = bind_headless().kiwi_waterfall, bind_headless().kiwi_sound
 
     class Disp:
         DISPLAY_WIDTH, WF_HEIGHT = 1024, 8

@@ -3,7 +3,10 @@
 The GPU engine is replaced by a test double that answers with the oracle (twin C for the two kernels,
 NumPy restatements for db2col / play_buffer), so what is tested here is the host plumbing around the
 seams: batching, queues, time binning by division, hand-out of the db2col / play_buffer results, the
-KiwiWorker retry policy, the wire <-> int16 conversion and the channel sharding."""
+wire <-> int16 conversion, the channel sharding -- and the binding itself: every test that takes the `gpu` fixture runs
+twice, with the seams bound over the package's bare `headless` classes and over the REAL reference's
+`utils_supersdr.kiwi_waterfall / kiwi_sound` (where /root/reference exists: tests/refload.py); the tests that exercise the
+reference's own code through the seams (zoom arithmetic, passband tables, pacing loop, recorder, KiwiWorker) take `ref`."""
 import os
 import queue
 import sys
@@ -18,7 +21,26 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import ssdr_oracle as O  # noqa: E402
 import twinlib  # noqa: E402
 
+import refload  # noqa: E402
+
 GOLD = os.path.join(ROOT, "tests", "golden")
+NEEDS_REF = pytest.mark.skipif(not refload.available(), reason="the reference (utils_supersdr.py) is not on this box")
+
+
+@pytest.fixture(params=["headless", pytest.param("reference", marks=NEEDS_REF)])
+def gpu(request):
+    """the seams bound over a pair of worker classes: namespace(kiwi_waterfall, kiwi_sound, module)"""
+    from supersdr_amd.workers import bind, bind_headless
+    return bind_headless() if request.param == "headless" else bind(refload.load()[0])
+
+
+@pytest.fixture
+def ref():
+    """the seams bound over the real reference's classes"""
+    if not refload.available():
+        pytest.skip("the reference (utils_supersdr.py) is not on this box")
+    from supersdr_amd.workers import bind
+    return bind(refload.load()[0])
 
 
 class TwinEngine:
@@ -70,6 +92,14 @@ class TwinEngine:
 
     def set_wf_lines(self, lines):
         self.last_wf = np.array(lines, np.int16)
+
+    def db2col_line(self, wf_sum, n_avg, k):
+        spec = np.asarray(wf_sum, np.int16).astype(np.float32) / np.float32(n_avg)
+        col, lo, hi, dyn, mn, mx = O.spectrum_db2col(
+            spec, int(k.zoom), auto=bool(k.auto_scale), low_clip_db=k.low_clip_db, high_clip_db=k.high_clip_db,
+            dynamic_range=k.dynamic_range, delta_low_db=k.delta_low_db, delta_high_db=k.delta_high_db)
+        k.low_clip_db, k.high_clip_db, k.dynamic_range, k.wf_min_db, k.wf_max_db = lo, hi, dyn, mn, mx
+        return col
 
     def set_recording(self, on):
         self.recording = bool(on)
@@ -127,16 +157,67 @@ class Eibi:
         self.calls.append((a, b))
 
 
-def make_pair(n_ch=2, channel=1, zoom=10, freq=7100.0):
-    from supersdr_amd.workers import IQHub, kiwi_waterfall, kiwi_sound
-    hub = IQHub(n_ch, engine=TwinEngine(n_ch))
-    wf = kiwi_waterfall("gpu", 0, "", zoom, freq, Eibi(), Disp(), hub=hub, channel=channel, timeout=0.2)
-    snd = kiwi_sound(freq, "USB", 30, 3000, "", wf, 4)
+def make_pair(gpu, n_ch=2, channel=1, zoom=10, freq=7100.0, **hub_kw):
+    from supersdr_amd.workers import IQHub
+    hub = IQHub(n_ch, engine=TwinEngine(n_ch), **hub_kw)
+    wf = gpu.kiwi_waterfall("gpu", 0, "", zoom, freq, Eibi(), Disp(), hub=hub, channel=channel, timeout=0.2)
+    snd = gpu.kiwi_sound(freq, "USB", 30, 3000, "", wf, 4)
     return hub, wf, snd
 
 
-def test_seams_deliver_gpu_results_per_channel():
-    hub, wf, snd = make_pair()
+def test_the_bound_classes_are_the_maintainers_own(ref):
+    """bind(): the seams sit in front of utils_supersdr's classes; everything that is not a seam is the reference's own
+    code object (nothing restated in the package), and the constructor of the reference ran as it is."""
+    U = ref.module
+    assert issubclass(ref.kiwi_waterfall, U.kiwi_waterfall) and issubclass(ref.kiwi_sound, U.kiwi_sound)
+    for name in ("set_freq_zoom", "gen_div", "zoom_to_span", "start_frequency_to_counter", "change_passband", "set_white_flag",
+                 "bins_to_khz", "offset_to_bin", "keepalive", "start_stream"):
+        assert getattr(ref.kiwi_waterfall, name) is getattr(U.kiwi_waterfall, name), name
+    for name in ("run", "change_agc_delay", "change_passband", "set_agc_params", "set_mode_freq_pb", "get_audio_chunk", "keepalive"):
+        assert getattr(ref.kiwi_sound, name) is getattr(U.kiwi_sound, name), name
+    for name in ("receive_spectrum", "spectrum_db2col", "run"):
+        assert getattr(ref.kiwi_waterfall, name) is not getattr(U.kiwi_waterfall, name), name
+    for name in ("process_audio_stream", "play_buffer"):
+        assert getattr(ref.kiwi_sound, name) is not getattr(U.kiwi_sound, name), name
+    saved = (U.kiwi_sdr, U.socket, U.wsclient, U.Stream)
+    hub, wf, snd = make_pair(ref, n_ch=1, channel=0)
+    assert (U.kiwi_sdr, U.socket, U.wsclient, U.Stream) == saved          # the stand-ins were there for the constructors only
+    assert wf.wf_stream is wf._gpu_stream and snd.stream is snd._gpu_stream
+    assert isinstance(snd.kiwi_filter, U.filtering) and snd.n_tap == 33 and isinstance(snd.audio_rec, U.audio_recording)
+    assert wf.wf_stream.zoom == 10                                        # "SET zoom=%d start=%d" of start_stream arrived
+    assert hub.engine.param_log[-1][1].mode == 2 and hub.engine.param_log[-1][1].agc_thresh == -80    # "SET mod=usb", "SET agc="
+
+
+def test_unmodified_reference_classes_run_on_the_gpu_stream(ref):
+    """GpuStream alone, without the seams: the reference's OWN receive_spectrum / process_audio_stream parse the W/F and
+    SND frames it builds from GPU results (wire format of utils_supersdr.py:782-784, 1065-1074) -- same numbers."""
+    from supersdr_amd.workers import IQHub, GpuStream
+    U = ref.module
+    hub = IQHub(1, engine=TwinEngine(1), gpu_post=False)
+    iq = O.synth_iq(1, 2 * 1024, seed=21)
+    hub.feed(0, iq[0])
+    wf = U.kiwi_waterfall.__new__(U.kiwi_waterfall)                       # no constructor: only the stream and what the method reads
+    wf.wf_stream = GpuStream(hub, 0, "W/F", 7100.0, timeout=0.2)
+    assert bytes(wf.wf_stream.receive_message()[:3]) == b"W/F"            # the constructor's greeting
+    U.kiwi_waterfall.receive_spectrum(wf)
+    want = twinlib.load().wf(iq, 1)
+    assert wf.spectrum.dtype == np.float32 and np.array_equal(wf.spectrum, want[0, 0].astype(np.float32))
+    snd = U.kiwi_sound.__new__(U.kiwi_sound)
+    snd.stream = GpuStream(hub, 0, "SND", 7100.0, timeout=0.2)
+    snd.run_index, snd.delta_t, snd.terminate, snd.kiwi_wf = 0, 0.0, False, wf
+    assert b"MSG audio_init" in bytes(snd.stream.receive_message()) and bytes(snd.stream.receive_message()[:3]) == b"SND"
+    eng = hub.engine
+    st, hist = twinlib.fresh_state(eng.consts)
+    ref_pcm, ref_rssi = twinlib.load().audio(iq, eng.consts, eng.taps, st, hist)
+    for f in range(4):
+        s = U.kiwi_sound.process_audio_stream(snd)
+        assert s.dtype == np.int16 and np.array_equal(s, ref_pcm[0, f * 512:(f + 1) * 512])
+        assert abs(snd.rssi - float(ref_rssi[0, f])) <= 0.05 + 1e-9      # the header carries rssi in 0.1 dB steps
+        assert snd.adc_overflow_flag is False
+
+
+def test_seams_deliver_gpu_results_per_channel(gpu):
+    hub, wf, snd = make_pair(gpu)
     iq = O.synth_iq(2, 3 * 1024, seed=8, modes=[0, 1])
     snd.freq = 7100.0 + ((1 * 37) % 97 - 48) * 0.1           # tune channel 1 onto its carrier (kHz)
     snd.set_mode_freq_pb()
@@ -161,8 +242,8 @@ def test_seams_deliver_gpu_results_per_channel():
     assert snd.terminate and wf.terminate
 
 
-def test_waterfall_run_loop_binning_scroll_and_db2col_vs_reference_golden():
-    hub, wf, snd = make_pair(n_ch=1, channel=0, zoom=8)
+def test_waterfall_run_loop_binning_scroll_and_db2col_vs_reference_golden(gpu):
+    hub, wf, snd = make_pair(gpu, n_ch=1, channel=0, zoom=8)
     # db2col has no host implementation: without a result from ssdr_run_db2col the method refuses
     wf.spectrum = np.zeros(1024, np.float32)
     with pytest.raises(RuntimeError):
@@ -182,12 +263,15 @@ def test_waterfall_run_loop_binning_scroll_and_db2col_vs_reference_golden():
     assert wf.run_index == 5
     # 3-deep delay buffer, newest line on row 0 (utils_supersdr.py:893-897)
     assert (wf.wf_data[2:] == 0).all() and (wf.wf_data[0] != 0).any() and (wf.wf_data[1] != 0).any()
-    wf.set_white_flag()
-    assert (wf.wf_data[0] == 255).all()
+    if hasattr(wf, "set_white_flag"):                          # the reference's (:875-877)
+        wf.set_white_flag()
+        assert (wf.wf_data[0] == 255).all()
 
 
-def test_freq_zoom_arithmetic():
-    hub, wf, snd = make_pair(n_ch=1, channel=0, zoom=10, freq=7100.0)
+def test_freq_zoom_arithmetic(ref):
+    """the reference's own zoom / tick arithmetic keeps running on the bound object (its "SET zoom= start=" lands in the
+    GPU stream, which has nothing to retune)"""
+    hub, wf, snd = make_pair(ref, n_ch=1, channel=0, zoom=10, freq=7100.0)
     assert wf.span_khz == 30000 / 1024 and wf.start_f_khz == 7100 - wf.span_khz / 2
     assert wf.set_freq_zoom(14200.0, 0) == 15000 and wf.span_khz == 30000
     assert wf.set_freq_zoom(1.0, 10) == wf.span_khz / 2 and wf.start_f_khz == 0
@@ -197,13 +281,16 @@ def test_freq_zoom_arithmetic():
     assert wf.bins_to_khz(512) == pytest.approx(7100.0) and wf.offset_to_bin(wf.span_khz) == 1024
     assert wf.deltabins_to_khz(1024) == pytest.approx(wf.span_khz)
     assert wf.counter == round(wf.start_f_khz / 30000 * 2 ** 14 * 1024)
+    assert (wf.wf_stream.zoom, wf.wf_stream.start) == (8, wf.counter)
     assert wf.div_list and wf.subdiv_list
     wf.radio_mode = "LSB"
     assert wf.change_passband(10, -20) == (-2980, -40)
 
 
-def test_sound_control_plane_and_passbands():
-    hub, wf, snd = make_pair(n_ch=1, channel=0)
+def test_sound_control_plane_and_passbands(ref):
+    """the reference's set_mode_freq_pb / set_agc_params / change_passband / change_agc_delay, unmodified: their SET commands
+    become the channel's ssdr_chan_params"""
+    hub, wf, snd = make_pair(ref, n_ch=1, channel=0)
     eng = hub.engine
     for mode, want in (("USB", (30, 3000)), ("LSB", (-3000, -30)), ("AM", (-6000, 6000)), ("CW", (400, 800))):
         snd.radio_mode = mode
@@ -222,8 +309,8 @@ def test_sound_control_plane_and_passbands():
     assert eng.param_log[-1][1].f_shift_hz == pytest.approx(1500.0)
 
 
-def test_play_buffer_hands_out_gpu_blocks():
-    hub, wf, snd = make_pair(n_ch=1, channel=0)
+def test_play_buffer_hands_out_gpu_blocks(gpu):
+    hub, wf, snd = make_pair(gpu, n_ch=1, channel=0)
     iq = O.synth_iq(1, 2 * 1024, seed=3)
     hub.feed(0, iq[0])
     ref = O.PlayBuffer()
@@ -245,12 +332,13 @@ def test_play_buffer_hands_out_gpu_blocks():
     snd.late_flag = False
 
 
-def test_play_buffer_wide_rate_blocks_and_tx_mute():
-    """20.25 kHz KiwiSDR: KIWI_RATE / SAMPLE_RATIO follow the hub, blocks are 1213 stereo samples (utils_supersdr.py:1211)"""
-    from supersdr_amd.workers import IQHub, kiwi_waterfall, kiwi_sound
+def test_play_buffer_wide_rate_blocks_and_tx_mute(gpu):
+    """20.25 kHz KiwiSDR: the stream greets with "MSG audio_init audio_rate=20250" and the worker's own constructor takes
+    KIWI_RATE / SAMPLE_RATIO from it (utils_supersdr.py:988-994); blocks are 1213 stereo samples (:1211)"""
+    from supersdr_amd.workers import IQHub
     hub = IQHub(1, engine=TwinEngine(1), kiwi_rate=20250)
-    wf = kiwi_waterfall("gpu", 0, "", 10, 7100.0, Eibi(), Disp(), hub=hub, channel=0, timeout=0.2)
-    snd = kiwi_sound(7100.0, "AM", -6000, 6000, "", wf, 4)
+    wf = gpu.kiwi_waterfall("gpu", 0, "", 10, 7100.0, Eibi(), Disp(), hub=hub, channel=0, timeout=0.2)
+    snd = gpu.kiwi_sound(7100.0, "AM", -6000, 6000, "", wf, 4)
     assert snd.KIWI_RATE == 20250 and snd.SAMPLE_RATIO == 48000 / 20250 and int(512 * snd.SAMPLE_RATIO) == 1213
     hub.feed(0, O.synth_iq(1, 1024, seed=4)[0])
     ref = O.PlayBufferResampled()
@@ -283,10 +371,17 @@ def test_iq_wire_roundtrip_and_batcher_vs_reference_golden():
     assert fed[0][0] == 3 and np.array_equal(fed[0][1], g["iq_int16"]) and b.dropped == 1 and b.last_rssi == -41.0
 
 
-def test_worker_retry_policy():
-    from supersdr_amd.iqstream import GpuKiwiWorker, KiwiServerTerminatedConnection, KiwiTooBusyError, KiwiTimeLimitError
+def test_reference_kiwiworker_drives_an_iqbatcher_recorder():
+    """kiwi/worker.py:10-79 unchanged: KiwiWorker(args=(recorder, options, run_event)) with a recorder whose IQ hook is
+    IQBatcher -- connect / open / run / close and the retry table are the reference's, the IQ lands in the hub."""
+    if not refload.available():
+        pytest.skip("the reference (kiwi/worker.py) is not on this box")
+    _, KW, KC = refload.load()
+    from supersdr_amd.iqstream import IQBatcher
+    g = np.load(os.path.join(GOLD, "frames.npz"))
+    fed = []
 
-    class Rec:
+    class Rec(IQBatcher):
         def __init__(self, script):
             self.script, self.log = list(script), []
 
@@ -302,24 +397,26 @@ def test_worker_retry_policy():
         def run(self):
             step = self.script.pop(0) if self.script else "limit"
             self.log.append("run:" + step)
+            if step == "ok":
+                self._process_iq_samples(len(self.log), g["iq_complex64"], -40.0, {})    # what KiwiSDRStream.run ends in
             if step == "term":
-                raise KiwiServerTerminatedConnection("bye")
+                raise KC.KiwiServerTerminatedConnection("bye")
             if step == "busy":
-                raise KiwiTooBusyError("busy")
+                raise KC.KiwiTooBusyError("busy")
             if step == "limit":
-                raise KiwiTimeLimitError("limit")
+                raise KC.KiwiTimeLimitError("limit")
 
         def close(self):
             self.log.append("close")
 
     def run(script, **opt):
-        o = types.SimpleNamespace(connect_retries=2, connect_timeout=0, server_host="h", server_port=1,
+        o = types.SimpleNamespace(connect_retries=2, connect_timeout=0, server_host="h", server_port=1, rigctl_enabled=False,
                                   is_kiwi_tdoa=False, no_api=False, status=0)
         o.__dict__.update(opt)
         ev = threading.Event()
         ev.set()
-        rec = Rec(script)
-        w = GpuKiwiWorker(args=(rec, o, ev))
+        rec = Rec(script).attach(types.SimpleNamespace(feed=lambda ch, x: fed.append((ch, x.copy()))), 5)
+        w = KW.KiwiWorker(args=(rec, o, ev))
         w._event.wait = lambda timeout=None: None              # do not really sleep 5/15 s
         w.run()
         return rec.log, o, ev
@@ -327,12 +424,11 @@ def test_worker_retry_policy():
     log, o, ev = run(["ok", "term", "ok", "limit"])
     assert log == ["connect", "open", "run:ok", "run:term", "close", "connect", "open", "run:ok", "run:limit", "close"]
     assert not ev.is_set()
+    assert len(fed) == 2 and fed[0][0] == 5 and np.array_equal(fed[0][1], g["iq_int16"])
     log, o, ev = run(["refuse", "refuse"])
     assert log == ["connect", "connect", "close"]              # connect_retries exhausted
     log, o, ev = run(["busy"], is_kiwi_tdoa=True)
     assert o.status == 2 and log[-1] == "close"
-    log, o, ev = run(["term"], no_api=True)
-    assert log == ["connect", "open", "run:term", "close", "close"]
 
 
 def test_channel_blocks_partition():
@@ -357,16 +453,16 @@ def test_kiwi_wav_reader_vs_reference_golden():
 
 
 # ------------------------------------------------------------------ round 2: hardening of the host shim
-def test_sound_run_pacing_late_drop_and_refill_cycle(monkeypatch):
-    """kiwi_sound.run (utils_supersdr.py:1150-1186) through a whole late / refill cycle on a scripted clock: frames on
+@pytest.mark.timeout(60)
+def test_sound_run_pacing_late_drop_and_refill_cycle(ref, monkeypatch):
+    """the reference's kiwi_sound.run (utils_supersdr.py:1150-1186), unmodified, through a whole late / refill cycle on a scripted clock: frames on
     time are queued; a stall longer than (FULL_BUFF_LEN + 2) frames sets late_flag, frames read while late are dropped
     (with their 48 kHz blocks: nothing is left behind) and play_buffer plays silence; once the delay is worked off the
     queue is refilled to FULL_BUFF_LEN and playback resumes."""
-    import supersdr_amd.ref_surface as RS
     from supersdr_amd.workers import Frame
-    hub, wf, snd = make_pair(n_ch=1, channel=0)
+    hub, wf, snd = make_pair(ref, n_ch=1, channel=0)
     clock = {"ns": 10 ** 12}
-    monkeypatch.setattr(RS.time, "time_ns", lambda: clock["ns"])
+    monkeypatch.setattr(ref.module.time, "time_ns", lambda: clock["ns"])
     ms = 512 / 12000 * 1000
     # (read duration in ms) per get_audio_chunk call: 8 on time, one 400 ms stall, then fast reads
     script = [ms] * 8 + [400.0] + [1.0] * 40
@@ -409,12 +505,12 @@ def test_sound_run_pacing_late_drop_and_refill_cycle(monkeypatch):
     assert (out == 0).all() and snd.audio_buffer.qsize() == n0
 
 
-def test_adc_overflow_flag_drift_skip_and_recording_branch(tmp_path, monkeypatch):
+def test_adc_overflow_flag_drift_skip_and_recording_branch(gpu, tmp_path, monkeypatch):
     """the SND header semantics at the seam: adc_overflow_flag follows the frame's flag (utils_supersdr.py:1066-1067), the
     sample-rate drift rule reads and discards one frame (:1049-1052), and while audio_rec records, play_buffer appends
     the mono block that the same GPU run produced (:1139-1140) -- written out as a 48 kHz mono WAV by stop()."""
     import wave
-    hub, wf, snd = make_pair(n_ch=1, channel=0)
+    hub, wf, snd = make_pair(gpu, n_ch=1, channel=0)
     iq = O.synth_iq(1, 3 * 1024, seed=3)
     iq[0, 1024 + 700, 0] = 32767                                  # frame 3 (second frame of superframe 1) clips
     hub.feed(0, iq[0][:2048])
@@ -435,8 +531,11 @@ def test_adc_overflow_flag_drift_skip_and_recording_branch(tmp_path, monkeypatch
     snd.delta_t = 0.0
     # recording
     monkeypatch.chdir(tmp_path)
-    hub2, wf2, snd2 = make_pair(n_ch=1, channel=0)
-    snd2.audio_rec.start()
+    hub2, wf2, snd2 = make_pair(gpu, n_ch=1, channel=0)
+    if hasattr(snd2.audio_rec, "start"):
+        snd2.audio_rec.start()                                    # the reference's recorder (utils_supersdr.py:151-155)
+    else:
+        snd2.audio_rec.recording_flag = True
     assert snd2.audio_rec.recording_flag
     hub2.feed(0, iq[0][:2048])
     ref = O.PlayBuffer()
@@ -449,15 +548,18 @@ def test_adc_overflow_flag_drift_skip_and_recording_branch(tmp_path, monkeypatch
         ref(s, volume=snd2.volume, balance=snd2.audio_balance)
         want.append(ref.rec.copy())
     assert len(snd2.audio_rec.audio_buffer) == 4
-    snd2.audio_rec.stop()
+    assert np.array_equal(np.concatenate(snd2.audio_rec.audio_buffer), np.concatenate(want))
+    if not hasattr(snd2.audio_rec, "stop"):
+        return
+    snd2.audio_rec.stop()                                         # ... and its WAV writer (:157-172)
     with wave.open(snd2.audio_rec.filename, "rb") as w:
         assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 48000)
         data = np.frombuffer(w.readframes(w.getnframes()), np.int16)
     assert np.array_equal(data, np.concatenate(want))
 
 
-def test_unknown_mode_and_out_of_band_tuning_are_errors():
-    hub, wf, snd = make_pair(n_ch=1, channel=0)
+def test_unknown_mode_and_out_of_band_tuning_are_errors(gpu):
+    hub, wf, snd = make_pair(gpu, n_ch=1, channel=0)
     n0 = len(hub.engine.param_log)
     snd.radio_mode = "IQ"
     with pytest.raises(ValueError, match="no demodulator"):
@@ -479,14 +581,14 @@ def test_unknown_mode_and_out_of_band_tuning_are_errors():
     assert wf.iq_bin_to_khz(512) == 7100.0 and wf.iq_bin_to_khz(0) == 7094.0 and wf.iq_khz_to_bin(7106.0) == 1024
 
 
-def test_two_waterfall_clients_with_different_averaging_do_not_disturb_each_other():
+def test_two_waterfall_clients_with_different_averaging_do_not_disturb_each_other(gpu):
     """averaging is per kiwi_waterfall (utils_supersdr.py:881-886).  Client 0 wants N = 1, client 1 wants
     N = 3 on the same hub: the GPU then delivers single lines, client 1 takes the reference's mean of 3 of them and
     gets its db2col from the GPU for the binned line; nobody's group is restarted, nobody spins."""
-    from supersdr_amd.workers import IQHub, kiwi_waterfall
-    hub = IQHub(2, engine=TwinEngine(2))
-    a = kiwi_waterfall("gpu", 0, "", 10, 7100.0, None, Disp(), hub=hub, channel=0, timeout=0.2)
-    b = kiwi_waterfall("gpu", 0, "", 10, 7100.0, None, Disp(), hub=hub, channel=1, timeout=0.2)
+    from supersdr_amd.workers import IQHub
+    hub = IQHub(2, engine=TwinEngine(2), trace_rows=0)
+    a = gpu.kiwi_waterfall("gpu", 0, "", 10, 7100.0, Eibi(), Disp(), hub=hub, channel=0, timeout=0.2)
+    b = gpu.kiwi_waterfall("gpu", 0, "", 10, 7100.0, Eibi(), Disp(), hub=hub, channel=1, timeout=0.2)
     b.averaging_n = 3
     iq = O.synth_iq(2, 6 * 1024, seed=12)
     hub.set_averaging(1, 0)

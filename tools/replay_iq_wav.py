@@ -34,7 +34,13 @@ def write_wav(path, stereo_i16, rate=48000):
 def replay(wav, mode="AM", tune_khz=0.0, averaging=1, volume=100, zoom=10, center_khz=7100.0, device=0, probe=None):
     """-> (int16 [n, 2] 48 kHz stereo, float64 [rows, 1024] waterfall rows oldest first, float [frames] rssi)"""
     from supersdr_amd.iqstream import read_kiwi_iq_wav
-    from supersdr_amd.workers import IQHub, kiwi_waterfall, kiwi_sound
+    from supersdr_amd.workers import IQHub, bind, bind_headless
+    try:                                     # next to supersdr.py: the maintainer's own classes; anywhere else: the bare pair
+        import utils_supersdr
+        gpu = bind(utils_supersdr)
+    except Exception:
+        gpu = bind_headless()
+    kiwi_waterfall, kiwi_sound = gpu.kiwi_waterfall, gpu.kiwi_sound
     blocks, _ = read_kiwi_iq_wav(wav)
     hub = IQHub(1, device=device)
     wf = kiwi_waterfall("replay", 0, "", zoom, center_khz, _Eibi(), _Disp(), hub=hub, channel=0, timeout=0.05)
