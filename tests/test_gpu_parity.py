@@ -413,6 +413,11 @@ def test_random_parameter_surface_bit_exact_vs_twin(S, twin, seed, n_frames):
     assert np.array_equal(np.concatenate(fl, axis=1), flags_t)
     assert st_g.tobytes() == st.tobytes() and np.array_equal(hist_g, hist)
     assert np.array_equal(np.concatenate(wfs), twin.wf(iq, 1, consts["wf_cal_lin"]))
+    # ... and against the normative float64 definition, under the conditioning rule of tests/tolerances.py: EVERY
+    # well-conditioned channel within 1e-5 RMS of full scale, every channel within 1e-3
+    import tolerances as T
+    pcm_o, rssi_o = O.audio_chain(iq, [O.ChanParams(**k) for k in kw])
+    T.assert_pcm_within_tolerance(np.concatenate(ps_, axis=1), pcm_o, iq, rssi_o, [k["smeter_cal_db"] for k in kw], min_well=n_ch // 3)
     # the host-compiled constants are the oracle's
     for c in (0, 17, 95):
         k = O.compile_params(O.ChanParams(**kw[c]))
@@ -524,10 +529,8 @@ def test_workers_end_to_end_on_gpu(S, twin):
     n_ch = 3
     hub = IQHub(n_ch)
     wfs = [kiwi_waterfall("gpu", 0, "", 10, 7100.0, None, Disp(), hub=hub, channel=c, timeout=1.0) for c in range(n_ch)]
-    snds = [kiwi_sound(7100.0 + ((c * 37) % 97 - 48) * 0.1, ["AM", "USB", "LSB"][c], 30, 3000, "", wfs[c], 4) for c in range(n_ch)]
-    for c, s in enumerate(snds):
-        s.change_passband(0, 0)
-        s.set_mode_freq_pb()
+    pb = {"AM": (-6000, 6000), "USB": (30, 3000), "LSB": (-3000, -30)}          # the reference's passbands (utils_supersdr.py:46-50)
+    snds = [kiwi_sound(7100.0 + ((c * 37) % 97 - 48) * 0.1, m, pb[m][0], pb[m][1], "", wfs[c], 4) for c, m in enumerate(["AM", "USB", "LSB"])]
     iq = O.synth_iq(n_ch, 4 * 1024, seed=31, modes=[0, 1, 2])
     feeders = [IQBatcher().attach(hub, c) for c in range(n_ch)]
     for k in range(8):                                        # 512-sample IQ frames, as the server sends them
@@ -875,10 +878,10 @@ def test_decimating_front_end_bit_exact_vs_twin_and_oracle(S, twin, decim):
     for pos0, nf, wf in wfs:                                           # the waterfall sees the wide stream, 1024 samples per line
         seg = iq[:, pos0 * 512 * decim:(pos0 + nf) * 512 * decim]
         assert np.array_equal(wf, twin.wf(seg, 1, consts["wf_cal_lin"]))
-    pcm_o, _ = O.audio_chain(iq, [O.ChanParams(**k) for k in kw], decim)
-    ok = np.array([k["mode"] != "nbfm" for k in kw])                  # (an FM discriminator on a silent channel is noise on noise)
-    rms = np.sqrt(((pcm.astype(np.float64) - pcm_o) ** 2).mean(axis=1)) / 32768.0
-    assert np.sort(rms[ok])[: int(0.9 * ok.sum())].max() < PCM_RMS_TOL, np.sort(rms[ok])
+    # vs the float64 oracle: every well-conditioned channel (tests/tolerances.py), no best-of selection
+    import tolerances as T
+    pcm_o, rssi_o = O.audio_chain(iq, [O.ChanParams(**k) for k in kw], decim)
+    T.assert_pcm_within_tolerance(pcm, pcm_o, iq, rssi_o, [k["smeter_cal_db"] for k in kw], min_well=n_ch // 4)
     with S.SsdrEngine(2) as eng:
         with pytest.raises(S.SsdrError):
             eng.set_decimation(3)
@@ -940,3 +943,132 @@ def test_fused_superframe_kernel_equals_the_two_kernels(S, twin, n_ch):
         eng.set_params(1, [S.default_params("am")])
         eng.set_averaging(3)
         assert eng.run_chain() == (0, False)
+
+
+# ------------------------------------------------------------------ round 3
+def test_set_concurrent_bits_are_bit_identical_to_the_default(S):
+    """ssdr_set_concurrent: bit 0 (audio stage on a second stream beside the waterfall kernel, which then takes
+    one workgroup per CU) and bit 1 (the per-path audio kernels one after the other) are scheduling only -- waterfall, PCM,
+    RSSI, flags, carried state and FIR history of a mixed batch (all three frame paths, N = 3 groups straddling calls) are
+    bit-identical to the default in every combination."""
+    n_ch, calls = 37, [2, 6, 4]
+    iq = O.synth_iq(n_ch, sum(calls) * 512, seed=77)
+    iq[3, 700, 0] = 32767
+    ps, _ = mixed_params(S, n_ch)
+    outs = {}
+    for mode in (0, 1, 2, 3):
+        with S.SsdrEngine(n_ch) as eng:
+            eng.set_params(0, ps)
+            eng.set_averaging(3)
+            eng.set_concurrent(mode)
+            assert all(n > 0 for n in eng.audio_paths())
+            wfs, pcms, rssis, flags, pos = [], [], [], [], 0
+            for nf in calls:
+                eng.push_iq(iq[:, pos * 512:(pos + nf) * 512])
+                wfs.append(eng.run_wf())
+                p, r = eng.run_audio()
+                pcms.append(p), rssis.append(r), flags.append(eng.audio_flags())
+                pos += nf
+            st, hist = eng.get_state()
+            sums = eng.output_checksum()
+        outs[mode] = (np.concatenate(wfs), np.concatenate(pcms, axis=1), np.concatenate(rssis, axis=1),
+                      np.concatenate(flags, axis=1), st.tobytes(), hist, sums)
+    for mode in (1, 2, 3):
+        for a, b in zip(outs[0], outs[mode]):
+            assert (a == b) if isinstance(a, (bytes, tuple)) else np.array_equal(a, b), mode
+    assert outs[0][3].sum() == 1
+
+
+def test_output_checksum_is_a_function_of_the_results_only(S):
+    """ssdr_output_checksum (the multi-GPU parity hash): the same bytes give the same three sums whatever
+    produced them (two kernels or the fused one, device-generated or pushed input, a second ctx), one changed input sample
+    changes them, and the sums equal the host's own position-weighted sums of the fetched results."""
+    n_ch, nf = 300, 8
+
+    def host_sum(a):                                  # sum_i (word_i + 0x9E3779B9 mod 2^32) * (2 i + 1)  mod 2^64
+        w = (np.ascontiguousarray(a).view(np.uint32).reshape(-1).astype(np.uint64) + np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
+        k = np.uint64(2) * np.arange(len(w), dtype=np.uint64) + np.uint64(1)
+        with np.errstate(over="ignore"):
+            return int((w * k).sum(dtype=np.uint64))    # uint64 arithmetic wraps mod 2^64
+
+    with S.SsdrEngine(n_ch) as eng:
+        eng.synth_iq(nf, seed=5, first_channel_id=1000)
+        iq = eng.read_input()
+        lines, fused = eng.run_chain()
+        a = eng.output_checksum()
+        wf, (pcm, rssi) = eng.fetch_wf(lines), eng.fetch_audio()
+        assert not fused
+    assert a == (host_sum(wf), host_sum(pcm), host_sum(rssi))
+    with S.SsdrEngine(n_ch) as eng:                 # pushed instead of generated, fused kernel instead of two
+        eng.set_fused(True)
+        eng.push_iq(iq)
+        lines, fused = eng.run_chain()
+        assert fused and eng.output_checksum() == a
+    iq2 = iq.copy()
+    iq2[123, 2000, 1] ^= 1
+    with S.SsdrEngine(n_ch) as eng:
+        eng.push_iq(iq2)
+        eng.run_wf(fetch=False), eng.run_audio(fetch=False)
+        b = eng.output_checksum()
+    assert b != a and (b[0] != a[0] or b[1] != a[1])
+
+
+def test_reset_state_and_rate_change_clear_the_hop512_tail(S, twin):
+    """at hop 512 the half-line carried from the previous batch is stream state.  ssdr_reset_state (and
+    ssdr_set_decimation, which resets the streams) must return it to silence: the first line after a reset is then the
+    line of a fresh ctx, not one built on a stale half-line of the old stream."""
+    n_ch = 5
+    iq = O.synth_iq(n_ch, 6 * 512, seed=31)
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_hop(512)
+        eng.push_iq(iq[:, :2048])
+        eng.run_wf()
+        eng.reset_state()
+        eng.push_iq(iq[:, 2048:])
+        got = eng.run_wf()
+        eng.push_iq(iq[:, :1024])
+        eng.run_wf()
+        eng.reset_state(1, 2)                        # a channel range: only those tails are cleared
+        eng.push_iq(iq[:, 2048:])
+        part = eng.run_wf()
+        eng.set_decimation(2)
+        eng.push_iq(iq[:, :2048])                    # 2 frames at D = 2
+        dec = eng.run_wf()
+        consts, _ = eng.get_consts()
+    cal = consts["wf_cal_lin"]
+    fresh = twin.wf_hop(np.concatenate([np.zeros((n_ch, 512, 2), np.int16), iq[:, 2048:]], axis=1), 512, 1, cal)
+    assert np.array_equal(got, fresh)
+    carried = twin.wf_hop(np.concatenate([iq[:, 512:1024], iq[:, 2048:]], axis=1), 512, 1, cal)
+    for c in range(n_ch):
+        assert np.array_equal(part[:, c], (fresh if c in (1, 2) else carried)[:, c]), c
+    assert np.array_equal(dec, twin.wf_hop(np.concatenate([np.zeros((n_ch, 512, 2), np.int16), iq[:, :2048]], axis=1), 512, 1, cal))
+
+
+def test_pipelined_feed_carries_flags_and_n_per_slot(S):
+    """what belongs to a batch travels with its slot -- the ADC-overflow flags of ITS frames (not of the batch
+    submitted after it) and the averaging N that was in force when it was submitted."""
+    n_ch, nf = 4, 2
+    iq = O.synth_iq(n_ch, 4 * nf * 512, seed=19)
+    iq[2, 1 * nf * 512 + 600, 0] = -32768            # batch 1, frame 1, channel 2
+    iq[0, 3 * nf * 512 + 5, 1] = 32767               # batch 3, frame 0, channel 0
+    with S.SsdrEngine(n_ch) as eng:
+        eng.feed_open(nf, depth=3)
+        ns = [1, 1, 2, 2]
+        got = []
+        for b in range(4):
+            eng.set_averaging(ns[b])
+            eng.feed_slot()[:] = iq[:, b * nf * 512:(b + 1) * nf * 512]
+            eng.feed_submit()
+            if b >= 2:
+                wf, pcm, rssi = eng.feed_collect()
+                got.append((len(wf), eng.feed_n_avg, eng.feed_flags.copy()))
+        while len(got) < 4:
+            wf, pcm, rssi = eng.feed_collect()
+            got.append((len(wf), eng.feed_n_avg, eng.feed_flags.copy()))
+        eng.feed_close()
+    assert [g[1] for g in got] == ns and [g[0] for g in got] == [1, 1, 0, 1]
+    want = np.zeros((4, n_ch, nf), np.uint8)
+    want[1, 2, 1] = 1
+    want[3, 0, 0] = 1
+    for b in range(4):
+        assert np.array_equal(got[b][2], want[b]), b

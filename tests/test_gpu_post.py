@@ -413,3 +413,113 @@ def test_replay_tool_end_to_end(S, tmp_path):
     R.write_wav(str(out), audio)
     raw = out.read_bytes()
     assert raw[:4] == b"RIFF" and len(raw) == 44 + audio.size * 2 and pcm_t.std() > 100
+
+
+# ------------------------------------------------------------------ round 3
+class _Disp:
+    DISPLAY_WIDTH, WF_HEIGHT = 1024, 8
+
+
+class _Eibi:
+    def get_stations(self, a, b):
+        pass
+
+
+def _drive(hub, gpu, iq, averaging=(1, 1), record=False):
+    """two receivers on `hub`, everything the hub produces for them consumed through the seams"""
+    wf = [gpu.kiwi_waterfall("gpu", 0, "", 6, 7100.0, _Eibi(), _Disp(), hub=hub, channel=c, timeout=1.0) for c in range(2)]
+    snd = [gpu.kiwi_sound(7100.0 - 2.5 + 3.7 * c, ["USB", "AM"][c], [30, -6000][c], [3000, 6000][c], "", wf[c], 8) for c in range(2)]
+    wf[1].wf_auto_scaling = False
+    wf[1].delta_low_db, wf[1].delta_high_db = -10, 20
+    snd[0].volume, snd[0].audio_balance = 150, 0.5
+    for c in range(2):
+        wf[c].averaging_n = averaging[c]
+        hub.set_averaging(averaging[c], c)
+    if record:
+        snd[1].audio_rec.recording_flag = True
+    n_sf = iq.shape[1] // 1024
+    for k in range(n_sf):
+        if k == n_sf // 2:                           # display state changes mid-stream: latched per superframe
+            wf[0].zoom, snd[1].volume = 9, 60
+        for c in range(2):
+            hub.feed(c, iq[c, k * 1024:(k + 1) * 1024])
+    if hub.pipeline:
+        hub.flush()
+    out = {"color": [[], []], "scal": [[], []], "play": [[], []], "rec": [[], []], "pcm": [[], []], "flags": [[], []]}
+    for c in range(2):
+        while hub.wf_queue[c].qsize():
+            wf[c].step()
+            out["color"][c].append(np.array(wf[c].wf_color))
+            out["scal"][c].append((wf[c].low_clip_db, wf[c].high_clip_db, wf[c].dynamic_range, wf[c].wf_min_db, wf[c].wf_max_db))
+        while hub.snd_queue[c].qsize():
+            f = snd[c].process_audio_stream()
+            out["pcm"][c].append(np.array(f)), out["flags"][c].append(snd[c].adc_overflow_flag)
+            snd[c].audio_buffer.put(f)
+            o = np.zeros((2048, 2), np.int16)
+            snd[c].play_buffer(o, 2048, None, None)
+            out["play"][c].append(o)
+        out["rec"][c] = [np.array(b) for b in snd[c].audio_rec.audio_buffer]
+    return out
+
+
+def test_pipelined_hub_with_post_equals_the_synchronous_hub(S):
+    """IQHub(pipeline=True, gpu_post=True): db2col and play_buffer run inside the ssdr_feed_* slot
+    pipeline with the display state latched at submit -- one submit and one collect per superframe instead of six blocking
+    calls -- and everything the two workers see (wf_color and its scalars with auto and manual limits, a zoom change
+    mid-stream, PCM, flags, the 48 kHz blocks with volume / pan changes, the recording branch) is bit-identical to the
+    synchronous hub's."""
+    from supersdr_amd.workers import IQHub, bind_headless
+    gpu = bind_headless()
+    iq = O.synth_iq(2, 9 * 1024, seed=61, modes=[1, 0])
+    iq[1, 5 * 1024 + 17, 0] = 32767
+    res = {}
+    for pipe in (False, True):
+        hub = IQHub(2, pipeline=pipe, depth=3, trace_rows=8)
+        res[pipe] = _drive(hub, gpu, iq, averaging=(1, 1), record=True)
+        res[pipe]["trace"] = hub.spectrum_trace(5, 100)
+        hub.close()
+    a, b = res[False], res[True]
+    for key in ("color", "play", "rec", "pcm"):
+        for c in range(2):
+            assert len(a[key][c]) == len(b[key][c]) and len(a[key][c]) > 0 or key == "rec", (key, c)
+            for x, y in zip(a[key][c], b[key][c]):
+                assert np.array_equal(x, y), (key, c)
+    assert a["scal"] == b["scal"] and a["flags"] == b["flags"] and sum(a["flags"][1]) == 1
+    assert len(a["rec"][1]) == 18 and len(a["rec"][0]) == 0
+    assert np.array_equal(a["trace"][0], b["trace"][0]) and np.array_equal(a["trace"][1], b["trace"][1])
+    # time binning on the GPU, both clients N = 3, pipelined
+    res3 = {}
+    for pipe in (False, True):
+        hub = IQHub(2, pipeline=pipe, depth=2)
+        res3[pipe] = _drive(hub, gpu, iq, averaging=(3, 3))
+        hub.close()
+    for c in range(2):
+        assert len(res3[True]["color"][c]) == 3
+        for x, y in zip(res3[False]["color"][c], res3[True]["color"][c]):
+            assert np.array_equal(x, y)
+
+
+def test_db2col_line_touches_nothing_but_its_own_line(S):
+    """a client that binned N lines itself (the hub's clients disagree on N) gets its spectrum_db2col from
+    ssdr_db2col_line: the device copy of wf_data (spectrum_trace) of ALL channels, and the lines of the last batch, are what
+    they were; the result equals ssdr_run_db2col's for the same line and display state."""
+    from supersdr_amd._lib import Db2colChan
+    n_ch = 3
+    iq = O.synth_iq(n_ch, 6 * 1024, seed=8)
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_wfdata_rows(8)
+        chans = [Db2colChan(zoom=4 + c, auto_scale=1, low_clip_db=-120.0, high_clip_db=-60.0, dynamic_range=40.0) for c in range(n_ch)]
+        for k in range(6):
+            eng.push_iq(iq[:, k * 1024:(k + 1) * 1024])
+            wf = eng.run_wf()
+            col = eng.run_db2col(chans, len(wf))
+        trace0 = eng.run_trace(4, 100)
+        sums0 = eng.output_checksum()
+        line = (wf[0, 1].astype(np.int32) * 3).astype(np.int16)          # "a sum of 3 lines"
+        k = Db2colChan(zoom=7, auto_scale=1, low_clip_db=-120.0, high_clip_db=-60.0, dynamic_range=40.0)
+        c1 = eng.db2col_line(line, 3, k)
+        trace1 = eng.run_trace(4, 100)
+        assert np.array_equal(trace0[0], trace1[0]) and np.array_equal(trace0[1], trace1[1])
+        assert eng.output_checksum() == sums0 and np.array_equal(eng.fetch_wf(1), wf)
+        ref = O.spectrum_db2col(line.astype(np.float32) / np.float32(3), 7, True)
+        assert np.array_equal(c1, ref[0]) and k.wf_min_db == np.float32(ref[4]) and k.wf_max_db == np.float32(ref[5])

@@ -266,21 +266,8 @@ def test_twin_tracks_float64_oracle_over_random_parameters(seed, n_frames):
     st, hist = twinlib.fresh_state(consts)
     pcm_t, rssi_t = twin.audio(iq, consts, taps, st, hist)
     pcm_o, rssi_o = O.audio_chain(iq, params)
-    rms = np.sqrt(((pcm_t.astype(np.float64) - pcm_o) ** 2).mean(axis=1)) / 32768.0
-    # fp32 conditioning: the chain's roundings sit ~140 dB under the INPUT level, so what is left of a signal that the
-    # channel filter takes 40+ dB down (out-of-band carrier, narrow passband) is only known to ~1e-4 relative; the FM
-    # discriminator turns that straight into phase.  The north_star tolerance is asserted where the filtered power
-    # stays within 40 dB of the input power, a 100x looser bound elsewhere.
-    in_db = 10 * np.log10(np.maximum((iq.astype(np.float64) ** 2).sum(axis=2).mean(axis=1), 1e-20) / 32768.0 ** 2)
-    in_db = in_db + np.array([k["smeter_cal_db"] for k in kw])
-    well = (rssi_o > in_db[:, None] - 40).all(axis=1)
-    assert well.sum() >= n_ch // 2
-    # ... and where |y| itself does not dip: the instants where a filtered transient crosses zero are as ill-conditioned for
-    # the discriminator; the 0.5 % largest deviations of a channel are left to the loose bound as well
-    dev = np.sort(np.abs(pcm_t.astype(np.float64) - pcm_o), axis=1)[:, : int(pcm_o.shape[1] * 0.995)]
-    rms_trim = np.sqrt((dev ** 2).mean(axis=1)) / 32768.0
-    assert rms_trim[well].max() < 1e-5, (int(np.argmax(rms_trim * well)), rms_trim.max())
-    assert rms.max() < 1e-3
+    import tolerances as T                                   # the conditioning rule of the 1e-5 figure, stated once
+    well, _ = T.assert_pcm_within_tolerance(pcm_t, pcm_o, iq, rssi_o, [k["smeter_cal_db"] for k in kw], min_well=n_ch // 2)
     assert np.abs(rssi_t - rssi_o)[well].max() < 1e-3
     assert np.abs(rssi_t - rssi_o)[rssi_o > -150].max() < 2e-2
     assert len({k["mode"] for k in kw}) >= 4
