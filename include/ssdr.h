@@ -131,6 +131,13 @@ int ssdr_compile_params_decim(const ssdr_chan_params *p, uint32_t decim, ssdr_ch
  * previous batch (silence after ssdr_create / ssdr_set_hop).  A change restarts the averaging group. */
 int ssdr_set_hop(ssdr_ctx *ctx, uint32_t hop);
 
+/* Exact bins.  The waterfall kernel computes in float32; ~3e-4 of its bins, those whose |X| lies within the fp32 FFT's rounding
+ * error of a 1-dB threshold, land one step away from where the float64 definition (oracle/ssdr_oracle.py: NumPy float64
+ * FFT) puts them.  on = 1: ssdr_run_wf evaluates the stage in float64 instead (same window table, same thresholds) and
+ * its int16 sums equal the float64 definition's bit for bit.  Roughly 25x slower than the default kernel; off by default;
+ * not available to the fused kernel of ssdr_run_chain (which then runs the two stages). */
+int ssdr_set_exact_bins(ssdr_ctx *ctx, int on);
+
 /* -- data plane.  ssdr_push_iq is the IQ ingest hook: KiwiSDRStream._process_iq_samples
  *    (kiwi/client.py:493-494).  iq may be a host pointer (copied) or a device pointer
  *    (referenced, must stay valid until the run_* calls on it have completed). */

@@ -74,6 +74,7 @@ _SIGS = {
     "ssdr_reset_state": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
     "ssdr_set_averaging": (C.c_int, [_P, C.c_uint32]),
     "ssdr_set_hop": (C.c_int, [_P, C.c_uint32]),
+    "ssdr_set_exact_bins": (C.c_int, [_P, C.c_int]),
     "ssdr_set_decimation": (C.c_int, [_P, C.c_uint32]),
     "ssdr_compile_params_decim": (C.c_int, [C.POINTER(ChanParams), C.c_uint32, C.POINTER(ChanConsts), _P]),
     "ssdr_push_iq": (C.c_int, [_P, _P, C.c_uint32, C.c_int]),

@@ -3,6 +3,7 @@
 // Never throws, never aborts: every failure is a negative return code.
 #include "ssdr_kernels.h"
 #include "ssdr_resample_taps.h"
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,6 +35,8 @@ struct ssdr_ctx {
     bool concurrent = false, audio_pending = false;
     // tables
     float *d_win = nullptr, *d_thr = nullptr;
+    bool exact_bins = false;                            // ssdr_set_exact_bins: the waterfall stage in float64
+    double2 *d_tw64 = nullptr;                          // [512] e^{-2 pi j m / 1024} in double
     float2 *d_tw = nullptr;
     uint2 *d_lut = nullptr;
     // per-channel
@@ -217,7 +220,7 @@ void ssdr_destroy(ssdr_ctx *c)
     void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_wf_tail, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_flags, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
                     c->d_play_taps, c->d_play_hist, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
-                    c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1};
+                    c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -471,6 +474,23 @@ int ssdr_set_hop(ssdr_ctx *c, uint32_t hop)
     return SSDR_OK;
 }
 
+int ssdr_set_exact_bins(ssdr_ctx *c, int on)
+{
+    if (!c) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    if (on && !c->d_tw64) {
+        std::vector<double2> tw(512);
+        const double kPi = 3.14159265358979323846;
+        for (int m = 0; m < 512; m++) tw[m] = make_double2(std::cos(2.0 * kPi * m / SSDR_NFFT), -std::sin(2.0 * kPi * m / SSDR_NFFT));
+        tw[0] = make_double2(1.0, 0.0);
+        tw[256] = make_double2(0.0, -1.0);
+        HIP_TRY(hipMalloc(&c->d_tw64, 512 * sizeof(double2)));
+        HIP_TRY(hipMemcpy(c->d_tw64, tw.data(), 512 * sizeof(double2), hipMemcpyHostToDevice));
+    }
+    c->exact_bins = on != 0;
+    return SSDR_OK;
+}
+
 int ssdr_get_config(ssdr_ctx *c, uint32_t *hop, uint32_t *decim, uint32_t *averaging, uint32_t *kiwi_rate)
 {
     if (!c) return SSDR_EINVAL;
@@ -659,7 +679,8 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
         c->fused_wf = a;
     } else {
         if ((rc = timed_begin(c)) != SSDR_OK) return rc;
-        HIP_TRY(ssdr_launch_wf(a, grid ? grid : 1, c->stream));
+        if (c->exact_bins) { if (n_groups) HIP_TRY(ssdr_launch_wf_exact(a, c->d_tw64, c->d_thr, c->stream)); }
+        else HIP_TRY(ssdr_launch_wf(a, grid ? grid : 1, c->stream));
         if ((rc = timed_end(c, SSDR_K_WF)) != SSDR_OK) return rc;
     }
     if (hop512)                  // the batch's last half-line is the next batch's first: [n_ch] rows of 2 KB out of the input
@@ -798,7 +819,7 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
     for (uint32_t ch = 0; ch < c->n_ch; ch++) n_am += ssdr_audio_path(c->h_consts[ch]) == SSDR_PATH_AM_RAW;
     // the fused kernel covers the metric's configuration: every channel on the full-band AM path, N = 1, hop 1024, 12 kHz IQ
     const bool eligible = n_am == c->n_ch && c->n_avg == 1 && c->hop == SSDR_NFFT && c->decim == 1 && !(c->in_frames & 1u) &&
-                          !c->concurrent && c->fused_grid != 0 && c->fused_enabled;
+                          !c->concurrent && c->fused_grid != 0 && c->fused_enabled && !c->exact_bins;
     if (fused) *fused = eligible ? 1 : 0;
     c->fuse_next = eligible;
     int rc = ssdr_run_wf(c, nullptr, lines_ready, 0);

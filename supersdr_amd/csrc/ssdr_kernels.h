@@ -129,6 +129,7 @@ struct SsdrFusedArgs { SsdrWfArgs wf; SsdrAudioArgs au; };
 hipError_t ssdr_launch_fused_am(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream);
 hipError_t ssdr_fused_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream);
+hipError_t ssdr_launch_wf_exact(const SsdrWfArgs &a, const double2 *tw, const float *thr, hipStream_t stream);   // ssdr_wf_exact.hip
 hipError_t ssdr_wf_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, int path, hipStream_t stream);
 hipError_t ssdr_launch_audio_dec(const SsdrAudioArgs &a, uint32_t decim, hipStream_t stream);

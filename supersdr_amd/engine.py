@@ -100,6 +100,10 @@ class SsdrEngine:
         check(lib.ssdr_set_hop(self._ctx, int(hop)), "ssdr_set_hop")
         self.hop = int(hop)
 
+    def set_exact_bins(self, on):
+        """waterfall stage in float64: the int16 sums then equal the float64 definition (NumPy oracle) bit for bit; ~25x slower"""
+        check(lib.ssdr_set_exact_bins(self._ctx, int(bool(on))), "ssdr_set_exact_bins")
+
     # ---- data plane
     def push_iq(self, iq):
         """iq: int16 [n_ch, n_frames*512, 2] host array (copied to the GPU)."""

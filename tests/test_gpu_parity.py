@@ -1072,3 +1072,43 @@ def test_pipelined_feed_carries_flags_and_n_per_slot(S):
     want[3, 0, 0] = 1
     for b in range(4):
         assert np.array_equal(got[b][2], want[b]), b
+
+
+@pytest.mark.parametrize("n_ch,n_avg,hop", [(64, 1, 1024), (33, 10, 1024), (7, 3, 512), (1, 1, 1024)])
+def test_exact_bins_equal_the_float64_oracle_bit_for_bit(S, n_ch, n_avg, hop):
+    """ssdr_set_exact_bins (north_star: "bit-exact for the int16 waterfall bins"): with the waterfall stage
+    evaluated in float64 there is NO guard band -- every int16 sum equals oracle/ssdr_oracle.py's (NumPy float64 FFT) on
+    BASELINE configs[1]- and configs[3]-shaped batches (N = 1 and N = 10 time binning, mixed calibrations, groups
+    straddling ragged calls, hop 512), while the default fp32 kernel differs from the same oracle in ~3e-4 of the bins."""
+    calls = [4, 6, 2, 18] if hop == 1024 else [1, 2, 7, 3, 10]
+    n_frames = sum(calls)
+    iq = O.synth_iq(n_ch, n_frames * 512, seed=900 + n_ch, modes=[c % 4 for c in range(n_ch)])
+    iq[0, :1024] = 0                                                       # a silent line: p = 0 -> byte 0
+    cal = np.linspace(-9, 9, n_ch) if n_ch > 1 else np.array([0.0])
+    out = {}
+    for exact in (True, False):
+        with S.SsdrEngine(n_ch) as eng:
+            eng.set_params(0, [S.default_params("am", wf_cal_db=float(cal[c])) for c in range(n_ch)])
+            eng.set_hop(hop)
+            eng.set_averaging(n_avg)
+            eng.set_exact_bins(exact)
+            got, pos = [], 0
+            for nf in calls:
+                eng.push_iq(iq[:, pos * 512:(pos + nf) * 512])
+                got.append(eng.run_wf())
+                pos += nf
+        out[exact] = np.concatenate(got, axis=0)
+    n_diff = 0
+    for c in range(n_ch):
+        if hop == 1024:
+            ref = O.wf_sum_lines(iq[c].reshape(-1, 1024, 2), n_avg, cal[c])
+        else:
+            stream = np.concatenate([np.zeros((512, 2), np.int16), iq[c]])                   # silence in front
+            b = O.wf_lines_hop(stream, 512, cal[c]).astype(np.int16)
+            L = len(b) // n_avg
+            ref = b[: L * n_avg].reshape(L, n_avg, 1024).sum(axis=1).astype(np.int16)
+        assert out[True].shape[0] == len(ref)
+        assert np.array_equal(out[True][:, c], ref), (c, int((out[True][:, c] != ref).sum()))
+        n_diff += int((out[False][:, c] != ref).sum())
+    if n_ch >= 33:
+        assert 0 < n_diff < 3e-3 * out[False].size * n_avg                # what the mode exists for
