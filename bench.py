@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- SuperSDR hot path on MI355X: real-time IQ channels sustained (WF + demod).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full|wf|mixed|million]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full|wf|mixed|million|decim4]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -20,8 +20,11 @@ Workloads (BASELINE.json configs):
   wf              configs[1]: 4096 ch/GPU, waterfall only, 256 lines per launch
   mixed           configs[3]: 65536 ch/GPU, AM/USB/LSB/NBFM by c mod 4, 10x time binning
   million         configs[4]: 2^20 channels in total, 2^20/N per GPU (strong scaling)
-The default run also times `wf` and `mixed` briefly after the main measurement and reports
-them, each with its own rooflines, under "extra" in the same JSON line.
+  decim4          the decimating front end: 16384 ch/GPU, IQ at 48 kHz, 125-tap channel filters
+The default run also times `wf`, `mixed`, `million`, `decim4` and the variants DESIGN.md discusses briefly after the
+main measurement and reports them, each with its own rooflines, under "extra" in the same JSON line.
+Every run ends with the parity hash of SURVEY.md 8e: each rank's checksums of a probe of its channel block, cross-checked
+by its neighbour rank ("parity" in the JSON; a mismatch is an error).
 """
 import argparse
 import json
@@ -46,12 +49,31 @@ WORKLOADS = {
     "mixed": (65536,     10,          10,    ("am", "usb", "lsb", "nbfm"), True, True),
     # configs[4]: 2^20 channels in total, 2^20 / N per GPU (strong scaling; 16 GiB of input on one GPU at N = 1)
     "million": (1 << 20, 4,           1,     ("am",),               True, True),
+    # the decimating front end (ssdr_set_decimation(4)): IQ at 48 kHz, 125-tap channel filters, waterfall lines from the wide stream
+    "decim4": (16384,    8,           1,     ("usb", "lsb"),        True, True),
 }
+WORKLOAD_DECIM = {"decim4": 4}
 WORKLOAD_TEXT = {"full": "65536 channels full chain (WF + AM demod + AGC), BASELINE configs[2]",
                  "wf": "4096 channels batched 1024-pt FFT + log-mag waterfall only, BASELINE configs[1]",
                  "mixed": "65536 channels mixed AM/USB/LSB/NBFM + 10x time binning, BASELINE configs[3]",
-                 "million": "2^20 channels full chain in total, channel-sharded, BASELINE configs[4]"}
+                 "million": "2^20 channels full chain in total, channel-sharded, BASELINE configs[4]",
+                 "decim4": "16384 channels, IQ at 48 kHz (ssdr_set_decimation(4)): USB / LSB behind 125-tap decimating channel filters + waterfall"}
 PATH_NAMES = ("FIR", "shift", "AM-shift")        # ssdr_audio_kernel<0|1|2>
+PATH_TEXT = ("general: NCO -> FIR -> demodulator", "full-band lane shift: NCO, no FIR", "full-band AM: no NCO, no FIR (|x e^{j phi}| = |x|)")
+F32_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: vector f32 peak (an FMA = 2 flop)
+RIDGE_FLOP_PER_BYTE = F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)          # 19.7
+# Executed vector work per unit: VALU wave-instructions from PMC SQ_INSTS_VALU / wave-units (profiles/r02_*_pmc_summary.txt,
+# profiles/README.md "VALU floor"), FMA share from the static opcode mix of the loops (profiles/r02_isa_histograms.txt;
+# for <0> the 512 filter FMAs of the 33-tap case are dynamic).  flops = 64 lanes x (instructions + FMA instructions).
+KERNEL_VALU = {
+    "ssdr_wf_kernel<false, false>": ("line", 1266 / 2, 0.55),
+    "ssdr_wf_kernel<true, false>": ("line", 1266 / 2, 0.55),
+    "ssdr_wf_kernel<false, true>": ("line", 1266 / 2, 0.55),
+    "ssdr_wf_kernel<true, true>": ("line", 1266 / 2, 0.55),
+    "ssdr_audio_kernel<0>": ("frame", 829, 0.75),
+    "ssdr_audio_kernel<1>": ("frame", 572, 0.42),
+    "ssdr_audio_kernel<2>": ("frame", 286, 0.17),
+}
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -164,6 +186,9 @@ def spawn_ranks(gpus, argv):
     for r in range(gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        if "SSDR_BENCH_DEVICE" not in os.environ:      # one host process per GPU, confined to it; the rank then
+            env["HIP_VISIBLE_DEVICES"] = str(r)         # sees exactly one device, index 0
+            env["SSDR_BENCH_DEVICE"] = "0"
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rcs = [p.wait() for p in procs]
@@ -174,15 +199,16 @@ def spawn_ranks(gpus, argv):
 # ---------------------------------------------------------------------------------------------------------------
 # one measurement
 # ---------------------------------------------------------------------------------------------------------------
-def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sframes, steps, warmup, spinup,
-            concurrent=0, host_feed=0, hop=1024, fused=0):
-    """Spin the clocks up, W warm-up steps, then exactly `steps` timed steps between barrier + synchronize pairs.
-    -> dict(value, ms_per_step, stages)."""
-    _, _, n_avg, modes, do_wf, do_audio = WORKLOADS[workload]
-    n_frames = 2 * sframes
-    eng = S.SsdrEngine(channels, device=local_rank)
-    params = [S.default_params(modes[c % len(modes)], f_shift_hz=(((rank * channels + c) * 37) % 97 - 48) * 100.0)
-              for c in range(min(channels, 388))]          # the parameter pattern repeats every 4*97 channels
+def configure(S, eng, workload, channels, first_channel_id, hop=1024, fused=0, concurrent=0, exact=0):
+    """channel parameters of `workload` for the block of channels that starts at global id `first_channel_id`
+    (mode by channel id mod len(modes), tuning by the generator's carrier formula)"""
+    _, _, n_avg, modes, _, _ = WORKLOADS[workload]
+    decim = WORKLOAD_DECIM.get(workload, 1)
+    if decim != 1:
+        eng.set_decimation(decim)
+    period = 97 * len(modes)                               # the parameter pattern repeats every len(modes) * 97 channels
+    params = [S.default_params(modes[(first_channel_id + c) % len(modes)], f_shift_hz=(((first_channel_id + c) * 37) % 97 - 48) * 100.0)
+              for c in range(min(channels, period))]
     for first in range(0, channels, len(params)):
         eng.set_params(first, params[: min(len(params), channels - first)])
     eng.reset_state()
@@ -190,7 +216,38 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     eng.set_fused(fused)
     eng.set_averaging(n_avg)
     eng.set_concurrent(concurrent)
-    eng.synth_iq(n_frames, seed=0x5D5D, first_channel_id=rank * channels)    # resident in HBM from here on
+    eng.set_exact_bins(exact)
+    return n_avg, decim
+
+
+def parity_probe(S, local_rank, workload, first_channel_id, channels=256, sframes=4, steps=2):
+    """SURVEY.md 8e "parity hash": a fresh ctx runs `steps` steps of `workload` on the `channels` channels that start at
+    global id `first_channel_id` and returns the checksums of what it produced (ssdr_output_checksum: waterfall sums,
+    PCM, RSSI).  Integer arithmetic over the result bytes: the same channel block gives the same three numbers on any
+    rank, any GPU, any launch shape -- or the ranks do not compute the same thing."""
+    _, _, _, _, do_wf, do_audio = WORKLOADS[workload]
+    with S.SsdrEngine(channels, device=local_rank) as eng:
+        configure(S, eng, workload, channels, first_channel_id)
+        eng.synth_iq(2 * sframes, seed=0x5D5D, first_channel_id=first_channel_id)
+        for _ in range(steps):
+            if do_wf:
+                eng.run_wf(fetch=False)
+            if do_audio:
+                eng.run_audio(fetch=False)
+        return eng.output_checksum()
+
+
+def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sframes, steps, warmup, spinup,
+            concurrent=0, host_feed=0, hop=1024, fused=0, exact=0, first_channel_id=None):
+    """Spin the clocks up, W warm-up steps, then exactly `steps` timed steps between barrier + synchronize pairs.
+    -> dict(value, ms_per_step, stages, ...)."""
+    _, _, _, modes, do_wf, do_audio = WORKLOADS[workload]
+    n_frames = 2 * sframes
+    if first_channel_id is None:
+        first_channel_id = rank * channels
+    eng = S.SsdrEngine(channels, device=local_rank)
+    n_avg, decim = configure(S, eng, workload, channels, first_channel_id, hop, fused, concurrent, exact)
+    eng.synth_iq(n_frames, seed=0x5D5D, first_channel_id=first_channel_id)    # resident in HBM from here on
     eng.sync()
 
     def step():
@@ -249,6 +306,7 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
         inflight[0] -= 1
     eng.sync()
     torch.cuda.synchronize()
+    own_wall = time.perf_counter() - t0                        # this rank's own time (reported per rank, never the value)
     rdv.barrier()
     wall = rdv.max_over_ranks(time.perf_counter() - t0)
 
@@ -264,24 +322,30 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     if wf_n:
         avg = wf_ms / wf_n
         # per line: hop 1024 reads 4096 B, hop 512 reads 2048 new bytes (the other half-line was the previous line's); 2048/N out
-        lines = channels * sframes * (2 if hop == 512 else 1)
+        lines = channels * sframes * decim * (2 if hop == 512 else 1)      # at D > 1 the lines come from the wide stream
         b = lines * ((2048.0 if hop == 512 else 4096.0) + 2048.0 / n_avg)
-        stages["wf"] = {"kernel": "ssdr_wf_kernel<%s, %s>" % ("true" if n_avg > 1 else "false", "true" if hop == 512 else "false"),
-                        "avg_ms": avg, "launches": wf_n, "bytes": b, "GBps": b / avg / 1e6, "lines_per_launch": lines}
+        stages["wf"] = {"kernel": "ssdr_wf_exact_kernel (float64)" if exact else
+                                  "ssdr_wf_kernel<%s, %s>" % ("true" if n_avg > 1 else "false", "true" if hop == 512 else "false"),
+                        "avg_ms": avg, "launches": wf_n, "bytes": b, "GBps": b / avg / 1e6, "lines_per_launch": lines, "units": lines}
     if au_n:
         avg = au_ms / au_n
-        b = channels * n_frames * 3072.0
+        b = channels * n_frames * (2048.0 * decim + 1024.0)
         live = [p for p in range(3) if paths[p]]
-        name = ("ssdr_audio_kernel<%d>" % live[0]) if len(live) == 1 else \
-               "audio stage: " + " + ".join("ssdr_audio_kernel<%d> (%s, %d ch)" % (p, PATH_NAMES[p], paths[p]) for p in live) + \
-               (" one after the other" if concurrent & 2 else " side by side")
-        stages["audio"] = {"kernel": name, "avg_ms": avg, "launches": au_n, "bytes": b, "GBps": b / avg / 1e6}
+        if decim > 1:
+            name = "ssdr_audio_dec_kernel<%d>" % decim
+        else:
+            name = ("ssdr_audio_kernel<%d>" % live[0]) if len(live) == 1 else \
+                   "audio stage: " + " + ".join("ssdr_audio_kernel<%d> (%s, %d ch)" % (p, PATH_NAMES[p], paths[p]) for p in live) + \
+                   (" one after the other" if concurrent & 2 else " side by side")
+        stages["audio"] = {"kernel": name, "avg_ms": avg, "launches": au_n, "bytes": b, "GBps": b / avg / 1e6,
+                           "units_by_kernel": {"ssdr_audio_kernel<%d>" % p: paths[p] * n_frames for p in live} if decim == 1 else {}}
     if fu_n:
         avg = fu_ms / fu_n
         b = channels * sframes * 8192.0                 # SURVEY.md 8d, fused budget at N = 1: 4096 in + 2048 + 2048 out
         stages["fused"] = {"kernel": "ssdr_fused_am_kernel", "avg_ms": avg, "launches": fu_n, "bytes": b, "GBps": b / avg / 1e6}
     return {"value": units / wall / RT_SUPERFRAMES_PER_S, "ms_per_step": wall / steps * 1e3, "stages": stages,
-            "n_avg": n_avg}
+            "n_avg": n_avg, "paths": paths, "decim": decim,
+            "own_value": channels * sframes * steps / own_wall / RT_SUPERFRAMES_PER_S}
 
 
 def pmc_traffic(workload, channels, sframes, hop=1024):
@@ -308,13 +372,49 @@ def stage_traffic(traffic, stage):
     return sum(vals) if vals and all(v is not None for v in vals) else None
 
 
+def executed_flops(stage):
+    """vector flops one launch executes (KERNEL_VALU), or None for a kernel that has no PMC record"""
+    per = stage.get("units_by_kernel") or ({stage["kernel"]: stage["units"]} if "units" in stage else {})
+    total = 0.0
+    for name, units in per.items():
+        if name not in KERNEL_VALU:
+            return None
+        _, instr, fma = KERNEL_VALU[name]
+        total += units * instr * 64.0 * (1.0 + fma)
+    return total or None
+
+
 def roofline(stage, traffic=None, src=None):
+    """The roof is chosen by the kernel's executed arithmetic intensity against the machine balance (157.3 Tflop/s over
+    8 TB/s = 19.7 flop/B): below it the HBM roof applies, above it the vector-f32 roof.  `frac` is against that roof;
+    `frac_hbm` (algorithmic bytes / time / 8 TB/s) is always given -- it is the figure north_star's target is stated in."""
+    hbm = stage["GBps"] / HBM_PEAK_GBPS
     r = {"kernel": stage["kernel"], "bound": "hbm", "achieved": stage["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-         "frac": stage["GBps"] / HBM_PEAK_GBPS, "traffic": traffic, "avg_kernel_ms": stage["avg_ms"],
+         "frac": hbm, "frac_hbm": hbm, "traffic": traffic, "avg_kernel_ms": stage["avg_ms"],
          "algorithmic_bytes_per_launch": stage["bytes"]}
+    fl = executed_flops(stage)
+    if fl is not None:
+        tf = fl / stage["avg_ms"] / 1e9
+        r["valu"] = {"flops_per_launch": fl, "flop_per_algorithmic_byte": fl / stage["bytes"], "ridge_flop_per_byte": RIDGE_FLOP_PER_BYTE,
+                     "achieved_tflops": tf, "peak_tflops": F32_PEAK_TFLOPS, "frac_f32": tf / F32_PEAK_TFLOPS,
+                     "source": "PMC SQ_INSTS_VALU per wave-unit x 64 lanes, FMA share from the opcode mix (profiles/README.md)"}
+        if fl / stage["bytes"] > RIDGE_FLOP_PER_BYTE:       # right of the ridge: the vector ALU's roof is the lower one
+            r.update({"bound": "valu", "achieved": tf, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_PEAK_TFLOPS})
     if traffic is not None:
         r["traffic_source"] = "profiles/" + src
     return r
+
+
+def parity_report(rdv, world, firsts, own, cross, what):
+    """gather every rank's (own block, next rank's block) checksums; rank r's view of block r+1 must equal rank r+1's own"""
+    allv = rdv.gather_ints(list(own) + list(cross))
+    owns = [v[:3] for v in allv]
+    crosses = [v[3:] for v in allv]
+    bad = [r for r in range(world) if crosses[r] != owns[(r + 1) % world]]
+    return {"ranks_agree": not bad, "mismatching_ranks": bad, "probe": what,
+            "check": "rank r recomputes the probe of rank (r+1) mod N's channel block: must equal that rank's own checksums"
+                     + (" (N = 1: a second fresh ctx must reproduce the first)" if world == 1 else ""),
+            "first_channel_ids": firsts, "checksums": [["%016x" % x for x in o] for o in owns]}
 
 
 def main():
@@ -338,6 +438,7 @@ def main():
                     help="1: ssdr_run_chain with the fused superframe kernel where the configuration allows it (full-band AM, N = 1)")
     ap.add_argument("--hop", type=int, default=1024, choices=[512, 1024],
                     help="samples between waterfall lines: 512 = 23.4 lines/s, the reference's waterfall rate (utils_supersdr.py:597)")
+    ap.add_argument("--exact", type=int, default=0, help="1: ssdr_set_exact_bins -- the waterfall stage in float64 (bins equal the float64 oracle bit for bit)")
     ap.add_argument("--dry-run", action="store_true",
                     help="control flow only (ranks, rendezvous over gloo, channel blocks, JSON line), no GPU work: the CPU test of --gpus")
     args = ap.parse_args()
@@ -354,17 +455,27 @@ def main():
     channels = args.channels or channels
     sframes = args.superframes or sframes
 
+    first_id = channel_block(rank, world, WORKLOADS["million"][0])[0] if args.workload == "million" and not args.channels else rank * channels
     if args.dry_run:
+        # control flow of the N-rank run without a GPU: rendezvous, channel blocks, and the parity-hash gather with stand-in
+        # checksums (a pure function of the block's first channel id, as the real ones are of the block's results)
         rdv = Rendezvous("gloo", None)
         rdv.barrier()
         total = rdv.sum_over_ranks(channels)
         wall = rdv.max_over_ranks(1e-3 * (rank + 1))
+        fake = lambda fid: [(fid * 2654435761 + k * 40503 + 12345) & 0xFFFFFFFFFFFFFFFF for k in range(3)]      # noqa: E731
+        firsts = [int(v[0]) for v in rdv.gather_ints([first_id])]
+        nxt = firsts[(rank + 1) % world]
+        own, cross = fake(first_id), fake(nxt if os.environ.get("SSDR_DRYRUN_BREAK_RANK") != str(rank) else nxt + 1)
+        parity = parity_report(rdv, world, firsts, own, cross, "dry run: stand-in checksums")
         if rank == 0:
             print(json.dumps({"metric": "real-time IQ channels sustained (WF+demod)", "value": None, "unit": "rt_channels",
-                              "n_gpus": world, "dry_run": True, "channels_total": int(total), "max_wall": wall,
+                              "n_gpus": world, "dry_run": True, "channels_total": int(total), "max_wall": wall, "parity": parity,
                               "config": {"workload": WORKLOAD_TEXT[args.workload], "channels_per_gpu": channels,
-                                         "rendezvous": rdv.backend if world > 1 else "none"}}), flush=True)
+                                         "first_channel_ids": firsts, "rendezvous": rdv.backend if world > 1 else "none"}}), flush=True)
         rdv.close()
+        if not parity["ranks_agree"]:
+            raise SystemExit(3)
         return
 
     if not torch.cuda.is_available():
@@ -381,7 +492,15 @@ def main():
     from supersdr_amd import _lib as L
 
     m = measure(S, L, torch, rdv, rank, world, local_rank, args.workload, channels, sframes, args.steps, args.warmup,
-                args.spinup, args.concurrent, args.host_feed, args.hop, args.fused)
+                args.spinup, args.concurrent, args.host_feed, args.hop, args.fused, args.exact, first_id)
+    # SURVEY.md 8e parity hash (untimed): every rank hashes a probe of its own channel block and of the NEXT rank's block;
+    # rank r's view of block r+1 must equal rank r+1's own (at N = 1: a second fresh ctx must reproduce the first)
+    firsts = [int(v[0]) for v in rdv.gather_ints([first_id])]
+    own = parity_probe(S, local_rank, args.workload, first_id)
+    cross = parity_probe(S, local_rank, args.workload, firsts[(rank + 1) % world])
+    parity = parity_report(rdv, world, firsts, own, cross,
+                           "fresh ctx, 256 channels from the block's first id x 4 superframes x 2 steps, ssdr_output_checksum (wf, pcm, rssi)")
+    per_rank = [v[0] for v in rdv.gather_floats([m["own_value"]])]
     stages = m["stages"]
     dom = max(stages, key=lambda k: stages[k]["avg_ms"])
     traffic, src = pmc_traffic(args.workload, channels, sframes, args.hop)
@@ -393,9 +512,16 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": WORKLOAD_TEXT[args.workload],
                    "channels_per_gpu": channels, "superframes_per_step": sframes, "averaging_n": n_avg, "wf_hop": args.hop,
+                   "audio_paths": {PATH_TEXT[p]: m["paths"][p] for p in range(3) if m["paths"][p]} if do_audio else {},
+                   "input_decimation": m["decim"], "wf_exact_bins": bool(args.exact),
                    "clock_spinup_s": args.spinup,
                    "input": "pinned host memory, pipelined H2D / kernels / D2H (PCIe-inclusive)" if args.host_feed else "resident in HBM",
-                   "sharding": "channel blocks per GPU, no collectives", "rendezvous": rdv.backend if world > 1 else "none"},
+                   "sharding": "channel blocks per GPU, no collectives",
+                   "rendezvous": ("none" if world == 1 else rdv.backend if not rdv.fallback_reason else
+                                  "gloo (RCCL FAILED: %s)" % rdv.fallback_reason)},
+        "parity": parity,
+        "per_rank": {"value_min": min(per_rank), "value_max": max(per_rank), "values": per_rank,
+                     "note": "each rank's own channel-superframes / its own wall time; `value` uses the max wall over ranks"},
         "roofline": roofline(stages[dom], stage_traffic(traffic, stages[dom]), src),
     }
     for k, label in (("wf", "roofline_fft"), ("audio", "roofline_audio"), ("fused", "roofline_fused")):
@@ -418,6 +544,7 @@ def main():
             tr, tsrc = pmc_traffic(wl, ch, sf)
             extra[wl] = {"workload": WORKLOAD_TEXT[wl], "value": e["value"], "unit": "rt_channels", "ms_per_step": e["ms_per_step"],
                          "steps": max(20, args.steps // 2), "channels_per_gpu": ch, "superframes_per_step": sf, "averaging_n": e["n_avg"],
+                         "audio_paths": {PATH_TEXT[p]: e["paths"][p] for p in range(3) if e["paths"][p]} if WORKLOADS[wl][5] else {},
                          "rooflines": [roofline(s, stage_traffic(tr, s), tsrc) for s in e["stages"].values()]}
         # variants of the default workload that the design discusses, timed by the same run:
         # both stages side by side on two streams; the fused superframe kernel; the waterfall at the reference's line rate
@@ -436,6 +563,15 @@ def main():
         extra["wf_hop512"] = {"workload": WORKLOAD_TEXT["wf"] + ", hop 512 (23.4 lines/s)", "value": e["value"], "unit": "rt_channels",
                               "ms_per_step": e["ms_per_step"], "steps": nst, "lines_per_s": e["stages"]["wf"]["lines_per_launch"] / e["ms_per_step"] * 1e3,
                               "rooflines": [roofline(s, stage_traffic(tr, s), tsrc) for s in e["stages"].values()]}
+        # configs[4] at N = 1 (2^20 channels on this one GPU), the decimating front end, and the float64 exact-bins mode
+        for key, wl, kw, nsteps in (("million", "million", {}, 10), ("decim4", "decim4", {}, nst), ("wf_exact_bins", "wf", dict(exact=1), 3)):
+            ch, sf = WORKLOADS[wl][0], WORKLOADS[wl][1]
+            e = measure(S, L, torch, rdv, rank, world, local_rank, wl, ch, sf, nsteps, 1, 0.3, **kw)
+            extra[key] = {"workload": WORKLOAD_TEXT[wl] + (", float64 waterfall stage (--exact 1)" if kw else ""), "value": e["value"],
+                          "unit": "rt_channels", "ms_per_step": e["ms_per_step"], "steps": nsteps, "channels_per_gpu": ch,
+                          "superframes_per_step": sf, "input_decimation": e["decim"],
+                          "audio_paths": {PATH_TEXT[p]: e["paths"][p] for p in range(3) if e["paths"][p]},
+                          "rooflines": [roofline(s_) for s_ in e["stages"].values()]}
         out["extra"] = extra
 
     if rank == 0:
@@ -443,6 +579,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
     rdv.close()
+    if not parity["ranks_agree"]:
+        raise SystemExit("bench.py: PARITY HASH MISMATCH between ranks: %r" % (parity,))
 
 
 if __name__ == "__main__":

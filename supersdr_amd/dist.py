@@ -30,6 +30,7 @@ class Rendezvous:
         self.backend = backend
         self.device = device
         self._dist = None
+        self.fallback_reason = None
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -41,9 +42,15 @@ class Rendezvous:
                 dist.init_process_group(backend=backend, **kw)
                 if backend == "nccl":
                     dist.barrier()                    # forces communicator creation now, not inside the timed region
-            except Exception:
-                # The rendezvous carries no data (a barrier and two scalars): if RCCL cannot come up, gloo does the
-                # same job over TCP and the measurement is unaffected.
+            except Exception as e:
+                # The rendezvous carries no data (a barrier and a few scalars): if RCCL cannot come up, gloo does the
+                # same job over TCP and the measurement is unaffected -- but it is said, loudly, and it is in the JSON.
+                if backend != "nccl":
+                    raise
+                import sys
+                self.fallback_reason = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+                print("supersdr_amd.dist: RCCL rendezvous FAILED on rank %d (%s); falling back to gloo over TCP for the "
+                      "barrier / max-over-ranks (no data path uses it)" % (self.rank, self.fallback_reason), file=sys.stderr, flush=True)
                 if dist.is_initialized():
                     dist.destroy_process_group()
                 self.backend = backend = "gloo"
@@ -71,6 +78,29 @@ class Rendezvous:
         t = torch.tensor([float(value)], dtype=torch.float64, device=dev)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
         return float(t.item())
+
+    def gather_ints(self, values):
+        """every rank's list of (up to 64-bit, unsigned) integers -> list over ranks of lists (on every rank)"""
+        values = [int(v) for v in values]
+        if self._dist is None:
+            return [values]
+        import torch
+        dev = self.device if (self.backend == "nccl" and self.device is not None) else "cpu"
+        # as two 32-bit halves in int64: no signed overflow on any backend
+        t = torch.tensor([[v >> 32, v & 0xFFFFFFFF] for v in values], dtype=torch.int64, device=dev).reshape(-1)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(outs, t)
+        return [[(int(o[2 * i]) << 32) | int(o[2 * i + 1]) for i in range(len(values))] for o in outs]
+
+    def gather_floats(self, values):
+        if self._dist is None:
+            return [[float(v) for v in values]]
+        import torch
+        dev = self.device if (self.backend == "nccl" and self.device is not None) else "cpu"
+        t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+        outs = [torch.empty_like(t) for _ in range(self.world)]
+        self._dist.all_gather(outs, t)
+        return [[float(x) for x in o] for o in outs]
 
     def close(self):
         if self._dist is not None:

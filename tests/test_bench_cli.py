@@ -53,3 +53,48 @@ def test_without_a_gpu_every_rank_fails_loudly():
     p = run(["--gpus", "2", "--no-cpu-baseline"])
     assert p.returncode != 0
     assert "needs a GPU" in p.stderr and "rank exit codes" in p.stderr
+
+
+def test_parity_hash_gather_and_mismatch_is_an_error():
+    """every rank's probe checksums are gathered, rank r's view of rank r+1's block is compared with that
+    rank's own, and a disagreement fails the run (exit code != 0) after the JSON line was printed."""
+    p = run(["--gpus", "3", "--dry-run"])
+    assert p.returncode == 0, p.stderr
+    d = last_json(p)
+    par = d["parity"]
+    assert par["ranks_agree"] and par["mismatching_ranks"] == [] and par["first_channel_ids"] == [0, 65536, 131072]
+    assert len(par["checksums"]) == 3 and all(len(c) == 3 and all(len(x) == 16 for x in c) for c in par["checksums"])
+    assert len({tuple(c) for c in par["checksums"]}) == 3          # different blocks hash differently
+    p = run(["--gpus", "3", "--dry-run"], {"SSDR_DRYRUN_BREAK_RANK": "1"})
+    assert p.returncode != 0
+    d = last_json(p)
+    assert not d["parity"]["ranks_agree"] and d["parity"]["mismatching_ranks"] == [1]
+    p = run(["--gpus", "2", "--dry-run", "--workload", "million"])
+    assert last_json(p)["parity"]["first_channel_ids"] == [0, 1 << 19]
+
+
+def test_spawned_ranks_are_confined_to_their_gpu():
+    """bench.py --gpus N without a launcher: rank r gets HIP_VISIBLE_DEVICES=r and addresses device 0"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    seen = []
+
+    class P:
+        def __init__(self, argv, env=None, stdout=None):
+            seen.append(env)
+
+        def wait(self):
+            return 0
+
+    b.subprocess.Popen = P
+    env0 = dict(os.environ)
+    os.environ.pop("SSDR_BENCH_DEVICE", None)
+    try:
+        b.spawn_ranks(3, ["--gpus", "3"])
+    finally:
+        os.environ.clear()
+        os.environ.update(env0)
+    assert [e["HIP_VISIBLE_DEVICES"] for e in seen] == ["0", "1", "2"] and all(e["SSDR_BENCH_DEVICE"] == "0" for e in seen)
+    assert [e["RANK"] for e in seen] == ["0", "1", "2"] and all(e["WORLD_SIZE"] == "3" for e in seen)
