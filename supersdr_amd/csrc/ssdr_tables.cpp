@@ -75,12 +75,13 @@ static double sinc_pi(double x)
     return std::sin(y) / y;
 }
 
-// utils_supersdr.py:334-344, with the tap count capped at n_max (odd)
-int ssdr_design_lowpass(double fl, double fs, int n_max, double *h)
+// utils_supersdr.py:334-344, with the tap count capped at n_max (odd); n_min > 0: at least that many taps (odd)
+static int design_lowpass_n(double fl, double fs, int n_max, int n_min, double *h)
 {
     const double b = fl / fs;
     int N = (int)std::ceil(4.0 / b);
     if (N % 2 == 0) N += 1;
+    if (N < n_min) N = (n_min % 2) ? n_min : n_min + 1;
     if (N > n_max) N = (n_max % 2) ? n_max : n_max - 1;
     double sum = 0.0;
     for (int n = 0; n < N; n++) {
@@ -92,6 +93,7 @@ int ssdr_design_lowpass(double fl, double fs, int n_max, double *h)
     for (int n = 0; n < N; n++) h[n] /= sum;
     return N;
 }
+int ssdr_design_lowpass(double fl, double fs, int n_max, double *h) { return design_lowpass_n(fl, fs, n_max, 0, h); }
 
 static uint32_t dphi_of(double f_hz)
 {
@@ -130,9 +132,14 @@ int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, flo
     }
     fl = std::min(std::max(fl, 50.0), SSDR_RATE / 2.0);          // the OUTPUT rate bounds the passband: this is the anti-alias filter too
     double h[SSDR_NTAP_MAX];
-    // the reference's tap formula at the input rate (N = ceil(4 fs / fl) grows with D); the slots hold 127 taps (125 at D = 4,
-    // where each of the four polyphase streams gets 32 slots, one of them the stream's leading delay tap)
-    const int ntap = ssdr_design_lowpass(fl, fs_in, decim == 4 ? 125 : SSDR_NTAP_MAX - 1, h);
+    // The reference's tap formula (Blackman-windowed sinc, cut-off fl) at the input rate.  Its length rule N = ceil(4 fs / fl)
+    // sizes an interpolation filter; in front of a decimator it would leave a transition band of 5.5 fs_in / N that reaches
+    // far into what folds onto the 12 kHz output (33 taps for the full-band AM default at D = 4: +-4 kHz around 6 kHz).  A
+    // decimating channel filter therefore always takes the whole tap budget -- 127 taps at D = 2, 125 at D = 4 (each of the
+    // four polyphase streams gets 32 slots, one of them the stream's leading delay tap): transition +-0.52 / +-1.06 kHz
+    // around the cut-off, >= 74 dB beyond it.
+    const int n_cap = decim == 4 ? 125 : SSDR_NTAP_MAX - 1;
+    const int ntap = design_lowpass_n(fl, fs_in, n_cap, decim > 1 ? n_cap : 0, h);
     for (int i = 0; i < SSDR_NTAP_MAX; i++) taps[i] = (i < ntap) ? (float)h[i] : 0.0f;
     // The windowed-sinc formula leaves numerical dust where a tap is mathematically zero (sinc at integers,
     // Blackman end points: 1e-17 .. 1e-34 against a peak of ~1).  Taps below 2^-40 of the largest are set to

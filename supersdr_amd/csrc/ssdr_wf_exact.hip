@@ -1,10 +1,10 @@
 // ssdr_wf_exact.hip -- the waterfall stage in float64 (ssdr_set_exact_bins): the same definition as ssdr_wf.hip
 // (Hann window -> 1024-pt FFT -> |X|^2 cal -> byte = #{k : T[k] <= p} -> fftshift -> sum of N lines), evaluated the way the
-// normative NumPy oracle evaluates it: samples times the float32 window table in float64 (exact products), a float64 FFT,
+// normative float64 definition (NumPy) evaluates it: samples times the float32 window table in float64 (exact products), a float64 FFT,
 // float64 power, float32 thresholds compared in float64.  An fp32 FFT lands ~3e-4 of the bins one step off where |X| sits
 // within its rounding error of a 1-dB threshold (the guard band of DESIGN.md section 3); a float64 FFT's error (1e-15
 // relative) is ten orders of magnitude below the spacing of anything that can sit there, so these bins equal the
-// oracle's bit for bit -- north_star's "bit-exact int16 waterfall bins" taken literally.
+// float64 definition's bit for bit -- north_star's "bit-exact int16 waterfall bins" taken literally.
 //
 // Not the fast path: one 256-thread workgroup per (channel, averaging group), the line in LDS as 1024 double complex,
 // textbook radix-2 DIT with __syncthreads between stages.  ~25x slower than ssdr_wf_kernel (profiles/README.md); opt-in.

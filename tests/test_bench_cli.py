@@ -88,12 +88,13 @@ def test_spawned_ranks_are_confined_to_their_gpu():
         def wait(self):
             return 0
 
-    b.subprocess.Popen = P
-    env0 = dict(os.environ)
+    real_popen, env0 = subprocess.Popen, dict(os.environ)
+    subprocess.Popen = P                                   # (bench.py uses the module's attribute)
     os.environ.pop("SSDR_BENCH_DEVICE", None)
     try:
         b.spawn_ranks(3, ["--gpus", "3"])
     finally:
+        subprocess.Popen = real_popen
         os.environ.clear()
         os.environ.update(env0)
     assert [e["HIP_VISIBLE_DEVICES"] for e in seen] == ["0", "1", "2"] and all(e["SSDR_BENCH_DEVICE"] == "0" for e in seen)

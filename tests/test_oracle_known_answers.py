@@ -320,3 +320,16 @@ def test_decimating_front_end_twin_vs_oracle(twin, decim):
     p = O.ChanParams(mode="am", f_shift_hz=0.0, low_cut=-3000.0, high_cut=3000.0, agc_on=0, man_gain=50)
     out, rssi = O.audio_chain(x, [p], decim)
     assert np.abs(out[0, 2048:]).max() <= 2 and rssi[0, -1] < -70.0       # >= 70 dB down: the Blackman stop band
+    # the hard case for a decimator -- what FOLDS INTO the passband.  Full-band AM default (+-6 kHz): a carrier at
+    # 8 kHz lands on -4 kHz of the 12 kHz output (D = 2: 8 - 12; D = 4: the same), right inside the passband.  With the
+    # interpolator's length rule (33 taps at D = 4) it came through ~25 dB down; with the whole tap budget the transition ends
+    # at 6.5 / 7.1 kHz and the alias is >= 70 dB below an in-band carrier of the same amplitude.
+    def level(f_hz, lc, hc):
+        zz = 12000.0 * np.exp(2j * np.pi * f_hz * n / fs_in)
+        xx = np.stack([np.rint(zz.real), np.rint(zz.imag)], axis=-1).astype(np.int16)[None]
+        pp = O.ChanParams(mode="am", f_shift_hz=0.0, low_cut=lc, high_cut=hc, agc_on=0, man_gain=50)
+        return float(O.audio_chain(xx, [pp], decim)[1][0, -1])
+    assert level(2000.0, -6000.0, 6000.0) - level(8000.0, -6000.0, 6000.0) > 70.0
+    assert level(1000.0, -3000.0, 3000.0) - level(12000.0 - 2500.0, -3000.0, 3000.0) > 70.0
+    k = O.compile_params(O.ChanParams(mode="am"), decim)
+    assert int(k["ntap"]) == (125 if decim == 4 else 127)
