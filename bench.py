@@ -62,17 +62,20 @@ PATH_NAMES = ("FIR", "shift", "AM-shift")        # ssdr_audio_kernel<0|1|2>
 PATH_TEXT = ("general: NCO -> FIR -> demodulator", "full-band lane shift: NCO, no FIR", "full-band AM: no NCO, no FIR (|x e^{j phi}| = |x|)")
 F32_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: vector f32 peak (an FMA = 2 flop)
 RIDGE_FLOP_PER_BYTE = F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)          # 19.7
-# Executed vector work per unit: VALU wave-instructions from PMC SQ_INSTS_VALU / wave-units (profiles/r02_*_pmc_summary.txt,
-# profiles/README.md "VALU floor"), FMA share from the static opcode mix of the loops (profiles/r02_isa_histograms.txt;
-# for <0> the 512 filter FMAs of the 33-tap case are dynamic).  flops = 64 lanes x (instructions + FMA instructions).
+# Executed vector work per unit: VALU wave-instructions from PMC SQ_INSTS_VALU / wave-units (profiles/r03_*_pmc_summary.txt:
+# 6.797e8 per 524 288 line pairs, 4.150e8 per 327 680, 5.456e8 / 1.872e8 / 9.373e7 per 655 360 / 327 680 / 327 680 frames,
+# 7.031e8 per 262 144 frames), FMA share from the static opcode mix of the loops (profiles/r02_isa_histograms.txt; the
+# filters' multiply-adds -- 512 per frame for 33 taps, 2000 for 125 at D = 4 -- are dynamic).
+# flops = 64 lanes x (instructions + FMA instructions).
 KERNEL_VALU = {
-    "ssdr_wf_kernel<false, false>": ("line", 1266 / 2, 0.55),
-    "ssdr_wf_kernel<true, false>": ("line", 1266 / 2, 0.55),
-    "ssdr_wf_kernel<false, true>": ("line", 1266 / 2, 0.55),
-    "ssdr_wf_kernel<true, true>": ("line", 1266 / 2, 0.55),
-    "ssdr_audio_kernel<0>": ("frame", 829, 0.75),
-    "ssdr_audio_kernel<1>": ("frame", 572, 0.42),
+    "ssdr_wf_kernel<false, false>": ("line", 1296 / 2, 0.60),
+    "ssdr_wf_kernel<true, false>": ("line", 1266 / 2, 0.60),
+    "ssdr_wf_kernel<false, true>": ("line", 1296 / 2, 0.60),
+    "ssdr_wf_kernel<true, true>": ("line", 1266 / 2, 0.60),
+    "ssdr_audio_kernel<0>": ("frame", 832, 0.75),
+    "ssdr_audio_kernel<1>": ("frame", 571, 0.42),
     "ssdr_audio_kernel<2>": ("frame", 286, 0.17),
+    "ssdr_audio_dec_kernel<4>": ("frame", 2682, 0.85),
 }
 
 
@@ -338,7 +341,8 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
                    "audio stage: " + " + ".join("ssdr_audio_kernel<%d> (%s, %d ch)" % (p, PATH_NAMES[p], paths[p]) for p in live) + \
                    (" one after the other" if concurrent & 2 else " side by side")
         stages["audio"] = {"kernel": name, "avg_ms": avg, "launches": au_n, "bytes": b, "GBps": b / avg / 1e6,
-                           "units_by_kernel": {"ssdr_audio_kernel<%d>" % p: paths[p] * n_frames for p in live} if decim == 1 else {}}
+                           "units_by_kernel": {"ssdr_audio_kernel<%d>" % p: paths[p] * n_frames for p in live} if decim == 1
+                                              else {name: channels * n_frames}}
     if fu_n:
         avg = fu_ms / fu_n
         b = channels * sframes * 8192.0                 # SURVEY.md 8d, fused budget at N = 1: 4096 in + 2048 + 2048 out
@@ -439,6 +443,8 @@ def main():
     ap.add_argument("--hop", type=int, default=1024, choices=[512, 1024],
                     help="samples between waterfall lines: 512 = 23.4 lines/s, the reference's waterfall rate (utils_supersdr.py:597)")
     ap.add_argument("--exact", type=int, default=0, help="1: ssdr_set_exact_bins -- the waterfall stage in float64 (bins equal the float64 oracle bit for bit)")
+    ap.add_argument("--no-parity-probe", action="store_true",
+                    help="profiling runs only: skip the probe launches of the parity hash (they would enter the per-kernel PMC means)")
     ap.add_argument("--dry-run", action="store_true",
                     help="control flow only (ranks, rendezvous over gloo, channel blocks, JSON line), no GPU work: the CPU test of --gpus")
     args = ap.parse_args()
@@ -496,10 +502,13 @@ def main():
     # SURVEY.md 8e parity hash (untimed): every rank hashes a probe of its own channel block and of the NEXT rank's block;
     # rank r's view of block r+1 must equal rank r+1's own (at N = 1: a second fresh ctx must reproduce the first)
     firsts = [int(v[0]) for v in rdv.gather_ints([first_id])]
-    own = parity_probe(S, local_rank, args.workload, first_id)
-    cross = parity_probe(S, local_rank, args.workload, firsts[(rank + 1) % world])
-    parity = parity_report(rdv, world, firsts, own, cross,
-                           "fresh ctx, 256 channels from the block's first id x 4 superframes x 2 steps, ssdr_output_checksum (wf, pcm, rssi)")
+    if args.no_parity_probe:
+        parity = {"ranks_agree": True, "skipped": "--no-parity-probe"}
+    else:
+        own = parity_probe(S, local_rank, args.workload, first_id)
+        cross = parity_probe(S, local_rank, args.workload, firsts[(rank + 1) % world])
+        parity = parity_report(rdv, world, firsts, own, cross,
+                               "fresh ctx, 256 channels from the block's first id x 4 superframes x 2 steps, ssdr_output_checksum (wf, pcm, rssi)")
     per_rank = [v[0] for v in rdv.gather_floats([m["own_value"]])]
     stages = m["stages"]
     dom = max(stages, key=lambda k: stages[k]["avg_ms"])

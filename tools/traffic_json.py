@@ -23,7 +23,7 @@ def mean_per_kernel(path, counter):
     with open(path) as f:
         for r in csv.DictReader(f):
             if r["Counter_Name"] == counter:
-                m = re.search(r"(ssdr_\w+_kernel<[^>]*>)", r["Kernel_Name"])
+                m = re.search(r"(ssdr_\w+_kernel(?:<[^>]*>)?)", r["Kernel_Name"])
                 if m:
                     acc[m.group(1)].append(float(r["Counter_Value"]))
     return {k: sum(v[2:]) / len(v[2:]) if len(v) > 2 else sum(v) / len(v) for k, v in acc.items()}
@@ -35,8 +35,8 @@ def main():
     cfg = line["config"]
     fetch = mean_per_kernel(d + "/fetch_counter_collection.csv", "FETCH_SIZE")
     write = mean_per_kernel(d + "/write_counter_collection.csv", "WRITE_SIZE")
-    wl = [k for k in ("full", "wf", "mixed", "million") if {"full": "configs[2]", "wf": "configs[1]", "mixed": "configs[3]",
-                                                           "million": "configs[4]"}[k] in cfg["workload"]][0]
+    wl = [k for k in ("full", "wf", "mixed", "million", "decim4") if {"full": "configs[2]", "wf": "configs[1]", "mixed": "configs[3]",
+                                                                     "million": "configs[4]", "decim4": "ssdr_set_decimation(4)"}[k] in cfg["workload"]][0]
     out = {"workload": wl, "channels_per_gpu": cfg["channels_per_gpu"], "superframes_per_step": cfg["superframes_per_step"],
            "wf_hop": cfg.get("wf_hop", 1024),
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = 2*FETCH_KB*1024 + WRITE_KB*1024",
