@@ -32,6 +32,9 @@
 #ifndef SSDR_WF_PAIR_MAJOR
 #define SSDR_WF_PAIR_MAJOR 0
 #endif
+#ifndef SSDR_WF_BLOCKED_ITEMS
+#define SSDR_WF_BLOCKED_ITEMS 0              // A/B: each wave takes a contiguous range of work items instead of a strided one
+#endif
 
 namespace {
 
@@ -400,7 +403,14 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
     const uint32_t n_items = n_pairs * a.n_groups;
     const uint32_t wave_stride = gridDim.x * WAVES;
 
+#if SSDR_WF_BLOCKED_ITEMS
+    const uint32_t per_wave = (n_items + wave_stride - 1) / wave_stride;
+    const uint32_t item_begin = (blockIdx.x * WAVES + wave) * per_wave;
+    const uint32_t item_end = min(item_begin + per_wave, n_items);
+    for (uint32_t item = item_begin; item < item_end; item++) {
+#else
     for (uint32_t item = blockIdx.x * WAVES + wave; item < n_items; item += wave_stride) {
+#endif
         const WfItem it = wf_item<HOP>(a, item, n_pairs, h);
         const float cal = a.consts[it.ch].wf_cal_lin;
         uint32_t acc[AVG ? 16 : 1];
