@@ -132,7 +132,7 @@ def cpu_baseline(workload, budget_s=5.0):
         for c in range(nch):
             k = O.compile_params(CB.chan_params(c, modes))
             for f in ("mode", "ntap", "dphi1", "dphi2", "wf_cal_lin", "smeter_cal_db", "agc_c0", "agc_c1",
-                      "agc_knee", "agc_delta8", "hang_frames", "fir_flags"):
+                      "agc_knee", "agc_delta8", "hang_frames", "fir_flags", "kfm"):
                 consts[f][c] = k[f]
             consts["ntap8"][c] = (k["ntap"] + 7) // 8 * 8
             taps[c] = k["taps"]

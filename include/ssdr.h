@@ -80,7 +80,7 @@ typedef struct ssdr_chan_consts {
     uint32_t tap_groups;            /* bit g set: taps 4g..4g+3 are not all zero (the FIR skips the others) */
     uint32_t fir_flags;             /* SSDR_FIR_*                                                            */
     uint32_t decim;                 /* D: the IQ arrives at D * 12 kHz (ssdr_set_decimation); taps are then stream-major, ntap8 per stream */
-    uint32_t pad[1];
+    float kfm;                      /* NBFM: output per radian = 16384 * rate / (2 pi 5000) -- 5 kHz deviation = half scale at the channel's rate */
 } ssdr_chan_consts;
 /* the channel filter is exactly a 4-sample delay (one unit tap at index 4: the full-band passband +-6 kHz at 12 kHz,
  * the reference's AM default, utils_supersdr.py:46).  The kernel then shifts samples across lanes instead of filtering,
@@ -198,6 +198,11 @@ int ssdr_run_playbuffer(ssdr_ctx *ctx, const ssdr_play_chan *chans, int16_t *out
  * (2048 or 1213 = int(512 * SAMPLE_RATIO), the OutputStream blocksize of :1211). */
 #define SSDR_RATE_WIDE 20250
 int ssdr_set_kiwi_rate(ssdr_ctx *ctx, uint32_t kiwi_rate);
+/* The same rate is the rate of the IQ the channels receive (a three-channel KiwiSDR delivers 20.25 kHz IQ and SND frames,
+ * utils_supersdr.py:988-994): NCO steps, channel-filter design, AGC time constants and the NBFM scale are compiled for it
+ * (ssdr_compile_params_rate), a frame stays 512 samples, the waterfall's 1024 bins then span 20.25 kHz and f_shift_hz may
+ * reach +-10125.  A change recompiles every channel's parameters and resets the streams, like ssdr_set_decimation. */
+int ssdr_compile_params_rate(const ssdr_chan_params *p, uint32_t decim, uint32_t rate, ssdr_chan_consts *consts, float *taps /*[128]*/);
 /* audio_rec.recording_flag (utils_supersdr.py:149-157, 1139-1140): while set, ssdr_run_playbuffer also keeps what play_buffer
  * appends to audio_rec.audio_buffer -- the interpolated block before the pan, pyaudio_buffer.astype(np.int16) -- and
  * ssdr_playbuffer_mono returns it for the last run: int16 [n_ch][n_frames*L], L = ssdr_playbuffer_frame_len(). */

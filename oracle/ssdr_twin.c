@@ -325,7 +325,7 @@ typedef struct {            /* per-channel kernel constants; same layout as the 
     uint32_t tap_groups;    /* unused here: zero taps are exact no-ops in the fma chain */
     uint32_t fir_flags;     /* bit 0: the filter is a pure 4-sample delay (one unit tap at index 4) */
     uint32_t decim;         /* D (0 or 1: none): the IQ arrives at D * 12 kHz; taps are stream-major, ntap8 per stream */
-    uint32_t pad[1];
+    float kfm;              /* NBFM: output per radian, 16384 * rate / (2 pi 5000) */
 } twin_consts;              /* 64 bytes */
 #define FIR_DELAY4 1u
 
@@ -403,7 +403,6 @@ static const float DC_A = 0.9921875f, DC_AL = 0.0078125f;
 /* float32((127/128)^(j+1)), j = 0..7 */
 static const float DC_APOW[8] = { 0x1.fcp-1f, 0x1.f808p-1f, 0x1.f417fp-1f, 0x1.f02fcp-1f,
                                   0x1.ec4f6p-1f, 0x1.e876c2p-1f, 0x1.e4a5d4p-1f, 0x1.e0dc88p-1f };
-static const float KFM = 0x1.8723a2p+12f;   /* float32(16384*12000/(2*pi*5000)) = 6258.227 */
 static const float P_FLOOR = 9.5367431640625e-07f;   /* 2^-20 */
 
 static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, const float *taps,
@@ -519,7 +518,7 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
         for (int n = 0; n < FRAME; n++) {
             float dr = fmaf(z2r[n], pr, z2i[n] * pi);
             float di = fmaf(z2i[n], pr, -(z2r[n] * pi));
-            aud[n] = atan2p(di, dr) * KFM;
+            aud[n] = atan2p(di, dr) * c->kfm;       /* 12 kHz: float32(16384*12000/(2*pi*5000)) = 6258.227 */
             pr = z2r[n]; pi = z2i[n];
         }
     }

@@ -31,7 +31,7 @@ class ChanConsts(C.Structure):
                 ("wf_cal_lin", C.c_float), ("smeter_cal_db", C.c_float),
                 ("agc_c0", C.c_float), ("agc_c1", C.c_float), ("agc_knee", C.c_float), ("agc_delta8", C.c_float),
                 ("hang_frames", C.c_uint32), ("ntap", C.c_uint32), ("tap_groups", C.c_uint32), ("fir_flags", C.c_uint32),
-                ("decim", C.c_uint32), ("pad", C.c_uint32 * 1)]
+                ("decim", C.c_uint32), ("kfm", C.c_float)]
 
 
 class Db2colChan(C.Structure):
@@ -77,6 +77,7 @@ _SIGS = {
     "ssdr_set_exact_bins": (C.c_int, [_P, C.c_int]),
     "ssdr_set_decimation": (C.c_int, [_P, C.c_uint32]),
     "ssdr_compile_params_decim": (C.c_int, [C.POINTER(ChanParams), C.c_uint32, C.POINTER(ChanConsts), _P]),
+    "ssdr_compile_params_rate": (C.c_int, [C.POINTER(ChanParams), C.c_uint32, C.c_uint32, C.POINTER(ChanConsts), _P]),
     "ssdr_push_iq": (C.c_int, [_P, _P, C.c_uint32, C.c_int]),
     "ssdr_run_wf": (C.c_int, [_P, _P, C.POINTER(C.c_uint32), C.c_int]),
     "ssdr_run_audio": (C.c_int, [_P, _P, _P, C.c_int]),

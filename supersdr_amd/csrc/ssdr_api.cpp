@@ -323,7 +323,7 @@ int ssdr_set_params(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan
     std::vector<ssdr_chan_consts> k(count);
     std::vector<float> taps((size_t)count * SSDR_NTAP_MAX);
     for (uint32_t i = 0; i < count; i++) {
-        const int rc = ssdr_compile_params_host(p + i, &k[i], taps.data() + (size_t)i * SSDR_NTAP_MAX, c->decim);
+        const int rc = ssdr_compile_params_host(p + i, &k[i], taps.data() + (size_t)i * SSDR_NTAP_MAX, c->decim, c->kiwi_rate);
         if (rc != SSDR_OK) return rc;
     }
     for (uint32_t i = 0; i < count; i++) c->h_params[first + i] = p[i];
@@ -441,6 +441,11 @@ int ssdr_set_averaging(ssdr_ctx *c, uint32_t n)
 int ssdr_compile_params_decim(const ssdr_chan_params *p, uint32_t decim, ssdr_chan_consts *consts, float *taps)
 {
     return ssdr_compile_params_host(p, consts, taps, decim);
+}
+
+int ssdr_compile_params_rate(const ssdr_chan_params *p, uint32_t decim, uint32_t rate, ssdr_chan_consts *consts, float *taps)
+{
+    return ssdr_compile_params_host(p, consts, taps, decim, rate);
 }
 
 int ssdr_set_decimation(ssdr_ctx *c, uint32_t decim)
@@ -1521,8 +1526,18 @@ int ssdr_run_smeter(ssdr_ctx *c, ssdr_smeter_chan *chans, const double *rssi_in,
 int ssdr_set_kiwi_rate(ssdr_ctx *c, uint32_t kiwi_rate)
 {
     if (!c || (kiwi_rate != SSDR_RATE && kiwi_rate != SSDR_RATE_WIDE)) return SSDR_EINVAL;
+    if (kiwi_rate == c->kiwi_rate) return SSDR_OK;
+    if (!c->feed.empty()) return SSDR_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    // the rate of the play-back stage AND of the IQ the channels receive: every channel's constants (NCO steps, filter,
+    // AGC time constants, NBFM scale) are compiled for it, and streams of the old rate mean nothing at the new one
+    const uint32_t keep = c->kiwi_rate;
     c->kiwi_rate = kiwi_rate;
-    return SSDR_OK;
+    std::vector<ssdr_chan_params> all = c->h_params;
+    int rc = ssdr_set_params(c, 0, c->n_ch, all.data());
+    if (rc != SSDR_OK) { c->kiwi_rate = keep; (void)ssdr_set_params(c, 0, c->n_ch, all.data()); return rc; }
+    c->have_input = false;
+    return ssdr_reset_state(c, 0, c->n_ch);
 }
 
 int ssdr_playbuffer_frame_len(ssdr_ctx *c, uint32_t *samples_per_frame)

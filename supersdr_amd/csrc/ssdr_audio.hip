@@ -283,7 +283,7 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
                 nco_block(n2, f, b2c, b2s);
                 demod_ssb(yr, yi, b2c, b2s, cs2, ss2, aud);
             }
-            else demod_fm(yr, yi, prev_re, prev_im, aud);
+            else demod_fm(yr, yi, prev_re, prev_im, kc.kfm, aud);
             // the filter output is an fma chain that ends in "+ 0": a -0 can only come out of the shift path
             prev_re = lane63(yr[7]);
             prev_im = lane63(yi[7]);
@@ -460,7 +460,7 @@ SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, cons
                 float b2c, b2s;
                 nco_block(n2, f, b2c, b2s);
                 demod_ssb(yr, yi, b2c, b2s, cs2, ss2, aud);
-            } else demod_fm(yr, yi, prev_re, prev_im, aud);
+            } else demod_fm(yr, yi, prev_re, prev_im, kc.kfm, aud);
             prev_re = lane63(yr[7]);
             prev_im = lane63(yi[7]);
             agc_pack_store(p, aud, l, agc, agc_d, agc_m, dst);

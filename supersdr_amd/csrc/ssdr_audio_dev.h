@@ -225,14 +225,14 @@ SSDR_DEV void demod_ssb(const float (&yr)[8], const float (&yi)[8], float c, flo
 }
 
 // NBFM discriminator: angle of y[n] * conj(y[n-1])
-SSDR_DEV void demod_fm(const float (&yr)[8], const float (&yi)[8], float prev_re, float prev_im, float (&aud)[8])
+SSDR_DEV void demod_fm(const float (&yr)[8], const float (&yi)[8], float prev_re, float prev_im, float kfm, float (&aud)[8])
 {
     float pr = from_prev_lane(prev_re, yr[7]), pi = from_prev_lane(prev_im, yi[7]);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         const float dr = fmaf(yr[j], pr, yi[j] * pi);
         const float di = fmaf(yi[j], pr, -(yr[j] * pi));
-        aud[j] = ssdr_atan2p(di, dr) * SSDR_KFM;
+        aud[j] = ssdr_atan2p(di, dr) * kfm;
         pr = yr[j]; pi = yi[j];
     }
 }

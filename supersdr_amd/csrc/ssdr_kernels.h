@@ -144,5 +144,5 @@ void ssdr_make_twiddles(float *wr, float *wi);        // [512] each
 void ssdr_make_tw_stage(float2 *tw);                  // [992]
 void ssdr_make_thresholds(float *thr);                // [256]
 int ssdr_make_quant_lut(uint2 *lut);                  // [SSDR_LUT_N]; returns 0, or -1 if a segment held two thresholds
-int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps, uint32_t decim);
+int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps, uint32_t decim, uint32_t rate_hz = SSDR_RATE);
 int ssdr_design_lowpass(double fl, double fs, int n_max, double *h);   // utils_supersdr.py:334-344; returns tap count

@@ -95,9 +95,9 @@ static int design_lowpass_n(double fl, double fs, int n_max, int n_min, double *
 }
 int ssdr_design_lowpass(double fl, double fs, int n_max, double *h) { return design_lowpass_n(fl, fs, n_max, 0, h); }
 
-static uint32_t dphi_of(double f_hz)
+static uint32_t dphi_of(double f_hz, double rate)
 {
-    const double x = std::nearbyint(f_hz / SSDR_RATE * 4294967296.0);
+    const double x = std::nearbyint(f_hz / rate * 4294967296.0);
     long long v = (long long)x % 4294967296ll;
     if (v < 0) v += 4294967296ll;
     return (uint32_t)v;
@@ -111,13 +111,16 @@ static uint32_t dphi_at(double f_hz, double fs)
     return (uint32_t)v;
 }
 
-// decim = D in {1, 2, 4}: the IQ arrives at D * 12 kHz and the channel filter decimates to 12 kHz.
-int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps, uint32_t decim)
+// decim = D in {1, 2, 4}: the IQ arrives at D * rate and the channel filter decimates to `rate`;
+// rate = 12000, or 20250 for a three-channel KiwiSDR (utils_supersdr.py:988-994)
+int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps, uint32_t decim, uint32_t rate_hz)
 {
     if (!p || !c || !taps) return SSDR_EINVAL;
     if (p->mode < SSDR_MODE_AM || p->mode > SSDR_MODE_NBFM) return SSDR_EINVAL;
     if (decim != 1 && decim != 2 && decim != 4) return SSDR_EINVAL;
-    const double fs_in = (double)SSDR_RATE * decim;
+    if (rate_hz != SSDR_RATE && rate_hz != SSDR_RATE_WIDE) return SSDR_EINVAL;
+    const double rate = (double)rate_hz;
+    const double fs_in = rate * decim;
     // the tuning offset must lie inside the IQ band: beyond +-fs/2 the NCO step wraps mod 2^32 and the channel would
     // silently demodulate an alias
     if (!(std::fabs(p->f_shift_hz) <= fs_in / 2.0)) return SSDR_EINVAL;
@@ -130,7 +133,7 @@ int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, flo
         f_bc = 0.0;
         fl = std::max(std::fabs(p->low_cut), std::fabs(p->high_cut));
     }
-    fl = std::min(std::max(fl, 50.0), SSDR_RATE / 2.0);          // the OUTPUT rate bounds the passband: this is the anti-alias filter too
+    fl = std::min(std::max(fl, 50.0), rate / 2.0);          // the OUTPUT rate bounds the passband: this is the anti-alias filter too
     double h[SSDR_NTAP_MAX];
     // The reference's tap formula (Blackman-windowed sinc, cut-off fl) at the input rate.  Its length rule N = ceil(4 fs / fl)
     // sizes an interpolation filter; in front of a decimator it would leave a transition band of 5.5 fs_in / N that reaches
@@ -163,7 +166,8 @@ int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, flo
         c->fir_flags = (nz == 1 && ntap > 4 && taps[4] == 1.0f) ? SSDR_FIR_DELAY4 : 0u;
     }
     c->dphi1 = dphi_at(p->f_shift_hz + f_bc, fs_in);            // the mixer runs at the input rate,
-    c->dphi2 = dphi_of(f_bc);                                   // the SSB re-mixer at the output rate
+    c->dphi2 = dphi_of(f_bc, rate);                             // the SSB re-mixer at the output rate
+    c->kfm = (float)(16384.0 * rate / (2.0 * kPi * 5000.0));    // NBFM: 5 kHz deviation <-> half scale
     c->decim = decim;
     if (decim > 1) {
         // Polyphase streams v_q[m] = z[D m + q], q = 0..D-1 (what a lane's D*8 consecutive inputs de-interleave into):
@@ -201,7 +205,7 @@ int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, flo
     }
     const double knee = (p->agc_thresh - p->smeter_cal_db) * (log2_10 / 10.0) + 30.0;
     const double tau = std::max(p->agc_decay, 1.0) / 1000.0;
-    const double delta8 = 2.0 * std::log2(std::exp(1.0)) * 8.0 / (tau * SSDR_RATE);
+    const double delta8 = 2.0 * std::log2(std::exp(1.0)) * 8.0 / (tau * rate);
     c->agc_c0 = (float)c0;
     c->agc_c1 = (float)c1;
     c->agc_knee = (float)knee;

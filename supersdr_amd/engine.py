@@ -13,7 +13,7 @@ from ._lib import SmeterChan, ChanParams, ChanConsts, ChanState, Db2colChan, Pla
 CONSTS_DTYPE = np.dtype([("mode", "<u4"), ("ntap8", "<u4"), ("dphi1", "<u4"), ("dphi2", "<u4"),
                          ("wf_cal_lin", "<f4"), ("smeter_cal_db", "<f4"), ("agc_c0", "<f4"), ("agc_c1", "<f4"),
                          ("agc_knee", "<f4"), ("agc_delta8", "<f4"), ("hang_frames", "<u4"), ("ntap", "<u4"),
-                         ("tap_groups", "<u4"), ("fir_flags", "<u4"), ("decim", "<u4"), ("pad", "<u4", (1,))])
+                         ("tap_groups", "<u4"), ("fir_flags", "<u4"), ("decim", "<u4"), ("kfm", "<f4")])
 STATE_DTYPE = np.dtype([("phi1", "<u4"), ("phi2", "<u4"), ("dc", "<f4"), ("agc_d", "<f4"), ("agc_m", "<f4", (8,)),
                         ("prev_re", "<f4"), ("prev_im", "<f4"), ("pad", "<u4", (2,))])
 assert CONSTS_DTYPE.itemsize == 64 and STATE_DTYPE.itemsize == 64
@@ -31,11 +31,12 @@ def default_params(mode="am", **over):
     return p
 
 
-def compile_params(p, decim=1):
-    """ChanParams -> (consts record, float32[128] taps), computed by the library's host code (decim: ssdr_set_decimation)."""
+def compile_params(p, decim=1, rate=L.RATE):
+    """ChanParams -> (consts record, float32[128] taps), computed by the library's host code (decim: ssdr_set_decimation,
+    rate: ssdr_set_kiwi_rate)."""
     k = ChanConsts()
     taps = np.zeros(L.NTAP_MAX, np.float32)
-    check(lib.ssdr_compile_params_decim(C.byref(p), int(decim), C.byref(k), taps.ctypes.data), "ssdr_compile_params")
+    check(lib.ssdr_compile_params_rate(C.byref(p), int(decim), int(rate), C.byref(k), taps.ctypes.data), "ssdr_compile_params")
     rec = np.frombuffer(bytes(k), dtype=CONSTS_DTYPE)[0]
     return rec, taps
 
@@ -301,7 +302,8 @@ class SsdrEngine:
         return chans
 
     def set_kiwi_rate(self, kiwi_rate):
-        """kiwi_sound.KIWI_RATE (utils_supersdr.py:991-994): 12000, or 20250 for play_buffer's resample_poly branch."""
+        """kiwi_sound.KIWI_RATE (utils_supersdr.py:991-994): 12000, or 20250 -- the rate of the IQ the channels receive (their
+        constants are recompiled for it, the streams reset) and of play_buffer, which then takes its resample_poly branch."""
         check(lib.ssdr_set_kiwi_rate(self._ctx, int(kiwi_rate)), "ssdr_set_kiwi_rate")
         self.kiwi_rate = int(kiwi_rate)
 

@@ -41,7 +41,7 @@ from . import _lib as L
 from ._lib import Db2colChan, PlayChan
 from .engine import SsdrEngine, default_params
 
-IQ_SPAN_KHZ = L.RATE / 1000.0          # what one channel's GPU waterfall covers: the 12 kHz IQ band around its centre
+IQ_SPAN_KHZ = L.RATE / 1000.0          # what one channel's GPU waterfall covers: the IQ band around its centre (12 kHz; hub.iq_span_khz)
 
 
 class Frame(np.ndarray):
@@ -96,10 +96,13 @@ class IQHub:
             self.engine.set_hop(hop)
         # spectrum_db2col and play_buffer run on the GPU with every superframe
         self.gpu_post = bool(gpu_post)
-        self.kiwi_rate = int(kiwi_rate)              # kiwi_sound.KIWI_RATE: selects play_buffer's branch (:1125)
+        # kiwi_sound.KIWI_RATE as the server announces it (:988-994): the rate of the IQ the channels receive (12000, or 20250 from
+        # a three-channel KiwiSDR) -- the channels' constants are compiled for it -- and of play_buffer, whose branch it selects (:1125)
+        self.kiwi_rate = int(kiwi_rate)
+        self.iq_span_khz = self.kiwi_rate / 1000.0
+        self.engine.set_kiwi_rate(self.kiwi_rate)
         self.play_len = 2048
         if self.gpu_post:
-            self.engine.set_kiwi_rate(self.kiwi_rate)
             self.play_len = self.engine.playbuffer_frame_len()
         # display reductions: wf_data's newest rows stay on the device, fed by every db2col run
         self.trace_rows = int(trace_rows) if self.gpu_post else 0
@@ -391,9 +394,10 @@ class GpuStream:
             raise ValueError("radio_mode %r has no demodulator on the GPU path (am, lsb, usb, cw, nbfm)" % (kv["mod"],))
         freq = float(kv.get("freq", self.center_khz))
         f_shift = (freq - self.center_khz) * 1000.0
-        if abs(f_shift) > L.RATE / 2:
+        rate = float(getattr(self.hub, "kiwi_rate", L.RATE))
+        if abs(f_shift) > rate / 2:
             raise ValueError("tuning %.3f kHz is outside the %g kHz IQ band around %.3f kHz that channel %d receives"
-                             % (freq, IQ_SPAN_KHZ, self.center_khz, self.channel))
+                             % (freq, rate / 1000.0, self.center_khz, self.channel))
         p = self.hub.params(self.channel)
         q = _copy_params(p, mode=L.MODE_BY_NAME[mode], f_shift_hz=f_shift, low_cut=float(kv.get("low_cut", p.low_cut)),
                          high_cut=float(kv.get("high_cut", p.high_cut)))
@@ -511,10 +515,10 @@ class WaterfallSeams:
 
     # ---- the true frequency axis of the GPU waterfall
     def iq_bin_to_khz(self, bin_):
-        return self.iq_center_khz + (bin_ - self.WF_BINS / 2) * IQ_SPAN_KHZ / self.WF_BINS
+        return self.iq_center_khz + (bin_ - self.WF_BINS / 2) * getattr(self.hub, "iq_span_khz", IQ_SPAN_KHZ) / self.WF_BINS
 
     def iq_khz_to_bin(self, khz):
-        return (khz - self.iq_center_khz) * self.WF_BINS / IQ_SPAN_KHZ + self.WF_BINS / 2
+        return (khz - self.iq_center_khz) * self.WF_BINS / getattr(self.hub, "iq_span_khz", IQ_SPAN_KHZ) + self.WF_BINS / 2
 
     def close_connection(self):
         self.terminate = True

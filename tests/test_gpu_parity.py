@@ -1112,3 +1112,60 @@ def test_exact_bins_equal_the_float64_oracle_bit_for_bit(S, n_ch, n_avg, hop):
         n_diff += int((out[False][:, c] != ref).sum())
     if n_ch >= 33:
         assert 0 < n_diff < 3e-3 * out[False].size * n_avg                # what the mode exists for
+
+
+def test_iq_chain_at_20250_hz_bit_exact_vs_twin_and_oracle(S, twin):
+    """ssdr_set_kiwi_rate(20250) (missing #3): the IQ of a three-channel KiwiSDR.  Every channel's constants are
+    recompiled for the rate (NCO steps, taps, AGC decay, NBFM scale = the oracle's at that rate), the streams reset; random
+    parameter sets over all modes, state crossing calls: PCM, RSSI, flags, state bit-exact vs the twin, vs the float64 oracle
+    under the tolerance rule; tuning may reach +-10.125 kHz; back at 12 kHz the full-band AM shortcut paths return."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import random_params as RP
+    import tolerances as T
+    rate = 20250
+    rng = np.random.default_rng(2025)
+    n_ch, n_frames = 64, 6
+    kw = [RP.draw(rng) for _ in range(n_ch)]
+    kw[0]["f_shift_hz"], kw[0]["mode"], kw[0]["low_cut"], kw[0]["high_cut"] = 9800.0, "usb", 30.0, 300.0
+    iq = RP.signal(rng, n_ch, n_frames * 512)
+    ps = [S.default_params(k["mode"], f_shift_hz=k["f_shift_hz"], low_cut=k["low_cut"], high_cut=k["high_cut"],
+                           agc_on=k["agc_on"], agc_hang=k["hang"], agc_thresh=k["thresh"], agc_slope=k["slope"],
+                           agc_decay=k["decay"], agc_man_gain=k["man_gain"], wf_cal_db=k["wf_cal_db"],
+                           smeter_cal_db=k["smeter_cal_db"]) for k in kw]
+    with S.SsdrEngine(n_ch) as eng:
+        with pytest.raises(S.SsdrError):
+            eng.set_params(0, ps[:1])               # 9.8 kHz off centre does not exist in a 12 kHz band
+        eng.set_params(1, ps[1:])                   # given at 12 kHz ...
+        assert sum(eng.audio_paths()[1:]) > 0       # (some of them on the full-band shortcut paths there)
+        eng.set_kiwi_rate(rate)                     # ... recompiled for 20.25 kHz
+        eng.set_params(0, ps[:1])
+        assert eng.audio_paths()[1:] == (0, 0) and eng.kiwi_rate == rate
+        pcms, rssis, fl, wfs, pos = [], [], [], [], 0
+        for nf in (2, 4):
+            eng.push_iq(iq[:, pos * 512:(pos + nf) * 512])
+            wfs.append(eng.run_wf())
+            p, r = eng.run_audio()
+            pcms.append(p), rssis.append(r), fl.append(eng.audio_flags())
+            pos += nf
+        consts, taps = eng.get_consts()
+        st_g, hist_g = eng.get_state()
+        with pytest.raises(S.SsdrError):
+            eng.set_params(1, [S.default_params("am", f_shift_hz=10200.0)])
+        with pytest.raises(S.SsdrError):
+            eng.set_kiwi_rate(12000)                # channel 0 sits 9.8 kHz off centre: refused, and nothing changed
+        assert eng.get_consts()[0]["kfm"][0] == consts["kfm"][0]
+        eng.set_params(0, [S.default_params("am")])
+        eng.set_kiwi_rate(12000)
+        assert sum(eng.audio_paths()[1:]) > 0
+    for c in (0, 5, 63):
+        k = O.compile_params(O.ChanParams(**kw[c]), 1, rate)
+        assert int(consts["dphi1"][c]) == int(k["dphi1"]) and int(consts["dphi2"][c]) == int(k["dphi2"]) and int(consts["ntap"][c]) == int(k["ntap"])
+        assert np.array_equal(taps[c], k["taps"]) and consts["kfm"][c] == k["kfm"] and consts["agc_delta8"][c] == k["agc_delta8"]
+    st, hist = twinlib.fresh_state(consts)
+    pcm_t, rssi_t, flags_t = twin.audio(iq, consts, taps, st, hist, want_flags=True)
+    pcm = np.concatenate(pcms, axis=1)
+    assert np.array_equal(pcm, pcm_t) and np.array_equal(np.concatenate(rssis, axis=1), rssi_t)
+    assert np.array_equal(np.concatenate(fl, axis=1), flags_t) and st_g.tobytes() == st.tobytes() and np.array_equal(hist_g, hist)
+    assert np.array_equal(np.concatenate(wfs), twin.wf(iq, 1, consts["wf_cal_lin"]))
+    pcm_o, rssi_o = O.audio_chain(iq, [O.ChanParams(**k) for k in kw], 1, rate)
+    T.assert_pcm_within_tolerance(pcm, pcm_o, iq, rssi_o, [k["smeter_cal_db"] for k in kw], min_well=n_ch // 3)

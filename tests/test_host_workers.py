@@ -58,7 +58,7 @@ class TwinEngine:
 
     def set_params(self, first, params):
         for i, p in enumerate(params):
-            k, t = self.S.compile_params(p)
+            k, t = self.S.compile_params(p, rate=getattr(self, "kiwi_rate", 12000))
             self.consts[first + i] = k
             self.taps[first + i] = t
             if hasattr(self, "param_log"):

@@ -28,7 +28,7 @@ def consts_for(params):
     for c, p in enumerate(params):
         k = O.compile_params(p)
         for f in ("mode", "ntap", "dphi1", "dphi2", "wf_cal_lin", "smeter_cal_db", "agc_c0", "agc_c1", "agc_knee",
-                  "agc_delta8", "hang_frames", "fir_flags"):
+                  "agc_delta8", "hang_frames", "fir_flags", "kfm"):
             consts[f][c] = k[f]
         consts["ntap8"][c] = (k["ntap"] + 7) // 8 * 8
         taps[c] = k["taps"]
@@ -298,7 +298,7 @@ def test_decimating_front_end_twin_vs_oracle(twin, decim):
     for c, p in enumerate(prm):
         k = O.compile_params(p, decim)
         for f in ("mode", "ntap", "ntap8", "dphi1", "dphi2", "wf_cal_lin", "smeter_cal_db", "agc_c0", "agc_c1", "agc_knee",
-                  "agc_delta8", "hang_frames", "fir_flags", "decim"):
+                  "agc_delta8", "hang_frames", "fir_flags", "decim", "kfm"):
             consts[f][c] = k[f]
         taps[c] = k["taps_streams"]
     st, hist = twinlib.fresh_state(consts)
@@ -333,3 +333,58 @@ def test_decimating_front_end_twin_vs_oracle(twin, decim):
     assert level(1000.0, -3000.0, 3000.0) - level(12000.0 - 2500.0, -3000.0, 3000.0) > 70.0
     k = O.compile_params(O.ChanParams(mode="am"), decim)
     assert int(k["ntap"]) == (125 if decim == 4 else 127)
+
+
+# ------------------------------------------------------------------ round 3: the IQ chain at 20.25 kHz
+def test_wide_rate_chain_twin_vs_oracle_and_known_answers():
+    """A three-channel KiwiSDR runs at 20.25 kHz (utils_supersdr.py:988-994): the same chain with every rate-dependent
+    constant compiled for that rate -- NCO steps f / fs, the tap formula at fs, AGC decay per sample, the NBFM scale.
+    Twin vs float64 oracle under the tolerance rule; and what the rate must do to a known signal."""
+    import random_params as RP
+    import tolerances as T
+    rate = 20250
+    rng = np.random.default_rng(77)
+    n_ch, n_frames = 24, 6
+    kw = [RP.draw(rng) for _ in range(n_ch)]
+    iq = RP.signal(rng, n_ch, n_frames * 512)
+    params = [O.ChanParams(**k) for k in kw]
+    consts = np.zeros(n_ch, twinlib.CONSTS_DTYPE)
+    taps = np.zeros((n_ch, 128), np.float32)
+    for c, p in enumerate(params):
+        k = O.compile_params(p, 1, rate)
+        for f in ("mode", "ntap", "dphi1", "dphi2", "wf_cal_lin", "smeter_cal_db", "agc_c0", "agc_c1", "agc_knee", "agc_delta8",
+                  "hang_frames", "fir_flags", "kfm"):
+            consts[f][c] = k[f]
+        consts["ntap8"][c] = (k["ntap"] + 7) // 8 * 8
+        taps[c] = k["taps"]
+    twin = twinlib.load()
+    st, hist = twinlib.fresh_state(consts)
+    pcm_t, rssi_t = twin.audio(iq, consts, taps, st, hist)
+    pcm_o, rssi_o = O.audio_chain(iq, params, 1, rate)
+    T.assert_pcm_within_tolerance(pcm_t, pcm_o, iq, rssi_o, [k["smeter_cal_db"] for k in kw], min_well=n_ch // 3)
+    # constants: the rate is in them
+    k12, k20 = O.compile_params(O.ChanParams("usb", f_shift_hz=1000.0)), O.compile_params(O.ChanParams("usb", f_shift_hz=1000.0), 1, rate)
+    assert abs(int(k20["dphi1"]) / int(k12["dphi1"]) - 12000 / 20250) < 1e-6
+    assert k20["ntap"] > k12["ntap"] and abs(float(k20["kfm"]) / float(k12["kfm"]) - 20250 / 12000) < 1e-6
+    assert abs(float(k20["agc_delta8"]) / float(k12["agc_delta8"]) - 12000 / 20250) < 1e-6
+    assert O.compile_params(O.ChanParams("am"), 1, rate)["fir_flags"] == 0          # +-6 kHz is no longer the whole band
+    O.compile_params(O.ChanParams("usb", f_shift_hz=9000.0), 1, rate)               # inside +-10.125 kHz
+    with pytest.raises(ValueError):
+        O.compile_params(O.ChanParams("usb", f_shift_hz=10200.0), 1, rate)
+    # NBFM: a carrier frequency-modulated with 2.5 kHz deviation at 500 Hz demodulates to 0.25 FS peak at EITHER rate
+    for r in (12000, rate):
+        n = np.arange(8 * 512)
+        ph = (2500.0 / 500.0) * -np.cos(2 * np.pi * 500.0 * n / r)              # beta = deviation / f_mod = 5 rad
+        z = 12000.0 * np.exp(1j * ph)
+        x = np.stack([np.rint(z.real), np.rint(z.imag)], axis=-1).astype(np.int16)[None]
+        out, _ = O.audio_chain(x, [O.ChanParams("nbfm", low_cut=-6000.0, high_cut=6000.0)], 1, r)
+        peak = np.abs(out[0, 2048:].astype(np.float64)).max()
+        assert abs(peak - 8192.0) < 8192.0 * 0.03, (r, peak)
+    # USB: a tone 1 kHz above the tuned frequency comes out as a 1 kHz tone at the channel's own rate
+    n = np.arange(8 * 512)
+    z = 8000.0 * np.exp(2j * np.pi * 4000.0 * n / rate)
+    x = np.stack([np.rint(z.real), np.rint(z.imag)], axis=-1).astype(np.int16)[None]
+    out, _ = O.audio_chain(x, [O.ChanParams("usb", f_shift_hz=3000.0, low_cut=30.0, high_cut=3000.0)], 1, rate)
+    seg = out[0, 1024:1024 + 2025].astype(np.float64)                                # 2025 samples = 100 cycles of 1 kHz at 20.25 kHz
+    spec = np.abs(np.fft.rfft(seg * np.hanning(len(seg))))
+    assert int(np.argmax(spec)) == 100
