@@ -243,6 +243,10 @@ int ssdr_run_smeter(ssdr_ctx *ctx, ssdr_smeter_chan *chans, const double *rssi_i
  * host memory) become the current input batch, as ssdr_push_iq would; rssi_out (may be NULL) receives
  * 0.1*smeter - 127 per frame. */
 int ssdr_push_iq_wire(ssdr_ctx *ctx, const uint8_t *bodies, uint32_t n_frames, float *rssi_out);
+/* The GNSS stamps of those frames -- the `gps` dict _process_aud hands to _process_iq_samples (kiwi/client.py:444-445, 454):
+ * gps_out uint32 [n_ch][n_frames][4] = last_gps_solution, dummy, gpssec, gpsnsec of each frame of the last
+ * ssdr_push_iq_wire (host memory). */
+int ssdr_wire_gps(ssdr_ctx *ctx, uint32_t *gps_out);
 
 /* IMA ADPCM decoder of compressed SND / W-F payloads (kiwi/client.py:33-87, 461-464, 476-479): n_streams
  * independent streams of n_bytes each (host memory, [n_streams][n_bytes]); state int32 [n_streams][2] =

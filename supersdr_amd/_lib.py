@@ -97,6 +97,7 @@ _SIGS = {
     "ssdr_set_recording": (C.c_int, [_P, C.c_int]),
     "ssdr_playbuffer_mono": (C.c_int, [_P, _P, C.c_int]),
     "ssdr_push_iq_wire": (C.c_int, [_P, _P, C.c_uint32, _P]),
+    "ssdr_wire_gps": (C.c_int, [_P, _P]),
     "ssdr_adpcm_decode": (C.c_int, [_P, _P, C.c_uint32, C.c_uint32, _P, _P]),
     "ssdr_feed_open": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "ssdr_feed_slot": (C.c_int, [_P, C.POINTER(_P)]),

@@ -144,6 +144,8 @@ struct ssdr_ctx {
     uint8_t *d_wire = nullptr;
     size_t wire_frames = 0;
     float *d_wire_rssi = nullptr;
+    uint32_t *d_wire_gps = nullptr;
+    uint32_t wire_run_frames = 0;
 };
 
 static int get_event(ssdr_ctx *c, hipEvent_t *e)
@@ -220,7 +222,7 @@ void ssdr_destroy(ssdr_ctx *c)
     void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_wf_tail, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_flags, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
                     c->d_play_taps, c->d_play_hist, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
-                    c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64};
+                    c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64, c->d_wire_gps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -1005,6 +1007,7 @@ int ssdr_feed_submit(ssdr_ctx *c)
         w.iq = s.d_in;
         w.ch_stride = (uint64_t)nf * SSDR_FRAME;
         w.rssi = s.d_wire_rssi;
+        w.gps = nullptr;
         int rcw;
         if ((rcw = timed_begin(c)) != SSDR_OK) return rcw;
         HIP_TRY(ssdr_launch_iqwire(w, c->stream));
@@ -1621,9 +1624,11 @@ int ssdr_push_iq_wire(ssdr_ctx *c, const uint8_t *bodies, uint32_t n_frames, flo
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_wire) { HIP_TRY(hipFree(c->d_wire)); c->d_wire = nullptr; }
         if (c->d_wire_rssi) { HIP_TRY(hipFree(c->d_wire_rssi)); c->d_wire_rssi = nullptr; }
+        if (c->d_wire_gps) { HIP_TRY(hipFree(c->d_wire_gps)); c->d_wire_gps = nullptr; }
         c->wire_frames = 0;
         HIP_TRY(hipMalloc(&c->d_wire, (size_t)c->n_ch * n_frames * SSDR_WIRE_BODY));
         HIP_TRY(hipMalloc(&c->d_wire_rssi, (size_t)c->n_ch * n_frames * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->d_wire_gps, (size_t)c->n_ch * n_frames * 4 * sizeof(uint32_t)));
         c->wire_frames = n_frames;
     }
     HIP_TRY(hipMemcpyAsync(c->d_wire, bodies, (size_t)c->n_ch * n_frames * SSDR_WIRE_BODY, hipMemcpyHostToDevice, c->stream));
@@ -1634,6 +1639,8 @@ int ssdr_push_iq_wire(ssdr_ctx *c, const uint8_t *bodies, uint32_t n_frames, flo
     a.iq = c->d_iq_own;
     a.ch_stride = (uint64_t)n_frames * SSDR_FRAME;
     a.rssi = c->d_wire_rssi;
+    a.gps = c->d_wire_gps;
+    c->wire_run_frames = n_frames;
     if ((rc = timed_begin(c)) != SSDR_OK) return rc;
     HIP_TRY(ssdr_launch_iqwire(a, c->stream));
     if ((rc = timed_end(c, SSDR_K_WIRE)) != SSDR_OK) return rc;
@@ -1643,6 +1650,16 @@ int ssdr_push_iq_wire(ssdr_ctx *c, const uint8_t *bodies, uint32_t n_frames, flo
     c->d_iq = c->d_iq_own;
     c->in_frames = n_frames;
     c->have_input = true;
+    return SSDR_OK;
+}
+
+int ssdr_wire_gps(ssdr_ctx *c, uint32_t *gps_out)
+{
+    if (!c || !gps_out) return SSDR_EINVAL;
+    if (!c->d_wire_gps || c->wire_run_frames == 0) return SSDR_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(gps_out, c->d_wire_gps, (size_t)c->n_ch * c->wire_run_frames * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
 }
 

@@ -114,6 +114,8 @@ struct SsdrWireArgs {
     uint32_t *iq;                            // [n_ch][ch_stride] dwords
     uint64_t ch_stride;
     float *rssi;                             // [n_ch][n_frames] or null: 0.1*smeter - 127 of each frame header
+    uint32_t *gps;                           // [n_ch][n_frames][4] or null: '<BBII' of the IQ branch (kiwi/client.py:444-445):
+                                             // last_gps_solution, dummy, gpssec, gpsnsec; and the header's flags / seq ride along: see ssdr.h
 };
 
 hipError_t ssdr_launch_db2col(const SsdrDb2colArgs &a, hipStream_t stream);

@@ -302,6 +302,14 @@ __global__ __launch_bounds__(64) void ssdr_iqwire_kernel(SsdrWireArgs a)
         const uint32_t smeter = ((uint32_t)body[5] << 8) | body[6];
         a.rssi[(uint64_t)ch * a.n_frames + f] = 0.1f * (float)smeter - 127.0f;
     }
+    if (l == 1 && a.gps) {                   // the GNSS stamp of the frame: '<BBII' at body[7..16] (unaligned: byte by byte)
+        auto le32 = [&](int o) { return (uint32_t)body[o] | ((uint32_t)body[o + 1] << 8) | ((uint32_t)body[o + 2] << 16) | ((uint32_t)body[o + 3] << 24); };
+        uint32_t *g = a.gps + ((uint64_t)ch * a.n_frames + f) * 4;
+        g[0] = body[7];                      // last_gps_solution
+        g[1] = body[8];                      // dummy
+        g[2] = le32(9);                      // gpssec
+        g[3] = le32(13);                     // gpsnsec
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

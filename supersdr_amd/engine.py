@@ -364,6 +364,13 @@ class SsdrEngine:
         check(lib.ssdr_push_iq_wire(self._ctx, bodies.ctypes.data, self.in_frames, rssi.ctypes.data), "ssdr_push_iq_wire")
         return rssi
 
+    def wire_gps(self):
+        """-> uint32 [n_ch, n_frames, 4]: last_gps_solution, dummy, gpssec, gpsnsec of every frame of the last push_iq_wire
+        (the `gps` dict of kiwi/client.py:444-445)"""
+        out = np.empty((self.n_ch, self.in_frames, 4), np.uint32)
+        check(lib.ssdr_wire_gps(self._ctx, out.ctypes.data), "ssdr_wire_gps")
+        return out
+
     # ---- measurement
     def set_profiling(self, on):
         check(lib.ssdr_set_profiling(self._ctx, int(bool(on))), "ssdr_set_profiling")

@@ -63,6 +63,7 @@ class IQBatcher:
     channel = 0
     last_rssi = -127.0
     last_seq = -1
+    last_gps = None                 # the GNSS stamp of the newest frame, as _process_aud built it (kiwi/client.py:444-445)
     dropped = 0
 
     def attach(self, hub, channel):
@@ -74,7 +75,7 @@ class IQBatcher:
             return
         if self.last_seq >= 0 and seq != ((self.last_seq + 1) & 0xFFFFFFFF):
             self.dropped += 1                       # sequence gap: the hub keeps streaming, history stays continuous
-        self.last_seq, self.last_rssi = seq, rssi
+        self.last_seq, self.last_rssi, self.last_gps = seq, rssi, gps
         z = np.asarray(samples)
         iq = np.empty((len(z), 2), np.int16)
         iq[:, 0] = z.real

@@ -311,7 +311,11 @@ def test_iq_wire_decode_matches_reference_golden(S):
     with S.SsdrEngine(n_ch) as eng:
         rssi = eng.push_iq_wire(bodies)
         back = eng.read_input()
+        gps = eng.wire_gps()
     assert np.array_equal(back.reshape(n_ch, n_frames, 512, 2), iq)
+    # the GNSS stamp of every frame (kiwi/client.py:444-445): the golden frame's is the one the reference decoded
+    assert gps.shape == (n_ch, n_frames, 4) and [int(x) for x in gps[1, 1]] == [1, 0, 5, 6]
+    assert [int(x) for x in gps[0, 0]] == [int(x) for x in g["iq_gps"]]
     assert rssi[0, 0] == np.float32(float(g["iq_rssi"]))
     assert np.allclose(rssi[1:], 0.1 * smeters[1:] - 127, atol=1e-4)
     # complex64 view as the reference builds it

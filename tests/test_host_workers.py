@@ -369,6 +369,8 @@ def test_iq_wire_roundtrip_and_batcher_vs_reference_golden():
     b._process_iq_samples(5, g["iq_complex64"], -40.0, {})     # what the reference hands to the hook
     b._process_iq_samples(7, g["iq_complex64"], -41.0, {})     # a sequence gap
     assert fed[0][0] == 3 and np.array_equal(fed[0][1], g["iq_int16"]) and b.dropped == 1 and b.last_rssi == -41.0
+    b._process_iq_samples(8, g["iq_complex64"], -41.0, {"gpssec": 5, "gpsnsec": 6})
+    assert b.last_gps == {"gpssec": 5, "gpsnsec": 6}                       # the frame's GNSS stamp is kept, not dropped
 
 
 def test_reference_kiwiworker_drives_an_iqbatcher_recorder():
