@@ -51,7 +51,10 @@ enum {
 };
 
 /* demodulator selection: "SET mod=%s" (utils_supersdr.py:1028; kiwi/client.py:217-249) */
-enum { SSDR_MODE_AM = 0, SSDR_MODE_LSB = 1, SSDR_MODE_USB = 2, SSDR_MODE_CW = 3, SSDR_MODE_NBFM = 4 };
+enum { SSDR_MODE_AM = 0, SSDR_MODE_LSB = 1, SSDR_MODE_USB = 2, SSDR_MODE_CW = 3, SSDR_MODE_NBFM = 4,
+       /* "SET mod=iq" (kiwi/client.py:217-249, default passband +-5 kHz): no demodulator -- the channel's tuned, filtered and
+        * gain-controlled complex baseband itself.  The PCM row of such a channel carries I; I,Q pairs: ssdr_audio_iq */
+       SSDR_MODE_IQ = 5 };
 
 /* Per-channel parameters: the reference's a13 parameter surface:
  *   "SET mod=%s low_cut=%d high_cut=%d freq=%.3f"              utils_supersdr.py:1028
@@ -153,6 +156,10 @@ int ssdr_run_audio(ssdr_ctx *ctx, int16_t *pcm_out, float *rssi_out, int out_is_
 /* SND header flags, bit 1 "ADC overflow" (kiwi_sound.adc_overflow_flag, utils_supersdr.py:1066-1067) for every frame of the
  * last ssdr_run_audio: flags_out uint8 [n_ch][n_frames], 1 where a sample of that frame has |I| or |Q| >= 32767. */
 int ssdr_audio_flags(ssdr_ctx *ctx, uint8_t *flags_out, int out_is_device);
+/* The IQ-mode channels' output of the last ssdr_run_audio, as a KiwiSDR sends it in mod=iq SND frames (kiwi/client.py:443-454
+ * before the byte order): iq_out int16 [n_ch][n_frames*512][2] interleaved I,Q = saturate(rint(y g)) of the filtered
+ * baseband y and the AGC gain g.  Rows of channels in other modes are zero.  SSDR_ESTATE if no channel is in IQ mode. */
+int ssdr_audio_iq(ssdr_ctx *ctx, int16_t *iq_out, int out_is_device);
 /* Both stages on the current batch, results kept on the device (ssdr_wf_device / ssdr_audio_device / ssdr_audio_flags): what
  * ssdr_run_wf followed by ssdr_run_audio do.  With ssdr_set_fused(ctx, 1), and when every channel is on the reference's
  * full-band AM passband, N = 1, hop 1024, 12 kHz IQ, an even frame count (the configuration of the metric), ONE kernel

@@ -406,7 +406,8 @@ static const float DC_APOW[8] = { 0x1.fcp-1f, 0x1.f808p-1f, 0x1.f417fp-1f, 0x1.f
 static const float P_FLOOR = 9.5367431640625e-07f;   /* 2^-20 */
 
 static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, const float *taps,
-                        twin_state *st, int16_t *hist /*[HIST][2]*/, int16_t *pcm, float *rssi, uint8_t *flag)
+                        twin_state *st, int16_t *hist /*[HIST][2]*/, int16_t *pcm, float *rssi, uint8_t *flag,
+                        int16_t *iq_out /*[512][2] or NULL: mode 5, I,Q of the filtered baseband under the AGC gain*/)
 {
     static _Thread_local float z1r[HIST + FRAME * 4], z1i[HIST + FRAME * 4];
     float z2r[FRAME], z2i[FRAME], p[FRAME], aud[FRAME];
@@ -513,6 +514,8 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
                 co = cn; si = sn;
             }
         }
+    } else if (c->mode == 5) {                       /* "iq": no demodulator, the PCM row carries I */
+        for (int n = 0; n < FRAME; n++) aud[n] = z2r[n];
     } else {
         float pr = st->prev_re, pi = st->prev_im;
         for (int n = 0; n < FRAME; n++) {
@@ -559,6 +562,12 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
             float y = rintf(aud[8 * l + j] * g);
             y = fminf(fmaxf(y, -32768.0f), 32767.0f);
             pcm[8 * l + j] = (int16_t)(int32_t)y;
+            if (iq_out && c->mode == 5) {
+                float q = rintf(z2i[8 * l + j] * g);
+                q = fminf(fmaxf(q, -32768.0f), 32767.0f);
+                iq_out[2 * (8 * l + j)] = pcm[8 * l + j];
+                iq_out[2 * (8 * l + j) + 1] = (int16_t)(int32_t)q;
+            }
         }
     }
     /* 5. rssi: inclusive sum scan over lanes (same six steps), total = lane 63 */
@@ -580,8 +589,9 @@ static void audio_frame(const int16_t *iq /*[512][2]*/, const twin_consts *c, co
 
 /* batch: iq[n_ch][n_frames*512][2]; consts[n_ch]; taps[n_ch][128]; state[n_ch]; hist[n_ch][128][2]
  * -> pcm[n_ch][n_frames*512], rssi[n_ch][n_frames]; state and hist updated in place. */
-void twin_audio2(const int16_t *iq, uint32_t n_ch, uint32_t n_frames, const twin_consts *consts,
-                 const float *taps, twin_state *state, int16_t *hist, int16_t *pcm, float *rssi, uint8_t *flags)
+void twin_audio3(const int16_t *iq, uint32_t n_ch, uint32_t n_frames, const twin_consts *consts,
+                 const float *taps, twin_state *state, int16_t *hist, int16_t *pcm, float *rssi, uint8_t *flags,
+                 int16_t *iq_out /*[n_ch][n_frames*512][2] or NULL; rows of channels not in mode 5 are left alone*/)
 {
     uint8_t dummy;
     const size_t D = consts[0].decim > 1 ? consts[0].decim : 1;     /* one input rate per batch */
@@ -590,7 +600,14 @@ void twin_audio2(const int16_t *iq, uint32_t n_ch, uint32_t n_frames, const twin
             audio_frame(iq + ((size_t)c * n_frames + f) * FRAME * D * 2, consts + c,
                         taps + (size_t)c * NTAP_MAX, state + c, hist + (size_t)c * HIST * 2,
                         pcm + ((size_t)c * n_frames + f) * FRAME, rssi + (size_t)c * n_frames + f,
-                        flags ? flags + (size_t)c * n_frames + f : &dummy);
+                        flags ? flags + (size_t)c * n_frames + f : &dummy,
+                        iq_out ? iq_out + ((size_t)c * n_frames + f) * FRAME * 2 : NULL);
+}
+
+void twin_audio2(const int16_t *iq, uint32_t n_ch, uint32_t n_frames, const twin_consts *consts,
+                 const float *taps, twin_state *state, int16_t *hist, int16_t *pcm, float *rssi, uint8_t *flags)
+{
+    twin_audio3(iq, n_ch, n_frames, consts, taps, state, hist, pcm, rssi, flags, NULL);
 }
 
 void twin_audio(const int16_t *iq, uint32_t n_ch, uint32_t n_frames, const twin_consts *consts,

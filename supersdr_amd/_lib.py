@@ -11,8 +11,8 @@ LIB_PATH = os.environ.get("SSDR_LIB_PATH") or os.path.join(_HERE, "libssdr.so") 
 
 NFFT, FRAME, RATE, NTAP_MAX, HIST = 1024, 512, 12000, 128, 128
 OK, EINVAL, ENOMEM, EHIP, ENODEV, ESTATE = 0, -1, -2, -3, -4, -5
-MODE_AM, MODE_LSB, MODE_USB, MODE_CW, MODE_NBFM = range(5)
-MODE_BY_NAME = {"am": 0, "lsb": 1, "usb": 2, "cw": 3, "nbfm": 4, "nfm": 4}
+MODE_AM, MODE_LSB, MODE_USB, MODE_CW, MODE_NBFM, MODE_IQ = range(6)
+MODE_BY_NAME = {"am": 0, "lsb": 1, "usb": 2, "cw": 3, "nbfm": 4, "nfm": 4, "iq": 5}
 K_WF, K_AUDIO, K_SYNTH, K_DB2COL, K_PLAY, K_WIRE, K_TRACE, K_SMETER, K_FUSED = range(9)
 T_WINDOW, T_TWIDDLE_RE, T_TWIDDLE_IM, T_DB_THRESH = range(4)
 
@@ -82,6 +82,7 @@ _SIGS = {
     "ssdr_run_wf": (C.c_int, [_P, _P, C.POINTER(C.c_uint32), C.c_int]),
     "ssdr_run_audio": (C.c_int, [_P, _P, _P, C.c_int]),
     "ssdr_audio_flags": (C.c_int, [_P, _P, C.c_int]),
+    "ssdr_audio_iq": (C.c_int, [_P, _P, C.c_int]),
     "ssdr_run_chain": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "ssdr_set_fused": (C.c_int, [_P, C.c_int]),
     "ssdr_sync": (C.c_int, [_P]),

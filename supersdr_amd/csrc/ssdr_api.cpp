@@ -72,6 +72,9 @@ struct ssdr_ctx {
     int16_t *d_pcm = nullptr;
     float *d_rssi = nullptr;
     size_t audio_frames = 0;
+    uint32_t *d_iq_out = nullptr;             // [n_ch][n_frames*512] I | Q << 16 of the channels in SSDR_MODE_IQ (allocated when one exists)
+    size_t iq_out_frames = 0;
+    bool iq_out_valid = false;
     uint8_t *d_flags = nullptr;               // ADC-overflow flag per frame of the last audio run
     size_t flags_frames = 0;
     uint32_t audio_run_frames = 0;            // frames the last audio run (or ssdr_set_pcm) produced: extent and stride of d_pcm / d_rssi
@@ -222,7 +225,7 @@ void ssdr_destroy(ssdr_ctx *c)
     void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_wf_tail, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_flags, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
                     c->d_play_taps, c->d_play_hist, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
-                    c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64, c->d_wire_gps};
+                    c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64, c->d_wire_gps, c->d_iq_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -243,7 +246,7 @@ void ssdr_destroy(ssdr_ctx *c)
 
 int ssdr_default_params(int mode, ssdr_chan_params *p)
 {
-    if (!p || mode < SSDR_MODE_AM || mode > SSDR_MODE_NBFM) return SSDR_EINVAL;
+    if (!p || mode < SSDR_MODE_AM || mode > SSDR_MODE_IQ) return SSDR_EINVAL;
     memset(p, 0, sizeof *p);
     p->mode = mode;
     p->agc_on = 1;                    // utils_supersdr.py:937
@@ -259,6 +262,7 @@ int ssdr_default_params(int mode, ssdr_chan_params *p)
     case SSDR_MODE_LSB: p->low_cut = -3000.0; p->high_cut = -30.0; break;
     case SSDR_MODE_USB: p->low_cut = 30.0; p->high_cut = 3000.0; break;
     case SSDR_MODE_CW: p->low_cut = 400.0; p->high_cut = 800.0; break;
+    case SSDR_MODE_IQ: p->low_cut = -5000.0; p->high_cut = 5000.0; break;       // kiwi/client.py:244-246
     default: p->low_cut = -6000.0; p->high_cut = 6000.0; break;
     }
     return SSDR_OK;
@@ -738,6 +742,24 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
     a.pcm = c->d_pcm;
     a.rssi = c->d_rssi;
     a.flags = c->d_flags;
+    a.iq_out = nullptr;
+    c->iq_out_valid = false;
+    {
+        bool any_iq = false;
+        for (uint32_t ch = 0; ch < c->n_ch && !any_iq; ch++) any_iq = c->h_consts[ch].mode == SSDR_MODE_IQ;
+        if (any_iq && c->feed.empty()) {          // (the pipelined feed hands out PCM rows only: an IQ channel's row carries I)
+            if (c->iq_out_frames < c->in_frames) {
+                HIP_TRY(hipStreamSynchronize(c->stream));
+                if (c->d_iq_out) { HIP_TRY(hipFree(c->d_iq_out)); c->d_iq_out = nullptr; }
+                c->iq_out_frames = 0;
+                HIP_TRY(hipMalloc(&c->d_iq_out, (size_t)c->n_ch * c->in_frames * SSDR_FRAME * 4));
+                c->iq_out_frames = c->in_frames;
+            }
+            HIP_TRY(hipMemsetAsync(c->d_iq_out, 0, (size_t)c->n_ch * c->in_frames * SSDR_FRAME * 4, c->stream));   // rows of the other modes
+            a.iq_out = c->d_iq_out;
+            c->iq_out_valid = true;
+        }
+    }
     int rc;
     hipStream_t s = c->stream;
     if (c->concurrent) {
@@ -847,6 +869,18 @@ int ssdr_audio_paths(ssdr_ctx *c, uint32_t counts[3])
     if (!c || !counts) return SSDR_EINVAL;
     for (int p = 0; p < SSDR_PATH_COUNT; p++) counts[p] = 0;
     for (uint32_t ch = 0; ch < c->n_ch; ch++) counts[ssdr_audio_path(c->h_consts[ch])]++;
+    return SSDR_OK;
+}
+
+int ssdr_audio_iq(ssdr_ctx *c, int16_t *iq_out, int out_is_device)
+{
+    if (!c || !iq_out) return SSDR_EINVAL;
+    if (!c->iq_out_valid || !c->d_iq_out || c->audio_run_frames == 0) return SSDR_ESTATE;
+    HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
+    HIP_TRY(hipMemcpyAsync(iq_out, c->d_iq_out, (size_t)c->n_ch * c->audio_run_frames * SSDR_FRAME * 4,
+                           out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    if (!out_is_device) HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
 }
 
@@ -1246,7 +1280,7 @@ int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob, uint64_t bytes)
         const ssdr_chan_consts *k = reinterpret_cast<const ssdr_chan_consts *>(static_cast<const char *>(blob) + sizeof h);
         for (uint32_t i = 0; i < c->n_ch; i++) {
             const uint32_t kd = k[i].decim > 1 ? k[i].decim : 1;
-            if (k[i].mode > SSDR_MODE_NBFM || k[i].ntap > SSDR_NTAP_MAX || k[i].ntap8 > SSDR_NTAP_MAX || (k[i].ntap8 & 7u) ||
+            if (k[i].mode > SSDR_MODE_IQ || k[i].ntap > SSDR_NTAP_MAX || k[i].ntap8 > SSDR_NTAP_MAX || (k[i].ntap8 & 7u) ||
                 k[i].ntap8 * kd > SSDR_NTAP_MAX || kd != h.decim || k[i].hang_frames > 8 ||
                 (h.decim > 1 && (k[i].fir_flags & SSDR_FIR_DELAY4)))
                 return SSDR_EINVAL;

@@ -158,6 +158,7 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
 #endif
         const uint32_t rw[8] = {raw0.x, raw0.y, raw0.z, raw0.w, raw1.x, raw1.y, raw1.z, raw1.w};
         float p[8], aud[8];
+        float yr[8], yi[8];                                 // the channel filter's output (unused on the full-band AM path)
         bool clip;
 
         if constexpr (PATH == PATH_AM_RAW) {
@@ -178,7 +179,6 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
             clip = trig ? wave_any(raw_clipped(rw)) : false;
             demod_am<true>(p, dc, aud);
         } else {
-            float yr[8], yi[8];
             float amax = 0.0f;
             float2 A[8], B[8];
             if (untuned) {
@@ -283,7 +283,11 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
                 nco_block(n2, f, b2c, b2s);
                 demod_ssb(yr, yi, b2c, b2s, cs2, ss2, aud);
             }
-            else demod_fm(yr, yi, prev_re, prev_im, kc.kfm, aud);
+            else if (mode == SSDR_MODE_NBFM) demod_fm(yr, yi, prev_re, prev_im, kc.kfm, aud);
+            else {                                          // SSDR_MODE_IQ: no demodulator, the PCM row carries I
+#pragma unroll
+                for (int j = 0; j < 8; j++) aud[j] = yr[j];
+            }
             // the filter output is an fma chain that ends in "+ 0": a -0 can only come out of the shift path
             prev_re = lane63(yr[7]);
             prev_im = lane63(yi[7]);
@@ -291,7 +295,11 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
         }
 
         // 4./5. AGC, pack, store; 6. RSSI and overflow flag
-        agc_pack_store(p, aud, l, agc, agc_d, agc_m, dst);
+        const float g = agc_pack_store(p, aud, l, agc, agc_d, agc_m, dst);
+        if constexpr (PATH == PATH_GENERAL) {
+            if (mode == SSDR_MODE_IQ && a.iq_out)           // wave-uniform: I,Q pairs of the filtered baseband under the same gain
+                iq_pack_store(yr, yi, g, a.iq_out + ((uint64_t)ch * a.n_frames + f) * SSDR_FRAME + 8 * l);
+        }
         rssi_flag_step(p, clip, f, a.n_frames, l, cal, rssi_sum, flag_keep, rssi_row, flag_row);
 
         // 7. carry: phases advance one frame; the frame tail becomes the FIR history
@@ -460,10 +468,15 @@ SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, cons
                 float b2c, b2s;
                 nco_block(n2, f, b2c, b2s);
                 demod_ssb(yr, yi, b2c, b2s, cs2, ss2, aud);
-            } else demod_fm(yr, yi, prev_re, prev_im, kc.kfm, aud);
+            } else if (mode == SSDR_MODE_NBFM) demod_fm(yr, yi, prev_re, prev_im, kc.kfm, aud);
+            else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) aud[j] = yr[j];
+            }
             prev_re = lane63(yr[7]);
             prev_im = lane63(yi[7]);
-            agc_pack_store(p, aud, l, agc, agc_d, agc_m, dst);
+            const float g = agc_pack_store(p, aud, l, agc, agc_d, agc_m, dst);
+            if (mode == SSDR_MODE_IQ && a.iq_out) iq_pack_store(yr, yi, g, a.iq_out + ((uint64_t)ch * a.n_frames + f) * SSDR_FRAME + 8 * l);
             rssi_flag_step(p, clip, f, a.n_frames, l, cal, rssi_sum, flag_keep, rssi_row, flag_row);
         }
         phi1 += (uint32_t)(SSDR_FRAME * D) * dphi1;

@@ -238,8 +238,8 @@ SSDR_DEV void demod_fm(const float (&yr)[8], const float (&yi)[8], float prev_re
 }
 
 // AGC (block peak -> log2 -> (max,+) follower across lanes -> gain), round-half-even, saturate, pack, store
-SSDR_DEV void agc_pack_store(const float (&p)[8], const float (&aud)[8], int l, const AgcK &k, float &agc_d,
-                             float (&agc_m)[8], int16_t *dst)
+SSDR_DEV float agc_pack_store(const float (&p)[8], const float (&aud)[8], int l, const AgcK &k, float &agc_d,
+                              float (&agc_m)[8], int16_t *dst)
 {
     // max of the eight powers and the floor in four three-input maxima (max is exact: any grouping gives the same value)
     const float pm = vmax3(vmax3(vmax3(p[0], p[1], p[2]), p[3], p[4]), vmax3(p[5], p[6], p[7]), SSDR_P_FLOOR);
@@ -272,6 +272,20 @@ SSDR_DEV void agc_pack_store(const float (&p)[8], const float (&aud)[8], int l, 
         w[j >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(i0, i1));
     }
     __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(dst));
+    return g;
+}
+
+// SSDR_MODE_IQ: the lane's eight filtered samples times the AGC gain as I | Q << 16 (round-half-even, saturating), 32 B per lane
+SSDR_DEV void iq_pack_store(const float (&yr)[8], const float (&yi)[8], float g, uint32_t *dst)
+{
+    u32x4 w0, w1;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t v = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(__float2int_rn(yr[j] * g), __float2int_rn(yi[j] * g)));
+        if (j < 4) w0[j] = v; else w1[j - 4] = v;
+    }
+    __builtin_nontemporal_store(w0, reinterpret_cast<u32x4 *>(dst));
+    __builtin_nontemporal_store(w1, reinterpret_cast<u32x4 *>(dst) + 1);
 }
 
 // Per-frame RSSI (sum over the frame = last lane of the inclusive sum scan) and ADC-overflow flag.  Lane (f mod 64)

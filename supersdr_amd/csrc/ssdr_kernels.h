@@ -53,6 +53,7 @@ struct SsdrAudioArgs {
     int16_t *pcm;                            // [n_ch][n_frames*512]
     float *rssi;                             // [n_ch][n_frames]
     uint8_t *flags;                          // [n_ch][n_frames] ADC overflow per frame
+    uint32_t *iq_out;                        // [n_ch][n_frames*512] I | Q << 16 of channels in SSDR_MODE_IQ, or null
     const uint32_t *chan_list;               // channels of this launch (one frame path), list_n of them
     uint32_t list_n;
 };
@@ -60,7 +61,7 @@ struct SsdrAudioArgs {
 enum { SSDR_PATH_GENERAL = 0, SSDR_PATH_DELAY4 = 1, SSDR_PATH_AM_RAW = 2, SSDR_PATH_COUNT = 3 };
 static inline int ssdr_audio_path(const ssdr_chan_consts &k)
 {
-    if (!(k.fir_flags & SSDR_FIR_DELAY4)) return SSDR_PATH_GENERAL;
+    if (!(k.fir_flags & SSDR_FIR_DELAY4) || k.mode == SSDR_MODE_IQ) return SSDR_PATH_GENERAL;
     return k.mode == SSDR_MODE_AM ? SSDR_PATH_AM_RAW : SSDR_PATH_DELAY4;
 }
 

@@ -116,7 +116,7 @@ static uint32_t dphi_at(double f_hz, double fs)
 int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps, uint32_t decim, uint32_t rate_hz)
 {
     if (!p || !c || !taps) return SSDR_EINVAL;
-    if (p->mode < SSDR_MODE_AM || p->mode > SSDR_MODE_NBFM) return SSDR_EINVAL;
+    if (p->mode < SSDR_MODE_AM || p->mode > SSDR_MODE_IQ) return SSDR_EINVAL;
     if (decim != 1 && decim != 2 && decim != 4) return SSDR_EINVAL;
     if (rate_hz != SSDR_RATE && rate_hz != SSDR_RATE_WIDE) return SSDR_EINVAL;
     const double rate = (double)rate_hz;
@@ -163,7 +163,7 @@ int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, flo
     {
         int nz = 0;
         for (int i = 0; i < ntap; i++) nz += (taps[i] != 0.0f);
-        c->fir_flags = (nz == 1 && ntap > 4 && taps[4] == 1.0f) ? SSDR_FIR_DELAY4 : 0u;
+        c->fir_flags = (nz == 1 && ntap > 4 && taps[4] == 1.0f && p->mode != SSDR_MODE_IQ) ? SSDR_FIR_DELAY4 : 0u;
     }
     c->dphi1 = dphi_at(p->f_shift_hz + f_bc, fs_in);            // the mixer runs at the input rate,
     c->dphi2 = dphi_of(f_bc, rate);                             // the SSB re-mixer at the output rate

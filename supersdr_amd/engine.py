@@ -187,6 +187,12 @@ class SsdrEngine:
         check(lib.ssdr_audio_flags(self._ctx, out.ctypes.data, 0), "ssdr_audio_flags")
         return out
 
+    def audio_iq(self):
+        """-> int16 [n_ch, n_frames*512, 2]: I,Q of the channels in "iq" mode for the last run_audio (rows of other modes: 0)"""
+        out = np.empty((self.n_ch, self.audio_frames * L.FRAME, 2), np.int16)
+        check(lib.ssdr_audio_iq(self._ctx, out.ctypes.data, 0), "ssdr_audio_iq")
+        return out
+
     def sync(self):
         check(lib.ssdr_sync(self._ctx), "ssdr_sync")
 

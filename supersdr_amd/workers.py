@@ -50,6 +50,7 @@ class Frame(np.ndarray):
     fields.  A frame that is dropped (late stream) takes its blocks with it -- nothing is keyed on the side."""
     play_block = None
     rec_block = None
+    iq_block = None                     # "SET mod=iq": int16 [512, 2] I,Q of the frame (the PCM samples are its I column)
     adc_overflow = False
     rssi = -127.0
 
@@ -57,9 +58,10 @@ class Frame(np.ndarray):
         pass
 
     @classmethod
-    def make(cls, pcm, rssi, play_block=None, rec_block=None, adc_overflow=False):
+    def make(cls, pcm, rssi, play_block=None, rec_block=None, adc_overflow=False, iq_block=None):
         f = np.array(pcm, np.int16).view(cls)
         f.rssi, f.play_block, f.rec_block, f.adc_overflow = float(rssi), play_block, rec_block, bool(adc_overflow)
+        f.iq_block = iq_block
         return f
 
 
@@ -223,6 +225,7 @@ class IQHub:
             color = eng.run_db2col(chans, len(wf))    # [lines, n_ch, 1024] float32 0..254
         pcm, rssi = eng.run_audio()                   # [n_ch, 1024], [n_ch, 2]
         flags = eng.audio_flags()                     # [n_ch, 2] SND header bit 1 (utils_supersdr.py:1066-1067)
+        iqo = eng.audio_iq() if any(p.mode == L.MODE_IQ for p in self._params) else None     # channels in "SET mod=iq"
         play = mono = None
         if self.gpu_post and any(s is not None for s in self.snd_clients):
             rec = self._sync_recording()
@@ -230,9 +233,9 @@ class IQHub:
             if rec:
                 mono = eng.playbuffer_mono()
         self.superframes += 1
-        self._hand_out(wf, n_avg, color, chans, pcm, rssi, flags, play, mono)
+        self._hand_out(wf, n_avg, color, chans, pcm, rssi, flags, play, mono, iqo)
 
-    def _hand_out(self, wf, n_avg, color, chans, pcm, rssi, flags, play, mono):
+    def _hand_out(self, wf, n_avg, color, chans, pcm, rssi, flags, play, mono, iqo=None):
         P = self.play_len
         for c in range(self.n_ch):
             for i, line in enumerate(wf):
@@ -245,7 +248,8 @@ class IQHub:
                 _put_drop_oldest(self.snd_queue[c], Frame.make(
                     pcm[c, f * L.FRAME:(f + 1) * L.FRAME], rssi[c, f],
                     play[c, f * P:(f + 1) * P].copy() if play is not None else None,
-                    mono[c, f * P:(f + 1) * P].copy() if mono is not None else None, flags[c, f]))
+                    mono[c, f * P:(f + 1) * P].copy() if mono is not None else None, flags[c, f],
+                    iqo[c, f * L.FRAME:(f + 1) * L.FRAME].copy() if iqo is not None and self._params[c].mode == L.MODE_IQ else None))
 
     def _run_pipelined(self):
         eng = self.engine
@@ -349,7 +353,8 @@ class GpuStream:
         "SET agc=%d hang=%d thresh=%d slope=%d decay=%d manGain=%d"      :979, 1023
     "SET zoom=%d start=%d" (:741, 839) is remembered (`zoom`, `start`); the rest (auth, keepalive, compression, ...)
     has no meaning without a server and is accepted.  A modulation without a demodulator here, or a frequency outside
-    the channel's IQ band, raises ValueError instead of being demodulated as something else.
+    the channel's IQ band, raises ValueError instead of being demodulated as something else.  "SET mod=iq" selects the
+    channel's filtered baseband itself (SSDR_MODE_IQ): its SND frames then carry I,Q pairs behind a GNSS stamp.
 
     receive_message(): server -> client frames, byte for byte in the wire format the reference parses
     (utils_supersdr.py:782-784, 1065-1074): first what the constructors wait for ("MSG audio_init audio_rate= sample_rate=",
@@ -390,8 +395,8 @@ class GpuStream:
 
     def _retune(self, kv):
         mode = kv["mod"].lower()
-        if mode not in L.MODE_BY_NAME:               # "SET mod=iq" and friends have no demodulator here: say so
-            raise ValueError("radio_mode %r has no demodulator on the GPU path (am, lsb, usb, cw, nbfm)" % (kv["mod"],))
+        if mode not in L.MODE_BY_NAME:               # "SET mod=sam", "drm", ... have no demodulator here: say so
+            raise ValueError("radio_mode %r has no demodulator on the GPU path (am, lsb, usb, cw, nbfm, iq)" % (kv["mod"],))
         freq = float(kv.get("freq", self.center_khz))
         f_shift = (freq - self.center_khz) * 1000.0
         rate = float(getattr(self.hub, "kiwi_rate", L.RATE))
@@ -412,6 +417,8 @@ class GpuStream:
         try:
             if self.kind == "SND":
                 f = self.hub.snd_queue[self.channel].get(timeout=self.timeout)
+                if f.iq_block is not None:           # the channel is in "SET mod=iq": I,Q pairs behind a GNSS stamp
+                    return snd_iq_frame(f.iq_block, f.rssi, self._next_seq(), adc_overflow=f.adc_overflow)
                 return snd_frame(f, f.rssi, self._next_seq(), adc_overflow=f.adc_overflow)
             while True:                              # a line summed for some client's N > 1 is not a wire line: skip it
                 line, n, _ = self.hub.wf_queue[self.channel].get(timeout=self.timeout)
@@ -439,6 +446,14 @@ def snd_frame(pcm, rssi, seq=0, adc_overflow=False):
     smeter = int(min(max(round((float(rssi) + 127.0) * 10.0), 0), 65535))
     return bytearray(b"SND" + struct.pack("<BI", 2 if adc_overflow else 0, seq) + struct.pack(">H", smeter) +
                      np.asarray(pcm, np.int16).astype(">i2").tobytes())
+
+
+def snd_iq_frame(iq, rssi, seq=0, adc_overflow=False, gps=(0, 0, 0, 0)):
+    """One SND message in IQ mode: the same 7-byte header, '<BBII' last_gps_solution, dummy, gpssec, gpsnsec, then big-endian
+    int16 I0, Q0, I1, Q1, ... (kiwi/client.py:443-454)"""
+    smeter = int(min(max(round((float(rssi) + 127.0) * 10.0), 0), 65535))
+    return bytearray(b"SND" + struct.pack("<BI", 2 if adc_overflow else 0, seq) + struct.pack(">H", smeter) +
+                     struct.pack("<BBII", *gps) + np.asarray(iq, np.int16).astype(">i2").tobytes())
 
 
 def _copy_params(p, **over):

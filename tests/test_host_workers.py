@@ -84,8 +84,12 @@ class TwinEngine:
         return self.last_wf
 
     def run_audio(self):
-        self.pcm, rssi, self.flags = self.twin.audio(self.iq, self.consts, self.taps, self.state, self.hist, want_flags=True)
+        self.pcm, rssi, self.flags, self.iqo = self.twin.audio(self.iq, self.consts, self.taps, self.state, self.hist,
+                                                               want_flags=True, want_iq=True)
         return self.pcm, rssi
+
+    def audio_iq(self):
+        return self.iqo
 
     def audio_flags(self):
         return self.flags
@@ -563,7 +567,7 @@ def test_adc_overflow_flag_drift_skip_and_recording_branch(gpu, tmp_path, monkey
 def test_unknown_mode_and_out_of_band_tuning_are_errors(gpu):
     hub, wf, snd = make_pair(gpu, n_ch=1, channel=0)
     n0 = len(hub.engine.param_log)
-    snd.radio_mode = "IQ"
+    snd.radio_mode = "SAM"
     with pytest.raises(ValueError, match="no demodulator"):
         snd.set_mode_freq_pb()
     snd.radio_mode = "AM"
@@ -637,3 +641,45 @@ def test_a_stalled_receiver_does_not_freeze_the_hub_and_backlogs_are_bounded():
     hub2 = IQHub(2, engine=TwinEngine(2), gpu_post=False, backlog_superframes=4, stall_superframes=100)
     hub2.feed(0, iq[0])
     assert hub2._ring.shape[1] == 4 * 1024 and hub2.dropped[0] == 8 * 1024 and hub2.superframes == 0
+
+
+def test_mod_iq_frames_reach_a_kiwiclient_through_the_gpu_stream():
+    """"SET mod=iq" (kiwi/client.py:217-249): the channel's filtered, gain-controlled baseband as I,Q pairs.  The GpuStream
+    builds mod=iq SND frames from them, and the reference's own KiwiSDRStream._process_aud decodes those into exactly the
+    complex samples (and the GNSS dict) its _process_iq_samples hook expects."""
+    from supersdr_amd.workers import IQHub, GpuStream
+    from supersdr_amd import _lib as L
+    hub = IQHub(2, engine=TwinEngine(2), gpu_post=False)
+    iq = O.synth_iq(2, 2 * 1024, seed=33, modes=[1, 1])
+    st0 = GpuStream(hub, 0, "SND", 7100.0, timeout=0.2)
+    st0.send_message("SET mod=iq low_cut=-5000 high_cut=5000 freq=7100.500")
+    assert hub.params(0).mode == L.MODE_IQ and hub.params(1).mode == L.MODE_AM
+    for c in range(2):
+        hub.feed(c, iq[c])
+    eng = hub.engine
+    st, hist = twinlib.fresh_state(eng.consts)
+    pcm_t, rssi_t, iq_t = twinlib.load().audio(iq, eng.consts, eng.taps, st, hist, want_iq=True)
+    assert np.array_equal(iq_t[0, :, 0], pcm_t[0]) and (iq_t[1] == 0).all() and np.abs(iq_t[0, :, 1]).max() > 1000
+    st0.receive_message(), st0.receive_message()                          # the greeting
+    frames = [st0.receive_message() for _ in range(4)]
+    assert all(len(f) == 3 + 7 + 10 + 2048 for f in frames)
+    if refload.available():
+        _, _, KC = refload.load()
+        got = []
+
+        class Rec(KC.KiwiSDRStream):
+            def _process_iq_samples(self, seq, samples, rssi, gps):
+                got.append((seq, samples.copy(), rssi, gps))
+
+        r = Rec()
+        r._options = types.SimpleNamespace(ADC_OV=False, S_meter=-1, sdt=0, sound=True, raw=False, tstamp=False, stats=False)
+        r._modulation, r._s_meter_valid, r._compression = "iq", True, False
+        for f in frames:
+            r._process_aud(f[3:])
+        z = np.concatenate([g[1] for g in got])
+        assert np.array_equal(z.real, iq_t[0, :, 0].astype(np.float32)) and np.array_equal(z.imag, iq_t[0, :, 1].astype(np.float32))
+        assert set(got[0][3]) == {"last_gps_solution", "dummy", "gpssec", "gpsnsec"} and [g[0] for g in got] == [1, 2, 3, 4]
+    # the other channel keeps sending ordinary PCM frames
+    st1 = GpuStream(hub, 1, "SND", 7100.0, timeout=0.2)
+    st1.receive_message(), st1.receive_message()
+    assert len(st1.receive_message()) == 3 + 7 + 1024

@@ -27,6 +27,7 @@ class Twin:
         lib.twin_wf_lines.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, P, P, P, P, P, P]
         lib.twin_audio.argtypes = [P, C.c_uint32, C.c_uint32, P, P, P, P, P, P]
         lib.twin_audio2.argtypes = [P, C.c_uint32, C.c_uint32, P, P, P, P, P, P, P]
+        lib.twin_audio3.argtypes = [P, C.c_uint32, C.c_uint32, P, P, P, P, P, P, P, P]
         lib.twin_quantise.argtypes = [C.c_float, P]
         lib.twin_quantise.restype = C.c_int
         for f in ("twin_log2p", "twin_exp2p"):
@@ -66,8 +67,9 @@ class Twin:
         L = n_lines // n_avg
         return b[: L * n_avg].astype(np.int16).reshape(L, n_avg, n_ch, 1024).sum(axis=1).astype(np.int16)
 
-    def audio(self, iq, consts, taps, state, hist, want_flags=False):
-        """iq int16[n_ch, n_frames*512, 2]; state/hist updated in place -> (pcm, rssi[, adc-overflow flags uint8])"""
+    def audio(self, iq, consts, taps, state, hist, want_flags=False, want_iq=False):
+        """iq int16[n_ch, n_frames*512, 2]; state/hist updated in place -> (pcm, rssi[, adc-overflow flags uint8][, iq_out
+        int16 [n_ch, n_frames*512, 2]: I,Q of the channels in mode 5, zero elsewhere])"""
         iq = np.ascontiguousarray(iq, np.int16)
         consts = np.ascontiguousarray(consts, CONSTS_DTYPE)
         n_ch, n_frames = iq.shape[0], iq.shape[1] // (512 * max(1, int(consts["decim"][0])))
@@ -76,9 +78,12 @@ class Twin:
         pcm = np.zeros((n_ch, n_frames * 512), np.int16)
         rssi = np.zeros((n_ch, n_frames), np.float32)
         flags = np.zeros((n_ch, n_frames), np.uint8)
-        self.lib.twin_audio2(iq.ctypes.data, n_ch, n_frames, consts.ctypes.data, taps.ctypes.data,
-                             state.ctypes.data, hist.ctypes.data, pcm.ctypes.data, rssi.ctypes.data, flags.ctypes.data)
-        return (pcm, rssi, flags) if want_flags else (pcm, rssi)
+        iqo = np.zeros((n_ch, n_frames * 512, 2), np.int16)
+        self.lib.twin_audio3(iq.ctypes.data, n_ch, n_frames, consts.ctypes.data, taps.ctypes.data,
+                             state.ctypes.data, hist.ctypes.data, pcm.ctypes.data, rssi.ctypes.data, flags.ctypes.data,
+                             iqo.ctypes.data)
+        out = (pcm, rssi) + ((flags,) if want_flags else ()) + ((iqo,) if want_iq else ())
+        return out
 
     def phasor32(self, ph):
         c, s = C.c_float(), C.c_float()
