@@ -139,6 +139,8 @@ class IQHub:
         return self._params[channel]
 
     def set_params(self, channel, p):
+        if self.pipeline and p.mode == L.MODE_IQ:    # the feed's slots hand out PCM rows only (an IQ channel's row carries I)
+            raise ValueError("mod=iq needs the synchronous hub: the pipelined feed does not return I,Q pairs")
         with self._lock:
             self.engine.set_params(channel, [p])     # raises for parameters the library refuses; the old ones stay
             self._params[channel] = p
