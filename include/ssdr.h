@@ -134,6 +134,19 @@ int ssdr_compile_params_decim(const ssdr_chan_params *p, uint32_t decim, ssdr_ch
  * previous batch (silence after ssdr_create / ssdr_set_hop).  A change restarts the averaging group. */
 int ssdr_set_hop(ssdr_ctx *ctx, uint32_t hop);
 
+/* Waterfall zoom: "SET zoom=%d start=%d" (utils_supersdr.py:741, 753-758, 839) -- a span narrower than the IQ band.  The
+ * server zooms with a DDC in front of its FFT; here a zoom stage sits in front of the waterfall kernel: per channel the
+ * input stream is mixed down by its zoom centre (offset_hz from the IQ band's centre, 32-bit phase accumulator), low-pass
+ * filtered with the reference's tap formula (utils_supersdr.py:334-344: cut-off = the new Nyquist rate/(2 Z), 32 Z - 1 taps)
+ * and decimated by Z to int16 I,Q (round-half-even, saturating) -- a stream at 1/Z of the input rate whose 1024-sample lines
+ * span 1/Z of the band around offset_hz.  zoom Z in {1, 2, 4, 8} is ctx-wide (every channel's lines keep the same cadence:
+ * one per 1024 Z input samples, or per 512 Z at hop 512), the centre is per channel.  A batch must then hold a whole
+ * number of lines (SSDR_EINVAL otherwise).  Changing Z or a centre restarts that stream (phase, filter history, averaging
+ * group).  The audio chain is not affected.  ssdr_read_zoom returns the zoomed I,Q of the last ssdr_run_wf (tests). */
+int ssdr_set_wf_zoom(ssdr_ctx *ctx, uint32_t zoom);
+int ssdr_set_wf_center(ssdr_ctx *ctx, uint32_t first, uint32_t count, const double *offset_hz);
+int ssdr_read_zoom(ssdr_ctx *ctx, uint32_t first, uint32_t count, int16_t *iq_out /*[count][n_in/Z][2]*/, uint32_t *samples_per_channel);
+
 /* Exact bins.  The waterfall kernel computes in float32; ~3e-4 of its bins, those whose |X| lies within the fp32 FFT's rounding
  * error of a 1-dB threshold, land one step away from where the float64 definition (oracle/ssdr_oracle.py: NumPy float64
  * FFT) puts them.  on = 1: ssdr_run_wf evaluates the stage in float64 instead (same window table, same thresholds) and
@@ -321,7 +334,7 @@ int ssdr_set_profiling(ssdr_ctx *ctx, int on);                  /* HIP-event pai
 /* bit 0: run the audio stage on a second stream beside the waterfall kernel (which then takes one workgroup per CU);
  * bit 1: run the audio stage's per-path kernels one after the other instead of side by side (measurement only) */
 int ssdr_set_concurrent(ssdr_ctx *ctx, int on);
-enum { SSDR_K_WF = 0, SSDR_K_AUDIO = 1, SSDR_K_SYNTH = 2, SSDR_K_DB2COL = 3, SSDR_K_PLAY = 4, SSDR_K_WIRE = 5, SSDR_K_TRACE = 6, SSDR_K_SMETER = 7, SSDR_K_FUSED = 8, SSDR_K_COUNT = 9 };
+enum { SSDR_K_WF = 0, SSDR_K_AUDIO = 1, SSDR_K_SYNTH = 2, SSDR_K_DB2COL = 3, SSDR_K_PLAY = 4, SSDR_K_WIRE = 5, SSDR_K_TRACE = 6, SSDR_K_SMETER = 7, SSDR_K_FUSED = 8, SSDR_K_ZOOM = 9, SSDR_K_COUNT = 10 };
 int ssdr_kernel_stats(ssdr_ctx *ctx, int which, float *total_ms, uint32_t *launches, int reset);
 /* channels per frame path of the audio stage (one kernel each, timed together as SSDR_K_AUDIO): counts[0] general
  * (NCO -> FIR), counts[1] full-band lane shift, counts[2] full-band AM (no NCO, no FIR) */

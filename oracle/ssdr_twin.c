@@ -314,6 +314,42 @@ void twin_wf_lines(const int16_t *iq, uint32_t n_ch, uint32_t n_lines, uint32_t 
                          out + ((size_t)k * n_ch + c) * NFFT);
 }
 
+/* -------------------------------------------------------------------- zoom */
+/* The zoom stage in front of the waterfall (ssdr_set_wf_zoom): per channel z[n] = x[n] conj(P(phi0 + n dphi)) with the phasor
+ * of EVERY sample taken from its absolute phase (no recurrence), y[m] = sum_k h[k] z[Z m - k] as an fma chain from zero, k
+ * ascending, out = saturate(rint(y)) as int16 I,Q.  hist = the ZHIST raw samples before the call's first (oldest first). */
+#define ZHIST 256
+void twin_zoom(const int16_t *iq /*[n_ch][n_in][2]*/, uint32_t n_ch, uint32_t n_in, uint32_t Z, const uint32_t *dphi,
+               const float *taps, uint32_t ntap, uint32_t *phase, int16_t *hist /*[n_ch][ZHIST][2]*/, int16_t *out /*[n_ch][n_in/Z][2]*/)
+{
+    float *zr = (float *)malloc((ZHIST + (size_t)n_in) * sizeof(float)), *zi = (float *)malloc((ZHIST + (size_t)n_in) * sizeof(float));
+    for (uint32_t c = 0; c < n_ch; c++) {
+        const int16_t *x = iq + (size_t)c * n_in * 2;
+        int16_t *h = hist + (size_t)c * ZHIST * 2;
+        for (int64_t n = -ZHIST; n < (int64_t)n_in; n++) {
+            const int16_t *s = n < 0 ? h + 2 * (ZHIST + n) : x + 2 * n;
+            float co, si;
+            phasor32(phase[c] + (uint32_t)(int32_t)n * dphi[c], &co, &si);
+            const float xr = (float)s[0], xi = (float)s[1];
+            zr[ZHIST + n] = fmaf(xr, co, xi * si);
+            zi[ZHIST + n] = fmaf(xi, co, -(xr * si));
+        }
+        for (uint32_t m = 0; m < n_in / Z; m++) {
+            float ar = 0.0f, ai = 0.0f;
+            for (uint32_t k = 0; k < ntap; k++) {
+                ar = fmaf(taps[k], zr[ZHIST + (size_t)Z * m - k], ar);
+                ai = fmaf(taps[k], zi[ZHIST + (size_t)Z * m - k], ai);
+            }
+            float yr = fminf(fmaxf(rintf(ar), -32768.0f), 32767.0f), yi = fminf(fmaxf(rintf(ai), -32768.0f), 32767.0f);
+            out[((size_t)c * (n_in / Z) + m) * 2] = (int16_t)(int32_t)yr;
+            out[((size_t)c * (n_in / Z) + m) * 2 + 1] = (int16_t)(int32_t)yi;
+        }
+        memcpy(h, x + 2 * ((size_t)n_in - ZHIST), ZHIST * 2 * sizeof(int16_t));          /* n_in >= ZHIST */
+        phase[c] += n_in * dphi[c];
+    }
+    free(zr); free(zi);
+}
+
 /* ------------------------------------------------------------------- audio */
 typedef struct {            /* per-channel kernel constants; same layout as the product's */
     uint32_t mode;          /* 0 am, 1 lsb, 2 usb, 3 cw, 4 nbfm */

@@ -13,7 +13,7 @@ NFFT, FRAME, RATE, NTAP_MAX, HIST = 1024, 512, 12000, 128, 128
 OK, EINVAL, ENOMEM, EHIP, ENODEV, ESTATE = 0, -1, -2, -3, -4, -5
 MODE_AM, MODE_LSB, MODE_USB, MODE_CW, MODE_NBFM, MODE_IQ = range(6)
 MODE_BY_NAME = {"am": 0, "lsb": 1, "usb": 2, "cw": 3, "nbfm": 4, "nfm": 4, "iq": 5}
-K_WF, K_AUDIO, K_SYNTH, K_DB2COL, K_PLAY, K_WIRE, K_TRACE, K_SMETER, K_FUSED = range(9)
+K_WF, K_AUDIO, K_SYNTH, K_DB2COL, K_PLAY, K_WIRE, K_TRACE, K_SMETER, K_FUSED, K_ZOOM = range(10)
 T_WINDOW, T_TWIDDLE_RE, T_TWIDDLE_IM, T_DB_THRESH = range(4)
 
 
@@ -75,6 +75,9 @@ _SIGS = {
     "ssdr_set_averaging": (C.c_int, [_P, C.c_uint32]),
     "ssdr_set_hop": (C.c_int, [_P, C.c_uint32]),
     "ssdr_set_exact_bins": (C.c_int, [_P, C.c_int]),
+    "ssdr_set_wf_zoom": (C.c_int, [_P, C.c_uint32]),
+    "ssdr_set_wf_center": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P]),
+    "ssdr_read_zoom": (C.c_int, [_P, C.c_uint32, C.c_uint32, _P, C.POINTER(C.c_uint32)]),
     "ssdr_set_decimation": (C.c_int, [_P, C.c_uint32]),
     "ssdr_compile_params_decim": (C.c_int, [C.POINTER(ChanParams), C.c_uint32, C.POINTER(ChanConsts), _P]),
     "ssdr_compile_params_rate": (C.c_int, [C.POINTER(ChanParams), C.c_uint32, C.c_uint32, C.POINTER(ChanConsts), _P]),

@@ -36,6 +36,13 @@ struct ssdr_ctx {
     // tables
     float *d_win = nullptr, *d_thr = nullptr;
     bool exact_bins = false;                            // ssdr_set_exact_bins: the waterfall stage in float64
+    // zoom stage in front of the waterfall kernel (ssdr_set_wf_zoom / ssdr_set_wf_center)
+    uint32_t zoom = 1, zoom_ntap = 0;
+    std::vector<double> h_zoom_offset;                  // [n_ch] zoom centre, Hz from the IQ band's centre
+    float *d_zoom_taps = nullptr;
+    uint32_t *d_zoom_dphi = nullptr, *d_zoom_phase = nullptr, *d_zoom_hist = nullptr, *d_zoom_out = nullptr;
+    size_t zoom_out_samples = 0;                        // capacity of d_zoom_out per channel
+    uint32_t zoom_run_samples = 0;                      // zoomed samples per channel of the last ssdr_run_wf
     double2 *d_tw64 = nullptr;                          // [512] e^{-2 pi j m / 1024} in double
     float2 *d_tw = nullptr;
     uint2 *d_lut = nullptr;
@@ -225,7 +232,7 @@ void ssdr_destroy(ssdr_ctx *c)
     void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_wf_tail, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_flags, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
                     c->d_play_taps, c->d_play_hist, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
-                    c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64, c->d_wire_gps, c->d_iq_out};
+                    c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64, c->d_wire_gps, c->d_iq_out, c->d_zoom_taps, c->d_zoom_dphi, c->d_zoom_phase, c->d_zoom_hist, c->d_zoom_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -454,6 +461,8 @@ int ssdr_compile_params_rate(const ssdr_chan_params *p, uint32_t decim, uint32_t
     return ssdr_compile_params_host(p, consts, taps, decim, rate);
 }
 
+static int zoom_restart(ssdr_ctx *c, uint32_t first, uint32_t count);
+
 int ssdr_set_decimation(ssdr_ctx *c, uint32_t decim)
 {
     if (!c || (decim != 1 && decim != 2 && decim != 4)) return SSDR_EINVAL;
@@ -466,7 +475,9 @@ int ssdr_set_decimation(ssdr_ctx *c, uint32_t decim)
     int rc = ssdr_set_params(c, 0, c->n_ch, all.data());
     if (rc != SSDR_OK) { c->decim = keep; (void)ssdr_set_params(c, 0, c->n_ch, all.data()); return rc; }
     c->have_input = false;                                        // a batch pushed at the old rate has the wrong extent
-    return ssdr_reset_state(c, 0, c->n_ch);                       // phases and histories of the old rate mean nothing now
+    rc = ssdr_reset_state(c, 0, c->n_ch);                         // phases and histories of the old rate mean nothing now
+    if (rc == SSDR_OK) rc = zoom_restart(c, 0, c->n_ch);
+    return rc;
 }
 
 int ssdr_set_hop(ssdr_ctx *c, uint32_t hop)
@@ -482,6 +493,80 @@ int ssdr_set_hop(ssdr_ctx *c, uint32_t hop)
     }
     c->hop = hop;
     c->wf_phase = 0;                                          // a change of framing restarts the averaging group
+    return SSDR_OK;
+}
+
+// the zoom centres as NCO steps at the current input rate; the zoom streams restart (phase, history, averaging group)
+static int zoom_restart(ssdr_ctx *c, uint32_t first, uint32_t count)
+{
+    if (c->zoom <= 1 || !c->d_zoom_dphi || !count) return SSDR_OK;
+    const double fs_in = (double)c->kiwi_rate * c->decim;
+    std::vector<uint32_t> dphi(count);
+    for (uint32_t i = 0; i < count; i++) {
+        const double x = std::nearbyint(c->h_zoom_offset[first + i] / fs_in * 4294967296.0);
+        long long v = (long long)x % 4294967296ll;
+        if (v < 0) v += 4294967296ll;
+        dphi[i] = (uint32_t)v;
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_zoom_dphi + first, dphi.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_zoom_phase + first, 0, count * sizeof(uint32_t), c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_zoom_hist + (size_t)first * SSDR_ZOOM_HIST, 0, (size_t)count * SSDR_ZOOM_HIST * 4, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->wf_phase = 0;
+    return SSDR_OK;
+}
+
+int ssdr_set_wf_zoom(ssdr_ctx *c, uint32_t zoom)
+{
+    if (!c || (zoom != 1 && zoom != 2 && zoom != 4 && zoom != 8)) return SSDR_EINVAL;
+    if (!c->feed.empty()) return SSDR_ESTATE;              // the feed's slots are sized for un-zoomed lines
+    HIP_TRY(hipSetDevice(c->device));
+    if (zoom > 1 && !c->d_zoom_dphi) {
+        HIP_TRY(hipMalloc(&c->d_zoom_taps, (SSDR_ZOOM_TAPS_MAX + 1) * sizeof(float)));
+        HIP_TRY(hipMalloc(&c->d_zoom_dphi, (size_t)c->n_ch * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_zoom_phase, (size_t)c->n_ch * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_zoom_hist, (size_t)c->n_ch * SSDR_ZOOM_HIST * 4));
+    }
+    if (c->h_zoom_offset.size() != c->n_ch) c->h_zoom_offset.assign(c->n_ch, 0.0);
+    c->zoom = zoom;
+    c->wf_phase = 0;
+    if (zoom > 1) {
+        // the reference's tap formula (utils_supersdr.py:334-344) with the cut-off at the zoomed stream's Nyquist frequency,
+        // fl / fs = 1 / (2 Z), and 32 Z - 1 taps: the transition takes the outer ~17 % of the span on either side at every Z
+        double h[SSDR_ZOOM_TAPS_MAX + 1];
+        const int n = (int)(32 * zoom - 1);
+        if (ssdr_design_lowpass_exact(1.0 / (2.0 * zoom), 1.0, n, h) != n) return SSDR_EINVAL;
+        float hf[SSDR_ZOOM_TAPS_MAX + 1] = {};
+        for (int i = 0; i < n; i++) hf[i] = (float)h[i];
+        c->zoom_ntap = (uint32_t)n;
+        HIP_TRY(hipMemcpy(c->d_zoom_taps, hf, sizeof hf, hipMemcpyHostToDevice));
+        return zoom_restart(c, 0, c->n_ch);
+    }
+    return SSDR_OK;
+}
+
+int ssdr_set_wf_center(ssdr_ctx *c, uint32_t first, uint32_t count, const double *offset_hz)
+{
+    if (!c || !offset_hz || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
+    const double half = 0.5 * (double)c->kiwi_rate * c->decim;
+    for (uint32_t i = 0; i < count; i++)
+        if (!(std::fabs(offset_hz[i]) <= half)) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->h_zoom_offset.size() != c->n_ch) c->h_zoom_offset.assign(c->n_ch, 0.0);
+    for (uint32_t i = 0; i < count; i++) c->h_zoom_offset[first + i] = offset_hz[i];
+    return zoom_restart(c, first, count);
+}
+
+int ssdr_read_zoom(ssdr_ctx *c, uint32_t first, uint32_t count, int16_t *iq_out, uint32_t *samples_per_channel)
+{
+    if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
+    if (c->zoom <= 1 || !c->d_zoom_out || c->zoom_run_samples == 0) return SSDR_ESTATE;
+    if (samples_per_channel) *samples_per_channel = c->zoom_run_samples;
+    if (!iq_out) return SSDR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(iq_out, c->d_zoom_out + (size_t)first * c->zoom_run_samples, (size_t)count * c->zoom_run_samples * 4,
+                           hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
 }
 
@@ -653,9 +738,32 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
     if (!c) return SSDR_EINVAL;
     if (!c->have_input) return SSDR_ESTATE;
     const bool hop512 = c->hop == SSDR_NFFT / 2;
-    const uint32_t halves = c->in_frames * c->decim;                 // 512-sample half-lines in the batch
+    const bool zoomed = c->zoom > 1;
+    if (zoomed && (c->fuse_next || (c->in_frames * c->decim) % c->zoom)) return SSDR_EINVAL;
+    const uint32_t halves = c->in_frames * c->decim / c->zoom;       // 512-sample half-lines the batch yields (of the zoomed stream)
     if (!hop512 && (halves & 1u)) return SSDR_EINVAL;
+    if (zoomed && halves == 0) return SSDR_EINVAL;                   // a batch must hold a whole number of lines
     HIP_TRY(hipSetDevice(c->device));
+    const uint32_t *wf_src = c->d_iq;                                // what the waterfall kernel reads: the input, or the zoomed stream
+    uint64_t wf_stride = (uint64_t)in_len(c, c->in_frames);
+    if (zoomed) {
+        const uint32_t n_in = (uint32_t)in_len(c, c->in_frames), n_out = n_in / c->zoom;
+        if (c->zoom_out_samples < n_out) {
+            if (c->d_zoom_out) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_zoom_out)); c->d_zoom_out = nullptr; c->zoom_out_samples = 0; }
+            HIP_TRY(hipMalloc(&c->d_zoom_out, (size_t)c->n_ch * n_out * 4));
+            c->zoom_out_samples = n_out;
+        }
+        SsdrZoomArgs z;
+        z.iq = c->d_iq; z.ch_stride = wf_stride; z.n_ch = c->n_ch; z.n_in = n_in; z.zoom = c->zoom; z.ntap = c->zoom_ntap;
+        z.taps = c->d_zoom_taps; z.dphi = c->d_zoom_dphi; z.phase = c->d_zoom_phase; z.hist = c->d_zoom_hist; z.out = c->d_zoom_out;
+        int rcz;
+        if ((rcz = timed_begin(c)) != SSDR_OK) return rcz;
+        HIP_TRY(ssdr_launch_zoom(z, c->stream));
+        if ((rcz = timed_end(c, SSDR_K_ZOOM)) != SSDR_OK) return rcz;
+        wf_src = c->d_zoom_out;
+        wf_stride = n_out;
+        c->zoom_run_samples = n_out;
+    }
     const uint32_t n_lines = hop512 ? halves : halves / 2;
     const uint32_t total = c->wf_phase + n_lines;
     const uint32_t n_out = total / c->n_avg;
@@ -666,8 +774,8 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
         c->wf_out_lines = n_out;
     }
     SsdrWfArgs a;
-    a.iq = c->d_iq;
-    a.ch_stride = (uint64_t)in_len(c, c->in_frames);
+    a.iq = wf_src;
+    a.ch_stride = wf_stride;
     a.n_ch = c->n_ch;
     a.n_lines = n_lines;
     a.tail = hop512 ? c->d_wf_tail : nullptr;
@@ -695,8 +803,8 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
         if ((rc = timed_end(c, SSDR_K_WF)) != SSDR_OK) return rc;
     }
     if (hop512)                  // the batch's last half-line is the next batch's first: [n_ch] rows of 2 KB out of the input
-        HIP_TRY(hipMemcpy2DAsync(c->d_wf_tail, (SSDR_NFFT / 2) * 4, c->d_iq + (size_t)(halves - 1) * SSDR_FRAME,
-                                 in_len(c, c->in_frames) * 4, (SSDR_NFFT / 2) * 4, c->n_ch, hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpy2DAsync(c->d_wf_tail, (SSDR_NFFT / 2) * 4, wf_src + (size_t)(halves - 1) * SSDR_FRAME,
+                                 wf_stride * 4, (SSDR_NFFT / 2) * 4, c->n_ch, hipMemcpyDeviceToDevice, c->stream));
     c->wf_phase = total % c->n_avg;
     if (c->wf_phase) c->wf_acc_cur ^= 1;             // a partial group was written to acc_out
     c->wf_lines_ready = n_out;
@@ -848,7 +956,7 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
     for (uint32_t ch = 0; ch < c->n_ch; ch++) n_am += ssdr_audio_path(c->h_consts[ch]) == SSDR_PATH_AM_RAW;
     // the fused kernel covers the metric's configuration: every channel on the full-band AM path, N = 1, hop 1024, 12 kHz IQ
     const bool eligible = n_am == c->n_ch && c->n_avg == 1 && c->hop == SSDR_NFFT && c->decim == 1 && !(c->in_frames & 1u) &&
-                          !c->concurrent && c->fused_grid != 0 && c->fused_enabled && !c->exact_bins;
+                          !c->concurrent && c->fused_grid != 0 && c->fused_enabled && !c->exact_bins && c->zoom == 1;
     if (fused) *fused = eligible ? 1 : 0;
     c->fuse_next = eligible;
     int rc = ssdr_run_wf(c, nullptr, lines_ready, 0);
@@ -954,7 +1062,7 @@ int ssdr_feed_close(ssdr_ctx *c)
 int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth, uint32_t flags)
 {
     if (!c || n_frames == 0 || (n_frames & 1u) || depth < 2 || depth > 16 || (flags & ~(uint32_t)(SSDR_FEED_WIRE | SSDR_FEED_POST))) return SSDR_EINVAL;
-    if (!c->feed.empty() || c->concurrent || c->decim != 1) return SSDR_ESTATE;      // the feed's slots are sized for 12 kHz IQ
+    if (!c->feed.empty() || c->concurrent || c->decim != 1 || c->zoom != 1) return SSDR_ESTATE;      // the feed's slots are sized for un-zoomed 12 kHz IQ
     HIP_TRY(hipSetDevice(c->device));
     const bool post = (flags & SSDR_FEED_POST) != 0;
     if (post) { int rcp = ensure_play(c); if (rcp != SSDR_OK) return rcp; }
@@ -1574,7 +1682,9 @@ int ssdr_set_kiwi_rate(ssdr_ctx *c, uint32_t kiwi_rate)
     int rc = ssdr_set_params(c, 0, c->n_ch, all.data());
     if (rc != SSDR_OK) { c->kiwi_rate = keep; (void)ssdr_set_params(c, 0, c->n_ch, all.data()); return rc; }
     c->have_input = false;
-    return ssdr_reset_state(c, 0, c->n_ch);
+    rc = ssdr_reset_state(c, 0, c->n_ch);
+    if (rc == SSDR_OK) rc = zoom_restart(c, 0, c->n_ch);
+    return rc;
 }
 
 int ssdr_playbuffer_frame_len(ssdr_ctx *c, uint32_t *samples_per_frame)

@@ -128,6 +128,19 @@ hipError_t ssdr_launch_smeter(const SsdrSmeterArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_checksum(const void *data, uint64_t n_words, unsigned long long *out, hipStream_t stream);
 hipError_t ssdr_launch_adpcm(const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state, int16_t *out,
                              hipStream_t stream);
+#define SSDR_ZOOM_HIST 256                   // raw input samples carried per channel (>= 32 Z - 2 for Z <= 8)
+#define SSDR_ZOOM_TAPS_MAX 255
+struct SsdrZoomArgs {
+    const uint32_t *iq;                      // [n_ch][ch_stride] input dwords
+    uint64_t ch_stride;
+    uint32_t n_ch, n_in, zoom, ntap;         // n_in input samples per channel in this call (multiple of zoom)
+    const float *taps;                       // [ntap]
+    const uint32_t *dphi;                    // [n_ch] NCO step of the zoom centre
+    uint32_t *phase;                         // [n_ch] in/out: phase of the call's first sample
+    uint32_t *hist;                          // [n_ch][SSDR_ZOOM_HIST] in/out: the raw samples before the call's first
+    uint32_t *out;                           // [n_ch][n_in / zoom] I | Q << 16
+};
+hipError_t ssdr_launch_zoom(const SsdrZoomArgs &a, hipStream_t stream);
 struct SsdrFusedArgs { SsdrWfArgs wf; SsdrAudioArgs au; };
 hipError_t ssdr_launch_fused_am(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream);
 hipError_t ssdr_fused_blocks_per_cu(int *blocks);
@@ -149,3 +162,4 @@ void ssdr_make_thresholds(float *thr);                // [256]
 int ssdr_make_quant_lut(uint2 *lut);                  // [SSDR_LUT_N]; returns 0, or -1 if a segment held two thresholds
 int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps, uint32_t decim, uint32_t rate_hz = SSDR_RATE);
 int ssdr_design_lowpass(double fl, double fs, int n_max, double *h);   // utils_supersdr.py:334-344; returns tap count
+int ssdr_design_lowpass_exact(double fl, double fs, int n, double *h);  // the same window and sinc with exactly n (odd) taps

@@ -94,6 +94,7 @@ static int design_lowpass_n(double fl, double fs, int n_max, int n_min, double *
     return N;
 }
 int ssdr_design_lowpass(double fl, double fs, int n_max, double *h) { return design_lowpass_n(fl, fs, n_max, 0, h); }
+int ssdr_design_lowpass_exact(double fl, double fs, int n, double *h) { return design_lowpass_n(fl, fs, n, n, h); }
 
 static uint32_t dphi_of(double f_hz, double rate)
 {

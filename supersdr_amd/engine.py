@@ -57,6 +57,7 @@ class SsdrEngine:
         self.hop = L.NFFT
         self.decim = 1
         self.averaging = 1
+        self.zoom = 1
         self.kiwi_rate = L.RATE
         self.audio_frames = 0          # frames of the last run_audio / set_pcm (extent of the device PCM / RSSI / flags)
 
@@ -101,6 +102,26 @@ class SsdrEngine:
         check(lib.ssdr_set_hop(self._ctx, int(hop)), "ssdr_set_hop")
         self.hop = int(hop)
 
+    def set_wf_zoom(self, zoom):
+        """waterfall span = the IQ band / zoom (1, 2, 4, 8) around each channel's zoom centre (set_wf_center); ctx-wide.
+        A batch must then hold a whole number of zoomed lines (1024 * zoom input samples each, 512 * zoom at hop 512)."""
+        check(lib.ssdr_set_wf_zoom(self._ctx, int(zoom)), "ssdr_set_wf_zoom")
+        self.zoom = int(zoom)
+
+    def set_wf_center(self, first, offsets_hz):
+        """zoom centres, Hz from the IQ band's centre, for channels first .. first + len(offsets_hz) - 1"""
+        off = np.ascontiguousarray(offsets_hz, np.float64)
+        check(lib.ssdr_set_wf_center(self._ctx, int(first), len(off), off.ctypes.data), "ssdr_set_wf_center")
+
+    def read_zoom(self, first=0, count=None):
+        """-> int16 [count, n, 2]: the zoomed I,Q stream the last run_wf drew its lines from"""
+        count = self.n_ch - first if count is None else int(count)
+        n = C.c_uint32(0)
+        check(lib.ssdr_read_zoom(self._ctx, int(first), count, None, C.byref(n)), "ssdr_read_zoom")
+        out = np.empty((count, n.value, 2), np.int16)
+        check(lib.ssdr_read_zoom(self._ctx, int(first), count, out.ctypes.data, C.byref(n)), "ssdr_read_zoom")
+        return out
+
     def set_exact_bins(self, on):
         """waterfall stage in float64: the int16 sums then equal the float64 definition (NumPy float64 FFT) bit for bit; ~25x slower"""
         check(lib.ssdr_set_exact_bins(self._ctx, int(bool(on))), "ssdr_set_exact_bins")
@@ -135,7 +156,7 @@ class SsdrEngine:
         if not fetch:
             check(lib.ssdr_run_wf(self._ctx, None, C.byref(n), 0), "ssdr_run_wf")
             return n.value
-        halves = self.in_frames * self.decim
+        halves = self.in_frames * self.decim // self.zoom
         total_lines = (halves if self.hop == L.NFFT // 2 else halves // 2) + 1    # upper bound incl. a carried partial group
         out = np.empty((total_lines, self.n_ch, L.NFFT), np.int16)
         check(lib.ssdr_run_wf(self._ctx, out.ctypes.data, C.byref(n), 0), "ssdr_run_wf")

@@ -1227,3 +1227,79 @@ def test_mod_iq_bit_exact_vs_twin_and_oracle(S, twin, decim):
     if decim == 1:                                      # AGC on, an AM carrier in the passband: the envelope's peaks sit at half scale
         mag = np.hypot(iqo[0, -512:, 0].astype(np.float64), iqo[0, -512:, 1].astype(np.float64))
         assert abs(mag.max() - 16384.0) < 16384.0 * 0.02 and mag.min() > 16384.0 * 0.25
+
+
+@pytest.mark.parametrize("Z,hop,n_avg,decim", [(2, 1024, 1, 1), (4, 1024, 3, 1), (8, 512, 1, 1), (4, 1024, 1, 2)])
+def test_waterfall_zoom_bit_exact_vs_twin_and_oracle(S, twin, Z, hop, n_avg, decim):
+    """ssdr_set_wf_zoom / ssdr_set_wf_center (VERDICT r2 missing #4; "SET zoom= start=", utils_supersdr.py:741, 753-758, 839): a
+    zoom stage (NCO at the zoom centre, the reference's tap formula at the new Nyquist, decimation by Z, int16 I,Q) in front of
+    the unchanged waterfall kernel.  Zoomed stream and lines bit-exact vs the twin over several calls (phase, filter history,
+    hop-512 tail and averaging groups carried), the stream within 1 LSB of the float64 oracle; the audio chain does not
+    notice; a batch that does not hold whole zoomed lines is refused; a new centre restarts that channel only."""
+    n_ch = 5
+    fs_in = 12000.0 * decim
+    unit = (1024 if hop == 1024 else 512) * Z // decim // 512       # frames per zoomed line
+    unit = max(unit, 1)
+    calls = [unit * k for k in (2, 1, 3)]
+    n_frames = sum(calls)
+    iq = O.synth_iq(n_ch, n_frames * 512 * decim, seed=300 + Z)
+    offs = np.array([0.0, 1500.0, -2750.25, 0.45 * fs_in, -0.3 * fs_in])
+    with S.SsdrEngine(n_ch) as eng:
+        if decim > 1:
+            eng.set_decimation(decim)
+        eng.set_params(0, [S.default_params("usb" if decim > 1 else "am", wf_cal_db=float(c - 2)) for c in range(n_ch)])
+        eng.set_hop(hop)
+        eng.set_averaging(n_avg)
+        eng.set_wf_zoom(Z)
+        eng.set_wf_center(0, offs)
+        with pytest.raises(S.SsdrError):
+            eng.set_wf_center(0, [0.6 * fs_in])
+        lines, zs, pcms, pos = [], [], [], 0
+        for nf in calls:
+            eng.push_iq(iq[:, pos * 512 * decim:(pos + nf) * 512 * decim])
+            lines.append(eng.run_wf())
+            zs.append(eng.read_zoom())
+            pcms.append(eng.run_audio()[0])
+            pos += nf
+        consts, taps = eng.get_consts()
+        if Z > 1 and hop == 1024 and decim == 1:
+            eng.push_iq(iq[:, :1024])                                # 2 frames: not a whole zoomed line
+            with pytest.raises(S.SsdrError):
+                eng.run_wf()
+    zoomed = np.concatenate(zs, axis=1)
+    dphi = np.array([O._dphi(f, fs_in) for f in offs], np.uint32)
+    ph, hist = np.zeros(n_ch, np.uint32), np.zeros((n_ch, 256, 2), np.int16)
+    zt = twin.zoom(iq, Z, dphi, O.zoom_taps(Z), ph, hist)
+    assert zoomed.shape == zt.shape == (n_ch, n_frames * 512 * decim // Z, 2) and np.array_equal(zoomed, zt)
+    for c in range(n_ch):
+        o = O.ZoomChannel(Z, offs[c], fs_in).process(iq[c])
+        dd = np.abs(zoomed[c].astype(np.int32) - o.astype(np.int32))
+        assert dd.max() <= 1 and (dd > 0).mean() < 0.01, c
+    got = np.concatenate(lines, axis=0)
+    cal = consts["wf_cal_lin"]
+    if hop == 1024:
+        ref = twin.wf(zt, n_avg, cal)
+    else:
+        ref = twin.wf_hop(np.concatenate([np.zeros((n_ch, 512, 2), np.int16), zt], axis=1), 512, n_avg, cal)
+    assert got.shape == ref.shape and got.shape[0] > 0 and np.array_equal(got, ref)
+    # the audio chain runs on the un-zoomed input as ever
+    st, hist_a = twinlib.fresh_state(consts)
+    pcm_t, _ = twin.audio(iq, consts, taps, st, hist_a)
+    assert np.array_equal(np.concatenate(pcms, axis=1), pcm_t)
+    # a new centre restarts that channel's zoom stream and nobody else's
+    if Z == 2:
+        with S.SsdrEngine(2) as eng:
+            eng.set_wf_zoom(2)
+            eng.set_wf_center(0, [1000.0, -1000.0])
+            eng.push_iq(iq[:2, :4096])
+            eng.run_wf()
+            eng.set_wf_center(1, [2000.0])
+            eng.push_iq(iq[:2, 4096:8192])
+            eng.run_wf()
+            z2 = eng.read_zoom()
+        d2 = np.array([O._dphi(1000.0, fs_in), O._dphi(2000.0, fs_in)], np.uint32)
+        ph, hist = np.zeros(2, np.uint32), np.zeros((2, 256, 2), np.int16)
+        t0 = twin.zoom(iq[:2, :8192], 2, np.array([d2[0], d2[0]], np.uint32), O.zoom_taps(2), ph, hist)[0, 2048:]
+        ph, hist = np.zeros(1, np.uint32), np.zeros((1, 256, 2), np.int16)
+        t1 = twin.zoom(iq[1:2, 4096:8192], 2, d2[1:], O.zoom_taps(2), ph, hist)[0]
+        assert np.array_equal(z2[0], t0) and np.array_equal(z2[1], t1)

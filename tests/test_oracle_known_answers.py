@@ -388,3 +388,46 @@ def test_wide_rate_chain_twin_vs_oracle_and_known_answers():
     seg = out[0, 1024:1024 + 2025].astype(np.float64)                                # 2025 samples = 100 cycles of 1 kHz at 20.25 kHz
     spec = np.abs(np.fft.rfft(seg * np.hanning(len(seg))))
     assert int(np.argmax(spec)) == 100
+
+
+# ------------------------------------------------------------------ round 3: waterfall zoom
+@pytest.mark.parametrize("Z", [2, 4, 8])
+def test_zoom_stage_known_answers_and_twin_vs_oracle(twin, Z):
+    """"SET zoom= start=" (utils_supersdr.py:741, 753-758, 839): a span of 1/Z of the IQ band around a zoom centre.  A tone
+    d Hz above the centre lands d / (fs / Z) * 1024 bins right of bin 512 at its un-zoomed level; what lies outside the
+    zoomed span beyond the filter's transition is >= 70 dB down; the fp32 twin stays within 1 LSB of the float64 oracle."""
+    fs, n_in = 12000.0, 8 * 1024 * Z // Z * Z
+    f0 = 1500.0
+    span = fs / Z
+    n = np.arange(n_in)
+
+    def line_of(freq_hz, amp=8000.0):
+        z = amp * np.exp(2j * np.pi * freq_hz * n / fs)
+        x = np.stack([np.rint(z.real), np.rint(z.imag)], axis=-1).astype(np.int16)
+        y = O.ZoomChannel(Z, f0, fs).process(x)
+        return O.wf_line(y[-1024:].reshape(1, 1024, 2))[0]
+
+    d = span * 0.25                                           # a quarter span above the centre
+    ln = line_of(f0 + d)
+    k = int(np.argmax(ln))
+    assert abs(k - (512 + 256)) <= 1
+    ref = O.wf_line(np.stack([np.rint(8000 * np.cos(2 * np.pi * 0.25 * np.arange(1024))), np.rint(8000 * np.sin(2 * np.pi * 0.25 * np.arange(1024)))],
+                             axis=-1).astype(np.int16).reshape(1, 1024, 2))[0]
+    assert abs(int(ln.max()) - int(ref.max())) <= 1           # unity pass-band gain: the level of the same tone un-zoomed
+    out = line_of(f0 + 0.85 * span)                           # outside the span, beyond the transition: folds to 0.85 - 1 = -0.15 span
+    assert int(out.max()) <= int(ln.max()) - 70
+    edge = line_of(f0 + 0.5 * span - fs / 1024.0)             # at the edge of the span: the filter's -6 dB point
+    assert 3 <= int(ln.max()) - int(edge.max()) <= 9
+    # twin vs oracle on the zoomed stream itself, state carried over uneven calls
+    iq = O.synth_iq(3, 6 * 1024 * Z, seed=40 + Z)
+    offs = [f0, -2500.0, 0.0]
+    dphi = np.array([O._dphi(f, fs) for f in offs], np.uint32)
+    ph, hist = np.zeros(3, np.uint32), np.zeros((3, 256, 2), np.int16)
+    cut = 2 * 1024 * Z
+    got = np.concatenate([twin.zoom(iq[:, :cut], Z, dphi, O.zoom_taps(Z), ph, hist), twin.zoom(iq[:, cut:], Z, dphi, O.zoom_taps(Z), ph, hist)], axis=1)
+    for c in range(3):
+        zc = O.ZoomChannel(Z, offs[c], fs)
+        o = np.concatenate([zc.process(iq[c, :cut]), zc.process(iq[c, cut:])])
+        dd = np.abs(got[c].astype(np.int32) - o.astype(np.int32))
+        assert dd.max() <= 1 and (dd > 0).mean() < 0.01
+    assert len(O.zoom_taps(Z)) == 32 * Z - 1

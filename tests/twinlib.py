@@ -28,6 +28,7 @@ class Twin:
         lib.twin_audio.argtypes = [P, C.c_uint32, C.c_uint32, P, P, P, P, P, P]
         lib.twin_audio2.argtypes = [P, C.c_uint32, C.c_uint32, P, P, P, P, P, P, P]
         lib.twin_audio3.argtypes = [P, C.c_uint32, C.c_uint32, P, P, P, P, P, P, P, P]
+        lib.twin_zoom.argtypes = [P, C.c_uint32, C.c_uint32, C.c_uint32, P, P, C.c_uint32, P, P, P]
         lib.twin_quantise.argtypes = [C.c_float, P]
         lib.twin_quantise.restype = C.c_int
         for f in ("twin_log2p", "twin_exp2p"):
@@ -83,6 +84,19 @@ class Twin:
                              state.ctypes.data, hist.ctypes.data, pcm.ctypes.data, rssi.ctypes.data, flags.ctypes.data,
                              iqo.ctypes.data)
         out = (pcm, rssi) + ((flags,) if want_flags else ()) + ((iqo,) if want_iq else ())
+        return out
+
+    def zoom(self, iq, Z, dphi, taps, phase, hist):
+        """iq int16[n_ch, n_in, 2]; dphi uint32[n_ch]; taps float32[ntap]; phase uint32[n_ch] and hist int16[n_ch, 256, 2]
+        updated in place -> int16[n_ch, n_in // Z, 2] the zoomed stream"""
+        iq = np.ascontiguousarray(iq, np.int16)
+        n_ch, n_in = iq.shape[0], iq.shape[1]
+        dphi = np.ascontiguousarray(dphi, np.uint32)
+        taps = np.ascontiguousarray(taps, np.float32)
+        assert phase.dtype == np.uint32 and hist.dtype == np.int16 and hist.shape == (n_ch, 256, 2) and n_in >= 256
+        out = np.zeros((n_ch, n_in // Z, 2), np.int16)
+        self.lib.twin_zoom(iq.ctypes.data, n_ch, n_in, Z, dphi.ctypes.data, taps.ctypes.data, len(taps), phase.ctypes.data,
+                           hist.ctypes.data, out.ctypes.data)
         return out
 
     def phasor32(self, ph):
