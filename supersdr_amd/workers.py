@@ -91,9 +91,17 @@ class IQHub:
     """
 
     def __init__(self, n_channels, device=0, engine=None, max_queue=64, gpu_post=True, kiwi_rate=12000, trace_rows=0,
-                 backlog_superframes=8, stall_superframes=4, pipeline=False, depth=3, hop=1024):
+                 backlog_superframes=8, stall_superframes=4, pipeline=False, depth=3, hop=1024, zoom=1):
         self.n_ch = int(n_channels)
         self.engine = engine if engine is not None else SsdrEngine(self.n_ch, device)
+        # waterfall zoom ("SET zoom=", utils_supersdr.py:741, 839): the lines then span 1/zoom of the IQ band around each
+        # channel's zoom centre (set_wf_center) and one line needs `zoom` superframes: the hub batches that many per GPU run
+        self.zoom = int(zoom)
+        if self.zoom != 1:
+            if pipeline:
+                raise ValueError("zoom needs the synchronous hub (the pipelined feed's slots hold un-zoomed lines)")
+            self.engine.set_wf_zoom(self.zoom)
+        self._sf = L.NFFT * self.zoom                # samples per channel and GPU run
         if hop != L.NFFT:                            # 512: two waterfall lines per superframe, 23.4 lines/s (MAX_FPS = 23, utils:597)
             self.engine.set_hop(hop)
         # spectrum_db2col and play_buffer run on the GPU with every superframe
@@ -113,12 +121,12 @@ class IQHub:
         self._smeter = None
         self.wf_clients = [None] * self.n_ch        # kiwi_waterfall objects: display state for db2col
         self.snd_clients = [None] * self.n_ch       # kiwi_sound objects: volume / balance for play_buffer
-        self._cap = max(2, int(backlog_superframes)) * L.NFFT
-        self._stall = max(1, int(stall_superframes)) * L.NFFT
+        self._cap = max(2, int(backlog_superframes)) * self._sf
+        self._stall = max(1, int(stall_superframes)) * self._sf
         self._ring = np.zeros((self.n_ch, self._cap, 2), np.int16)
         self._rd = [0] * self.n_ch                  # absolute sample counters; ring index = counter % cap
         self._wr = [0] * self.n_ch
-        self._batch = np.zeros((self.n_ch, L.NFFT, 2), np.int16)
+        self._batch = np.zeros((self.n_ch, self._sf, 2), np.int16)
         self.dropped = [0] * self.n_ch
         self.stalled = [0] * self.n_ch
         self.wf_queue = [queue.Queue(max_queue) for _ in range(self.n_ch)]
@@ -145,6 +153,11 @@ class IQHub:
             self.engine.set_params(channel, [p])     # raises for parameters the library refuses; the old ones stay
             self._params[channel] = p
 
+    def set_wf_center(self, channel, offset_hz):
+        """zoom centre of one channel, Hz from the centre of its IQ band (restarts that channel's zoomed stream)"""
+        with self._lock:
+            self.engine.set_wf_center(channel, [float(offset_hz)])
+
     def set_averaging(self, n, channel=None):
         """channel=None: every channel wants N (one receiver, or a caller that owns the whole hub)."""
         n = int(min(max(n, 1), 100))
@@ -165,7 +178,7 @@ class IQHub:
         with self._lock:
             pos = 0
             while pos < len(iq):                                 # ring-sized pieces, pumping in between
-                n = min(len(iq) - pos, L.NFFT)
+                n = min(len(iq) - pos, self._sf)
                 over = (self._wr[channel] - self._rd[channel]) + n - self._cap
                 if over > 0:                                     # nobody consumes: drop-oldest, like the result queues
                     self._rd[channel] += over
@@ -181,21 +194,21 @@ class IQHub:
 
     def _take(self, c):
         """next superframe of channel c into the batch; False (zero-filled) if the channel does not have one"""
-        if self._wr[c] - self._rd[c] < L.NFFT:
+        if self._wr[c] - self._rd[c] < self._sf:
             self._batch[c] = 0
             return False
         r = self._rd[c] % self._cap
-        first = min(L.NFFT, self._cap - r)
+        first = min(self._sf, self._cap - r)
         self._batch[c, :first] = self._ring[c, r:r + first]
-        if first < L.NFFT:
-            self._batch[c, first:] = self._ring[c, :L.NFFT - first]
-        self._rd[c] += L.NFFT
+        if first < self._sf:
+            self._batch[c, first:] = self._ring[c, :self._sf - first]
+        self._rd[c] += self._sf
         return True
 
     def _pump(self):
         while True:
             avail = [self._wr[c] - self._rd[c] for c in range(self.n_ch)]
-            if min(avail) < L.NFFT and max(avail) < self._stall + L.NFFT:
+            if min(avail) < self._sf and max(avail) < self._stall + self._sf:
                 return                                           # wait for the slowest channel, but not for ever
             for c in range(self.n_ch):
                 if not self._take(c):
@@ -246,7 +259,7 @@ class IQHub:
                     k = chans[c]
                     post = (color[i, c].copy(), k.low_clip_db, k.high_clip_db, k.dynamic_range, k.wf_min_db, k.wf_max_db)
                 _put_drop_oldest(self.wf_queue[c], (line[c].copy(), n_avg, post))
-            for f in range(2):
+            for f in range(pcm.shape[1] // L.FRAME):
                 _put_drop_oldest(self.snd_queue[c], Frame.make(
                     pcm[c, f * L.FRAME:(f + 1) * L.FRAME], rssi[c, f],
                     play[c, f * P:(f + 1) * P].copy() if play is not None else None,
@@ -531,11 +544,22 @@ class WaterfallSeams:
             hub.wf_clients[self.channel] = self
 
     # ---- the true frequency axis of the GPU waterfall
+    def set_iq_zoom_center(self, khz):
+        """centre of this channel's zoomed waterfall (hub built with zoom > 1), an absolute frequency inside its IQ band"""
+        self.hub.set_wf_center(self.channel, (float(khz) - self.iq_center_khz) * 1000.0)
+        self.iq_zoom_center_khz = float(khz)
+
+    def _iq_axis(self):
+        span = getattr(self.hub, "iq_span_khz", IQ_SPAN_KHZ) / getattr(self.hub, "zoom", 1)
+        return getattr(self, "iq_zoom_center_khz", self.iq_center_khz), span
+
     def iq_bin_to_khz(self, bin_):
-        return self.iq_center_khz + (bin_ - self.WF_BINS / 2) * getattr(self.hub, "iq_span_khz", IQ_SPAN_KHZ) / self.WF_BINS
+        centre, span = self._iq_axis()
+        return centre + (bin_ - self.WF_BINS / 2) * span / self.WF_BINS
 
     def iq_khz_to_bin(self, khz):
-        return (khz - self.iq_center_khz) * self.WF_BINS / getattr(self.hub, "iq_span_khz", IQ_SPAN_KHZ) + self.WF_BINS / 2
+        centre, span = self._iq_axis()
+        return (khz - centre) * self.WF_BINS / span + self.WF_BINS / 2
 
     def close_connection(self):
         self.terminate = True

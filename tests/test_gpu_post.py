@@ -527,3 +527,40 @@ def test_db2col_line_touches_nothing_but_its_own_line(S):
         assert eng.output_checksum() == sums0 and np.array_equal(eng.fetch_wf(1), wf)
         ref = O.spectrum_db2col(line.astype(np.float32) / np.float32(3), 7, True)
         assert np.array_equal(c1, ref[0]) and k.wf_min_db == np.float32(ref[4]) and k.wf_max_db == np.float32(ref[5])
+
+
+def test_hub_with_zoomed_waterfall(S, twin):
+    """IQHub(zoom=4): one GPU run per 4 superframes, one zoomed line each (span = a quarter of the IQ band around the
+    channel's zoom centre), 8 audio frames per run from the un-zoomed input; the worker's frequency axis follows."""
+    import twinlib
+    from supersdr_amd.workers import IQHub, bind_headless
+    gpu = bind_headless()
+    Z = 4
+    hub = IQHub(2, zoom=Z)
+    wf = [gpu.kiwi_waterfall("gpu", 0, "", 6, 7100.0, _Eibi(), _Disp(), hub=hub, channel=c, timeout=1.0) for c in range(2)]
+    snd = [gpu.kiwi_sound(7100.0, "AM", -6000, 6000, "", wf[c], 8) for c in range(2)]
+    wf[1].set_iq_zoom_center(7101.5)
+    assert wf[0].iq_bin_to_khz(512) == 7100.0 and wf[1].iq_bin_to_khz(512) == 7101.5
+    assert abs(wf[1].iq_bin_to_khz(1024) - (7101.5 + 1.5)) < 1e-9            # span 12 kHz / 4 = 3 kHz
+    iq = O.synth_iq(2, 3 * Z * 1024, seed=73)
+    for k in range(3 * Z):
+        for c in range(2):
+            hub.feed(c, iq[c, k * 1024:(k + 1) * 1024])
+    assert hub.superframes == 3
+    dphi = np.array([O._dphi(0.0, 12000.0), O._dphi(1500.0, 12000.0)], np.uint32)
+    ph, hist = np.zeros(2, np.uint32), np.zeros((2, 256, 2), np.int16)
+    zt = twin.zoom(iq, Z, dphi, O.zoom_taps(Z), ph, hist)
+    ref = twin.wf(zt, 1)
+    for c in range(2):
+        for k in range(3):
+            wf[c].step()
+            assert np.array_equal(wf[c].spectrum, ref[k, c].astype(np.float32)), (c, k)
+    consts, taps = hub.engine.get_consts()
+    st, hist_a = twinlib.fresh_state(consts)
+    pcm_t, _ = twin.audio(iq, consts, taps, st, hist_a)
+    for c in range(2):
+        got = np.concatenate([snd[c].process_audio_stream() for _ in range(3 * Z * 2)])
+        assert np.array_equal(got, pcm_t[c])
+    hub.close()
+    with pytest.raises(ValueError):
+        IQHub(1, zoom=2, pipeline=True)
