@@ -303,6 +303,8 @@ int ssdr_table(int which, float *out, uint32_t n)
     }
 }
 
+static int zoom_restart(ssdr_ctx *c, uint32_t first, uint32_t count, bool restart_group = true);
+
 int ssdr_reset_state(ssdr_ctx *c, uint32_t first, uint32_t count)
 {
     if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
@@ -325,7 +327,7 @@ int ssdr_reset_state(ssdr_ctx *c, uint32_t first, uint32_t count)
         HIP_TRY(hipMemsetAsync(c->d_wf_tail + (size_t)first * (SSDR_NFFT / 2), 0, (size_t)count * (SSDR_NFFT / 2) * 4, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (first == 0 && count == c->n_ch) { c->wf_phase = 0; c->synth_sample0 = 0; c->audio_started = false; }
-    return SSDR_OK;
+    return zoom_restart(c, first, count, false);         // the zoomed streams of these channels start over as well
 }
 
 int ssdr_set_params(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan_params *p)
@@ -461,8 +463,6 @@ int ssdr_compile_params_rate(const ssdr_chan_params *p, uint32_t decim, uint32_t
     return ssdr_compile_params_host(p, consts, taps, decim, rate);
 }
 
-static int zoom_restart(ssdr_ctx *c, uint32_t first, uint32_t count);
-
 int ssdr_set_decimation(ssdr_ctx *c, uint32_t decim)
 {
     if (!c || (decim != 1 && decim != 2 && decim != 4)) return SSDR_EINVAL;
@@ -497,7 +497,7 @@ int ssdr_set_hop(ssdr_ctx *c, uint32_t hop)
 }
 
 // the zoom centres as NCO steps at the current input rate; the zoom streams restart (phase, history, averaging group)
-static int zoom_restart(ssdr_ctx *c, uint32_t first, uint32_t count)
+static int zoom_restart(ssdr_ctx *c, uint32_t first, uint32_t count, bool restart_group)
 {
     if (c->zoom <= 1 || !c->d_zoom_dphi || !count) return SSDR_OK;
     const double fs_in = (double)c->kiwi_rate * c->decim;
@@ -512,7 +512,7 @@ static int zoom_restart(ssdr_ctx *c, uint32_t first, uint32_t count)
     HIP_TRY(hipMemsetAsync(c->d_zoom_phase + first, 0, count * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_zoom_hist + (size_t)first * SSDR_ZOOM_HIST, 0, (size_t)count * SSDR_ZOOM_HIST * 4, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->wf_phase = 0;
+    if (restart_group) c->wf_phase = 0;
     return SSDR_OK;
 }
 

@@ -1297,9 +1297,15 @@ def test_waterfall_zoom_bit_exact_vs_twin_and_oracle(S, twin, Z, hop, n_avg, dec
             eng.push_iq(iq[:2, 4096:8192])
             eng.run_wf()
             z2 = eng.read_zoom()
+            eng.reset_state()                                    # the zoomed streams restart with the others; the centres stay
+            eng.push_iq(iq[:2, :4096])
+            eng.run_wf()
+            z3 = eng.read_zoom()
         d2 = np.array([O._dphi(1000.0, fs_in), O._dphi(2000.0, fs_in)], np.uint32)
         ph, hist = np.zeros(2, np.uint32), np.zeros((2, 256, 2), np.int16)
         t0 = twin.zoom(iq[:2, :8192], 2, np.array([d2[0], d2[0]], np.uint32), O.zoom_taps(2), ph, hist)[0, 2048:]
         ph, hist = np.zeros(1, np.uint32), np.zeros((1, 256, 2), np.int16)
         t1 = twin.zoom(iq[1:2, 4096:8192], 2, d2[1:], O.zoom_taps(2), ph, hist)[0]
         assert np.array_equal(z2[0], t0) and np.array_equal(z2[1], t1)
+        ph, hist = np.zeros(2, np.uint32), np.zeros((2, 256, 2), np.int16)
+        assert np.array_equal(z3, twin.zoom(iq[:2, :4096], 2, d2, O.zoom_taps(2), ph, hist))
