@@ -408,7 +408,6 @@ SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, cons
     int16_t *dst = a.pcm + (uint64_t)ch * a.n_frames * SSDR_FRAME + 8 * l;
     float *rssi_row = a.rssi + (uint64_t)ch * a.n_frames;
     uint8_t *flag_row = a.flags + (uint64_t)ch * a.n_frames;
-    uint32_t rw[NB];
     float rssi_sum = 0.0f;
     uint32_t flag_keep = 0;
 
@@ -417,6 +416,7 @@ SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, cons
             nco_frame_table(n1, phi1, l, SSDR_FRAME * D);
             if (mode >= SSDR_MODE_LSB && mode <= SSDR_MODE_CW) nco_frame_table(n2, phi2, l);
         }
+        uint32_t rw[NB];
 #pragma unroll
         for (int i = 0; i < NB / 4; i++) {
             const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src) + i);
@@ -424,16 +424,22 @@ SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, cons
         }
         float p[8], aud[8], yr[8], yi[8];
         {
-            float2 Z[NB];
             float amax = 0.0f, bc, bs;
             nco_block(n1, f, bc, bs);
-            mix8<true, NB>(rw, bc, bs, cs1, ss1, Z, amax);
+            // eight inputs at a time: input 8 sb + t belongs to stream (t mod D), element (8 sb + t) / D of the lane's octet there;
+            // a sub-block fills 8 / D consecutive elements of every stream (only 8 mixed samples are ever live: 4 waves per SIMD)
+            constexpr int EPS = 8 / D;                       // elements per stream and sub-block (2 at D = 4, 4 at D = 2)
 #pragma unroll
-            for (int q = 0; q < D; q++) {
-                float2 V[8];
+            for (int sb = 0; sb < D; sb++) {
+                float2 Z8[8];
+                mix8_carry<true>(rw + 8 * sb, bc, bs, cs1, ss1, Z8, amax);
 #pragma unroll
-                for (int j = 0; j < 8; j++) V[j] = Z[D * j + q];
-                store_oct(s_z + q * ROCT * OCT, HOCT_S + l, V);
+                for (int q = 0; q < D; q++) {
+                    float4 *dstq = reinterpret_cast<float4 *>(s_z + q * ROCT * OCT + (HOCT_S + l) * OCT + EPS * sb);
+#pragma unroll
+                    for (int u = 0; u < EPS; u += 2)
+                        dstq[u >> 1] = make_float4(Z8[q + D * u].x, Z8[q + D * u].y, Z8[q + D * (u + 1)].x, Z8[q + D * (u + 1)].y);
+                }
             }
             lds_sync();
             const bool clip = wave_any(amax >= 32767.0f);
@@ -492,10 +498,12 @@ SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, cons
     }
 
     if (a.n_frames) {
-        if (l >= 64 - TAIL_LANES) {                              // raw tail of the last frame: 128 input samples
+        if (l >= 64 - TAIL_LANES) {                              // raw tail of the last frame: 128 input samples, read once more
+            // (not kept in the frame loop's registers: 8 D of them per lane would be live across the whole filter)
+            const u32x4 *lp = reinterpret_cast<const u32x4 *>(src - SSDR_FRAME * D);
             u32x4 *hp = reinterpret_cast<u32x4 *>(hist + NB * (l - (64 - TAIL_LANES)));
 #pragma unroll
-            for (int i = 0; i < NB / 4; i++) hp[i] = u32x4{rw[4 * i], rw[4 * i + 1], rw[4 * i + 2], rw[4 * i + 3]};
+            for (int i = 0; i < NB / 4; i++) hp[i] = lp[i];
         }
         if (l == 0) {
             st.phi1 = phi1; st.phi2 = phi2; st.dc = dc; st.agc_d = agc_d;

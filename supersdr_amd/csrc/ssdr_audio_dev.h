@@ -149,6 +149,22 @@ SSDR_DEV void mix8(const uint32_t (&rw)[N], float c, float s, float cs, float ss
     }
 }
 
+// the same on eight samples with the running phasor handed back: a lane's 8 D inputs in front of a decimating filter are
+// mixed eight at a time (the rotation chain is one and the same, so the values are those of mix8<CLIP, 8 D>)
+template <bool CLIP>
+SSDR_DEV void mix8_carry(const uint32_t *rw, float &c, float &s, float cs, float ss, float2 (&z)[8], float &amax)
+{
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const float xr = (float)(int16_t)(rw[j] & 0xFFFFu);
+        const float xi = (float)((int32_t)rw[j] >> 16);
+        if (CLIP) amax = vmax3_abs(amax, xr, xi);
+        z[j] = make_float2(fmaf(xr, c, xi * s), fmaf(xi, c, -(xr * s)));
+        const float cn = fmaf(c, cs, -(s * ss)), sn = fmaf(s, cs, c * ss);
+        c = cn; s = sn;
+    }
+}
+
 SSDR_DEV void load_oct(const float2 *z, int q, float2 (&v)[8])
 {
     const float4 *p = reinterpret_cast<const float4 *>(z + q * OCT);
