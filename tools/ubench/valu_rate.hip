@@ -13,6 +13,7 @@ __global__ void k(float *out, int iters)
 {
     f2 a[8], b = {1.0001f, 0.9999f}, c = {0.5f, 0.25f};
     for (int i = 0; i < 8; i++) a[i] = f2{(float)threadIdx.x + i, (float)i};
+    unsigned long long mask = __ballot(threadIdx.x & 1);
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int r = 0; r < REP / 8; r++) {
@@ -57,6 +58,23 @@ __global__ void k(float *out, int iters)
                 if (KIND == 36) asm volatile("v_fmac_f32 %0, %1, %2\n v_sqrt_f32 %3, %3" : "+v"(a[i].x), "+v"(a[(i + 4) & 7].y) : "v"(b.x), "v"(c.x));
                 if (KIND == 37) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
                 if (KIND == 38) asm volatile("v_rndne_f32 %0, %0" : "+v"(a[i].x));
+                if (KIND == 40) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "s"(mask));
+                if (KIND == 41) asm volatile("v_cmp_ge_f32 vcc, %1, %0\n s_nop 1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i].x) : "v"(b.x) : "vcc");
+                if (KIND == 42) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i].x) : "v"(b.x));
+                if (KIND == 43) asm volatile("v_cmp_ge_f32 vcc, %1, %0\n v_add_f32 %2, %2, %1\n v_add_f32 %3, %3, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i].x), "+v"(a[(i + 3) & 7].y), "+v"(a[(i + 5) & 7].y) : "v"(b.x) : "vcc");
+                if (KIND == 44) asm volatile("v_add_f32 %1, %1, %2\n v_add_f32 %0, %0, %2" : "+v"(a[i].x), "+v"(a[(i + 3) & 7].y) : "v"(b.x));
+                if (KIND == 45) asm volatile("s_nop 0");
+                if (KIND == 46) asm volatile("v_add_u32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "+v"(a[i].x) : "v"(b.x));
+                if (KIND == 47) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[i].x) : "v"(b.x), "v"(c.x));
+                if (KIND == 48) asm volatile("v_fmaak_f32 %0, %0, %1, 0x3f706e44" : "+v"(a[i].x) : "v"(b.x));
+                if (KIND == 49) asm volatile("v_mul_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i].x) : "v"(b.x));
+                if (KIND == 50) asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(a[i].x) : "v"(b.x));
+                if (KIND == 51) asm volatile("v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(a[i].x) : : "vcc");
+                if (KIND == 52) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[i].x) : "v"(b.x), "v"(c.x));
+                if (KIND == 53) asm volatile("v_cmp_ge_f32_e64 s[20:21], %1, %0\n s_nop 1\n v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i].x) : "v"(b.x) : "s20", "s21");
+                if (KIND == 54) asm volatile("v_cmp_ge_f32_e64 s[20:21], %1, %0\n v_add_f32 %2, %2, %1\n v_add_f32 %3, %3, %1\n v_cndmask_b32_e64 %0, %0, %1, s[20:21]" : "+v"(a[i].x), "+v"(a[(i + 3) & 7].y), "+v"(a[(i + 5) & 7].y) : "v"(b.x) : "s20", "s21");
+                if (KIND == 55) asm volatile("v_cmp_ge_f32 vcc, %1, %0\n s_nop 1\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(a[i].x) : "v"(b.x) : "vcc");
+                if (KIND == 56) asm volatile("s_mov_b64 vcc, %2\n s_nop 3\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i].x) : "v"(b.x), "s"(mask) : "vcc");
                 if (KIND == 39) asm volatile("v_fma_f32 %0, %1, %2, %0\n v_cvt_f32_i32 %3, %3" : "+v"(a[i].x), "+v"(a[(i + 4) & 7].y) : "v"(b.x), "v"(c.x));
             }
         }
@@ -130,5 +148,22 @@ int main()
     run<36>("v_fmac_f32 + v_sqrt_f32 (pair)", d);
     run<39>("v_fma_f32 + v_cvt_f32_i32 (pair)", d);
     run<38>("v_rndne_f32", d);
+    run<40>("v_cndmask_b32_e64 sgpr mask", d);
+    run<50>("v_cndmask_b32_e64 vcc", d);
+    run<51>("v_addc_co_u32 vcc in/out", d);
+    run<52>("v_cndmask_b32 vcc, dst != src", d);
+    run<53>("v_cmp_e64 sgpr + s_nop 1 + v_cndmask_e64 (2 instr)", d);
+    run<54>("v_cmp_e64 sgpr + 2 v_add + v_cndmask_e64 (4 instr)", d);
+    run<55>("v_cmp vcc + s_nop 1 + v_addc (2 instr)", d);
+    run<56>("s_mov vcc + s_nop 3 + v_cndmask vcc (1 valu)", d);
+    run<41>("v_cmp + s_nop 1 + v_cndmask vcc (2 instr)", d);
+    run<42>("v_cndmask_b32 vcc (no clobber)", d);
+    run<43>("v_cmp + 2 v_add_f32 + v_cndmask (4 instr)", d);
+    run<44>("2 v_add_f32 (2 instr)", d);
+    run<45>("s_nop 0", d);
+    run<46>("v_add_u32_sdwa WORD_0", d);
+    run<47>("v_min3_u32", d);
+    run<48>("v_fmaak_f32", d);
+    run<49>("v_mul_f32_dpp row_shr:1", d);
     return 0;
 }
