@@ -68,10 +68,10 @@ RIDGE_FLOP_PER_BYTE = F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)          # 
 # filters' multiply-adds -- 512 per frame for 33 taps, 2000 for 125 at D = 4 -- are dynamic).
 # flops = 64 lanes x (instructions + FMA instructions).
 KERNEL_VALU = {
-    "ssdr_wf_kernel<false, false>": ("line", 1296 / 2, 0.60),
-    "ssdr_wf_kernel<true, false>": ("line", 1266 / 2, 0.60),
-    "ssdr_wf_kernel<false, true>": ("line", 1296 / 2, 0.60),
-    "ssdr_wf_kernel<true, true>": ("line", 1266 / 2, 0.60),
+    "ssdr_wf_kernel<false, false>": ("line", 1229 / 2, 0.62),
+    "ssdr_wf_kernel<true, false>": ("line", 1199 / 2, 0.62),
+    "ssdr_wf_kernel<false, true>": ("line", 1229 / 2, 0.62),
+    "ssdr_wf_kernel<true, true>": ("line", 1199 / 2, 0.62),
     "ssdr_audio_kernel<0>": ("frame", 832, 0.75),
     "ssdr_audio_kernel<1>": ("frame", 571, 0.42),
     "ssdr_audio_kernel<2>": ("frame", 286, 0.17),

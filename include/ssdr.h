@@ -70,7 +70,7 @@ typedef struct ssdr_chan_params {
     double agc_slope;           /* dB   (:940)                                          */
     double agc_decay;           /* ms   (:941-944)                                      */
     double agc_man_gain;        /* dB   (:942)                                          */
-    double wf_cal_db;           /* additive waterfall calibration                       */
+    double wf_cal_db;           /* additive waterfall calibration, within +-200 dB      */
     double smeter_cal_db;       /* dBFS->dBm offset (Kiwi default -13, :790)            */
 } ssdr_chan_params;
 

@@ -45,7 +45,7 @@ struct ssdr_ctx {
     uint32_t zoom_run_samples = 0;                      // zoomed samples per channel of the last ssdr_run_wf
     double2 *d_tw64 = nullptr;                          // [512] e^{-2 pi j m / 1024} in double
     float2 *d_tw = nullptr;
-    uint2 *d_lut = nullptr;
+    uint32_t *d_lut = nullptr;
     // per-channel
     ssdr_chan_consts *d_consts = nullptr;
     float *d_taps = nullptr;
@@ -387,7 +387,7 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         HIP_TRY(hipMalloc(&c->d_win, SSDR_NFFT * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_thr, 256 * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_tw, SSDR_TW_STAGE_N * sizeof(float2)));
-        HIP_TRY(hipMalloc(&c->d_lut, SSDR_LUT_N * sizeof(uint2)));
+        HIP_TRY(hipMalloc(&c->d_lut, SSDR_LUT_N * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_consts, (size_t)n_channels * sizeof(ssdr_chan_consts)));
         HIP_TRY(hipMalloc(&c->d_taps, (size_t)n_channels * SSDR_NTAP_MAX * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_state, (size_t)n_channels * sizeof(ssdr_chan_state)));
@@ -411,9 +411,9 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         HIP_TRY(hipMemcpy(c->d_win, win.data(), win.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_thr, thr.data(), thr.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(c->d_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
-        std::vector<uint2> lut(SSDR_LUT_N);
+        std::vector<uint32_t> lut(SSDR_LUT_N);
         if (ssdr_make_quant_lut(lut.data()) != 0) return SSDR_EINVAL;
-        HIP_TRY(hipMemcpy(c->d_lut, lut.data(), lut.size() * sizeof(uint2), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_lut, lut.data(), lut.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         hipDeviceProp_t prop;
         HIP_TRY(hipGetDeviceProperties(&prop, device_id));
         int per_cu = 0;

@@ -14,15 +14,15 @@
 #define SSDR_WF_ABLATE 0                     // profiling ablations only (1 memory-only, 2 no loads, 3 no stores)
 #endif
 #define SSDR_TW_STAGE_N 992                  // per-stage twiddle table entries: 32*(1+2+4+8+16)
-// dB quantiser table: one entry per quarter-octave segment of [2^-37, 2^50] (0.75 dB < 1 dB: at most one threshold
-// inside a segment), indexed by bits(p) >> (23 - SSDR_LUT_BITS): shift + and, 2.8 KB.  (A 16-segment-per-octave table
-// indexed by one SDWA op was measured slower: 9x LDS bank conflicts, profiles/README.md.)
+// dB quantiser table: one 32-bit word per quarter-octave segment of [0, 1] (0.75 dB < 1 dB: at most one threshold
+// inside a segment), indexed by bits(p') >> (23 - SSDR_LUT_BITS) where p' = p * 2^-48 clamped to [0, 1] (the top
+// threshold T[255] = 2^48 lands on 1.0, the clamp rides on the multiply): byte = (bits(p') + word) >> 24, see
+// ssdr_wf.hip:quantise.  2 KB.  (A 16-segment-per-octave table indexed by one SDWA op was measured slower: 9x LDS
+// bank conflicts, profiles/README.md.)
 #define SSDR_LUT_BITS 2
-#define SSDR_LUT_PLO 0x1p-37f
-#define SSDR_LUT_PHI 0x1p50f
+#define SSDR_LUT_SCALE 0x1p-48f
 #define SSDR_LUT_SHIFT (23 - SSDR_LUT_BITS)
-#define SSDR_LUT_IDX0 (90 << SSDR_LUT_BITS)                      // bits(2^-37) >> SHIFT
-#define SSDR_LUT_N (((177 - 90) << SSDR_LUT_BITS) + 1)           // (bits(2^50) >> SHIFT) - IDX0 + 1
+#define SSDR_LUT_N ((127 << SSDR_LUT_BITS) + 1)                  // bits(1.0) >> SHIFT, + 1
 #define SSDR_AUDIO_BLOCK 64                  // one wave == one receiver channel
 
 struct SsdrWfArgs {
@@ -39,7 +39,7 @@ struct SsdrWfArgs {
     const ssdr_chan_consts *consts;          // [n_ch] (wf_cal_lin)
     const float *win;                        // [513]  first half of the symmetric window + midpoint
     const float2 *tw_stage;                  // [992]
-    const uint2 *lut;                        // [SSDR_LUT_N] quantiser segments: {count at lower edge, threshold inside or +inf}
+    const uint32_t *lut;                     // [SSDR_LUT_N] quantiser segment words (ssdr_make_quant_lut)
 };
 
 struct SsdrAudioArgs {
@@ -152,14 +152,14 @@ hipError_t ssdr_launch_audio_dec(const SsdrAudioArgs &a, uint32_t decim, hipStre
 hipError_t ssdr_launch_synth(const SsdrSynthArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_sqrt_selftest(unsigned long long *mismatch, hipStream_t stream);
 hipError_t ssdr_launch_sqrt_values(const float *in, float *out_scaled, float *out_int, uint32_t n, hipStream_t stream);
-hipError_t ssdr_launch_quant_selftest(const float *thr, const uint2 *lut, unsigned long long *mismatch, hipStream_t stream);
+hipError_t ssdr_launch_quant_selftest(const float *thr, const uint32_t *lut, unsigned long long *mismatch, hipStream_t stream);
 
 // host-side tables and parameter compilation (ssdr_tables.cpp)
 void ssdr_make_window(float *win);                    // [1024]
 void ssdr_make_twiddles(float *wr, float *wi);        // [512] each
 void ssdr_make_tw_stage(float2 *tw);                  // [992]
 void ssdr_make_thresholds(float *thr);                // [256]
-int ssdr_make_quant_lut(uint2 *lut);                  // [SSDR_LUT_N]; returns 0, or -1 if a segment held two thresholds
+int ssdr_make_quant_lut(uint32_t *lut);               // [SSDR_LUT_N]; returns 0, or -1 if a segment held two thresholds
 int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps, uint32_t decim, uint32_t rate_hz = SSDR_RATE);
 int ssdr_design_lowpass(double fl, double fs, int n_max, double *h);   // utils_supersdr.py:334-344; returns tap count
 int ssdr_design_lowpass_exact(double fl, double fs, int n, double *h);  // the same window and sinc with exactly n (odd) taps

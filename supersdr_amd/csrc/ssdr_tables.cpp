@@ -45,25 +45,30 @@ void ssdr_make_thresholds(float *thr)
     for (int k = 0; k < 256; k++) thr[k] = (float)(std::pow(10.0, (k - 255) / 10.0) * 281474976710656.0 /* 2^48 */);
 }
 
-// Quantiser segments (see ssdr_wf.hip:quantise): segment i holds the floats p with
-// (bits(p) >> SSDR_LUT_SHIFT) == SSDR_LUT_IDX0 + i; entry = {#{k>=1 : T[k] <= lower edge}, the threshold inside the
-// segment or +inf}.  A segment is narrower than 1 dB, so it never holds two thresholds (checked).
-int ssdr_make_quant_lut(uint2 *lut)
+// Quantiser segments (see ssdr_wf.hip:quantise).  The kernel looks at p' = p * 2^-48 clamped to [0, 1]; segment i holds
+// the floats with (bits(p') >> SSDR_LUT_SHIFT) == i.  With base = #{k>=1 : T'[k] <= lower edge} (T' = T * 2^-48, exact)
+// and t = the bits of the one threshold inside the segment (or of its upper edge if there is none), the word is
+//     (base << 24) + 2^24 - t        (mod 2^32)
+// so that bits(p') + word = ((base + 1) << 24) + (bits(p') - t): the top byte is base + 1 from the threshold on and
+// base below it (|bits(p') - t| <= 2^21 inside the segment).  A segment is narrower than 1 dB, so it never holds two
+// thresholds (checked).
+int ssdr_make_quant_lut(uint32_t *lut)
 {
     float thr[256];
     ssdr_make_thresholds(thr);
+    for (int k = 0; k < 256; k++) thr[k] *= SSDR_LUT_SCALE;
     for (int i = 0; i < SSDR_LUT_N; i++) {
-        const uint32_t lo_bits = (uint32_t)(SSDR_LUT_IDX0 + i) << SSDR_LUT_SHIFT;
+        const uint32_t lo_bits = (uint32_t)i << SSDR_LUT_SHIFT;
         const uint32_t hi_bits = lo_bits + (1u << SSDR_LUT_SHIFT);
         float lo, hi;
         std::memcpy(&lo, &lo_bits, 4);
         std::memcpy(&hi, &hi_bits, 4);
         uint32_t base = 0;
         for (int k = 1; k < 256; k++) base += (thr[k] <= lo) ? 1u : 0u;
-        uint32_t next_bits = 0x7F800000u;                       // +inf: no threshold inside
-        if (base < 255 && thr[base + 1] < hi) std::memcpy(&next_bits, &thr[base + 1], 4);
+        uint32_t t_bits = hi_bits;                              // no threshold inside: never reached
+        if (base < 255 && thr[base + 1] < hi) std::memcpy(&t_bits, &thr[base + 1], 4);
         if (base < 254 && thr[base + 2] < hi) return -1;
-        lut[i] = make_uint2(base, next_bits);
+        lut[i] = (base << 24) + (1u << 24) - t_bits;
     }
     return 0;
 }
@@ -125,6 +130,8 @@ int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, flo
     // the tuning offset must lie inside the IQ band: beyond +-fs/2 the NCO step wraps mod 2^32 and the channel would
     // silently demodulate an alias
     if (!(std::fabs(p->f_shift_hz) <= fs_in / 2.0)) return SSDR_EINVAL;
+    // the waterfall quantiser scales the calibration factor by 2^-48 (ssdr_wf.hip:quantise): it must stay a normal float
+    if (!(std::fabs(p->wf_cal_db) <= 200.0)) return SSDR_EINVAL;
     std::memset(c, 0, sizeof *c);
     double f_bc, fl;
     if (p->mode >= SSDR_MODE_LSB && p->mode <= SSDR_MODE_CW) {

@@ -44,16 +44,15 @@ constexpr int WAVES = SSDR_WF_BLOCK / 64;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// LDS map of the waterfall kernel (one allocation starting at LDS address 0, so that the quantiser's
-// table index IS the LDS address: entry i of the table lives at byte 8*i, i = bits(p) >> SSDR_LUT_SHIFT):
-//   window (513 floats: first half + midpoint, w[n] = w[1024-n]), per-stage twiddles for FFT stages
-//   6..10 (992 float2), quantiser table, then the per-wave transpose / staging buffers (2 x 4224 B).
-constexpr int LDS_LUT0 = SSDR_LUT_IDX0 * 8;                     // address of the first stored entry
-constexpr int LDS_LUT_END = LDS_LUT0 + SSDR_LUT_N * 8;
-constexpr int LDS_WIN = 0;                                      // [0, 2064)       table at [2880, 5672)
-constexpr int LDS_TW = (LDS_LUT_END + 15) & ~15;                // [5680, 13616)
+// LDS map of the waterfall kernel (one allocation starting at LDS address 0):
+//   window (513 floats: first half + midpoint, w[n] = w[1024-n]), quantiser table (its constant base rides in the
+//   DS instruction's offset field), per-stage twiddles for FFT stages 6..10 (992 float2), then the per-wave
+//   transpose / staging buffers (2 x 4224 B).
+constexpr int LDS_WIN = 0;                                      // [0, 2064)
+constexpr int LDS_LUT0 = 2064;                                  // [2064, 4100)
+constexpr int LDS_LUT_END = LDS_LUT0 + SSDR_LUT_N * 4;
+constexpr int LDS_TW = (LDS_LUT_END + 15) & ~15;                // [4112, 12048)
 constexpr int LDS_XCH = LDS_TW + SSDR_TW_STAGE_N * 8;
-static_assert(LDS_WIN + 2064 <= LDS_LUT0, "tables overlap");
 constexpr int LDS_TOTAL = LDS_XCH + WAVES * 2 * XCH_FLOATS * 4;
 static_assert(LDS_XCH % 16 == 0 && LDS_TW % 8 == 0, "alignment");
 static_assert(LDS_TOTAL <= 163840, "LDS budget");
@@ -158,36 +157,40 @@ SSDR_DEV void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// dB quantiser: byte = #{k in 1..255 : T[k] <= p}, exactly, without a logarithm.
-// A float's top bits (sign, exponent, SSDR_LUT_BITS mantissa bits) name a segment narrower than 1 dB;
-// a segment contains at most one 1-dB threshold, so the host tabulates per segment the count at
-// its lower edge and the one threshold that may lie inside it (+inf if none):
-//     byte = lut[seg].base + (p >= lut[seg].next)
-// p is clamped to [2^-37, 2^50] (below T[1] / above T[255]).  The table sits in LDS such that the
-// segment index scaled by the entry size is the LDS address.
-// Split in two so that the table reads of a whole batch are in flight together (and the next batch's are
-// issued before this batch's compares): quant_addr -> load -> quant_result.
-SSDR_DEV float quant_clamp(float p) { return __builtin_amdgcn_fmed3f(p, SSDR_LUT_PLO, SSDR_LUT_PHI); }
-SSDR_DEV uint32_t quant_addr(float pc, uint32_t mask)
+// dB quantiser: byte = #{k in 1..255 : T[k] <= p}, exactly, without a logarithm, a compare or a select.
+// p arrives scaled by 2^-48 (exact; the calibration factor carries it) and clamped to [0, 1] by the multiply that
+// produced it: T[255] = 2^48 is 1.0 there, everything below T[1] (zero and denormals included) sits in segments that
+// count 0.  A float's top bits (exponent, SSDR_LUT_BITS mantissa bits) name a segment narrower than 1 dB; a segment
+// contains at most one 1-dB threshold, and the host tabulates per segment one word (ssdr_tables.cpp:ssdr_make_quant_lut)
+// such that
+//     byte = (bits(p') + word[segment]) >> 24
+// -- the distance of p' from the threshold carries into the count.  Split in two so that the table reads of a whole
+// batch are in flight together (and the next batch's are issued before this batch's adds): quant_addr -> load ->
+// quant_word; the callers take the top bytes out pairwise with one v_perm_b32.
+SSDR_DEV float quant_scaled_power(f32x2 z, float calq)
 {
-    return (__float_as_uint(pc) >> (SSDR_LUT_SHIFT - 3)) & mask;            // mask = ~7
+    float p = fmaf(z.x, z.x, z.y * z.y), pc;
+    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(pc) : "v"(p), "v"(calq));
+    return pc;
 }
-SSDR_DEV uint32_t quant_result(float pc, uint2 e) { return e.x + ((pc >= __uint_as_float(e.y)) ? 1u : 0u); }
-SSDR_DEV uint32_t quantise(float p, const unsigned char *lut0, uint32_t mask)
+SSDR_DEV uint32_t quant_addr(float pc) { return (__float_as_uint(pc) >> (SSDR_LUT_SHIFT - 2)) & ~3u; }
+SSDR_DEV uint32_t quant_word(float pc, uint32_t w) { return __float_as_uint(pc) + w; }
+// bytes of two words -> byte(w0) | byte(w1) << 16
+SSDR_DEV uint32_t quant_pair(uint32_t w0, uint32_t w1) { return __builtin_amdgcn_perm(w1, w0, 0x0C070C03u); }
+SSDR_DEV uint32_t quantise(float p_scaled_clamped, const unsigned char *lut)
 {
-    const float pc = quant_clamp(p);
-    return quant_result(pc, *reinterpret_cast<const uint2 *>(lut0 + quant_addr(pc, mask)));
+    return quant_word(p_scaled_clamped, *reinterpret_cast<const uint32_t *>(lut + quant_addr(p_scaled_clamped))) >> 24;
 }
 
 // power + quantiser for the 32 bins of a lane, in 4 batches of 8 (bins 0-7, 16-23, 8-15, 24-31) with the table
 // reads software-pipelined one batch ahead and no LDS store in between, so nothing orders one look-up behind
-// another.  `sink(j, byte_j, byte_{j+16})` receives the results pairwise (j = 0..15).
+// another.  `sink(j, byte_j | byte_{j+16} << 16)` receives the results pairwise (j = 0..15).
 template <typename Sink>
-SSDR_DEV void quantise32(const f32x2 (&z)[32], float cal, const unsigned char *lut0, uint32_t mask, Sink sink)
+SSDR_DEV void quantise32(const f32x2 (&z)[32], float calq, const unsigned char *lut, Sink sink)
 {
     constexpr int ORDER[4] = {0, 16, 8, 24};
     float pc[2][8];
-    uint2 e[2][8];
+    uint32_t e[2][8];
     uint32_t lo[8];
 #pragma unroll
     for (int b = 0; b < 5; b++) {
@@ -195,8 +198,8 @@ SSDR_DEV void quantise32(const f32x2 (&z)[32], float cal, const unsigned char *l
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int j = ORDER[b] + i;
-                pc[b & 1][i] = quant_clamp(fmaf(z[j].x, z[j].x, z[j].y * z[j].y) * cal);
-                e[b & 1][i] = *reinterpret_cast<const uint2 *>(lut0 + quant_addr(pc[b & 1][i], mask));
+                pc[b & 1][i] = quant_scaled_power(z[j], calq);
+                e[b & 1][i] = *reinterpret_cast<const uint32_t *>(lut + quant_addr(pc[b & 1][i]));
             }
         }
         SCHED_FENCE();
@@ -204,9 +207,9 @@ SSDR_DEV void quantise32(const f32x2 (&z)[32], float cal, const unsigned char *l
             const int pb = b - 1;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const uint32_t r = quant_result(pc[pb & 1][i], e[pb & 1][i]);
+                const uint32_t r = quant_word(pc[pb & 1][i], e[pb & 1][i]);
                 if ((pb & 1) == 0) lo[i] = r;                       // bins j (batch 0 or 2)
-                else sink(ORDER[pb - 1] + i, lo[i], r);             // bins j+16 arrive one batch later
+                else sink(ORDER[pb - 1] + i, quant_pair(lo[i], r)); // bins j+16 arrive one batch later
             }
         }
     }
@@ -374,11 +377,11 @@ SSDR_DEV WfItem wf_item(const SsdrWfArgs &a, uint32_t item, uint32_t n_pairs, in
     return it;
 }
 
-SSDR_DEV void load_tables(unsigned char *smem, const float *win, const float2 *tw, const uint2 *lut)
+SSDR_DEV void load_tables(unsigned char *smem, const float *win, const float2 *tw, const uint32_t *lut)
 {
     float *s_win = reinterpret_cast<float *>(smem + LDS_WIN);
     f32x2 *s_tw = reinterpret_cast<f32x2 *>(smem + LDS_TW);
-    uint2 *s_lut = reinterpret_cast<uint2 *>(smem + LDS_LUT0);
+    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + LDS_LUT0);
     for (int i = threadIdx.x; i < 513; i += blockDim.x) s_win[i] = win[i];
     for (int i = threadIdx.x; i < SSDR_TW_STAGE_N; i += blockDim.x) s_tw[i] = f32x2{tw[i].x, tw[i].y};
     for (int i = threadIdx.x; i < SSDR_LUT_N; i += blockDim.x) s_lut[i] = lut[i];
@@ -397,8 +400,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, l = lane & 31;
     float *xch_wave = reinterpret_cast<float *>(smem + LDS_XCH) + wave * 2 * XCH_FLOATS;      // wave-uniform
-    const uint32_t lut_mask = ~7u;
-    const unsigned char *lut0 = smem;
+    const unsigned char *lut = smem + LDS_LUT0;
     const uint32_t n_pairs = (a.n_ch + 1) >> 1;
     const uint32_t n_items = n_pairs * a.n_groups;
     const uint32_t wave_stride = gridDim.x * WAVES;
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
     for (uint32_t item = blockIdx.x * WAVES + wave; item < n_items; item += wave_stride) {
 #endif
         const WfItem it = wf_item<HOP>(a, item, n_pairs, h);
-        const float cal = a.consts[it.ch].wf_cal_lin;
+        const float calq = a.consts[it.ch].wf_cal_lin * SSDR_LUT_SCALE;
         uint32_t acc[AVG ? 16 : 1];
 #pragma unroll
         for (int j = 0; j < (AVG ? 16 : 1); j++) acc[j] = 0;
@@ -440,10 +442,10 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
 
             // |X|^2 -> 1-dB byte; bin k = 32 j + l lands at fftshifted position 32 ((j+16)&31) + l
             if (AVG) {
-                quantise32(z, cal, lut0, lut_mask, [&](int j, uint32_t q0, uint32_t q1) { acc[j] += q0 + (q1 << 16); });
+                quantise32(z, calq, lut, [&](int j, uint32_t q01) { acc[j] += q01; });
             } else {
                 uint32_t q[16];                                     // bins j | j+16, written out after the last look-up
-                quantise32(z, cal, lut0, lut_mask, [&](int j, uint32_t q0, uint32_t q1) { q[j] = q0 | (q1 << 16); });
+                quantise32(z, calq, lut, [&](int j, uint32_t q01) { q[j] = q01; });
                 int16_t *x16 = reinterpret_cast<int16_t *>(xch_wave + opaque(h) * XCH_FLOATS) + opaque(l);
 #pragma unroll
                 for (int j = 0; j < 16; j++) {
@@ -501,8 +503,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
     const int h = lane >> 5, l = lane & 31;
     float *xch_wave = reinterpret_cast<float *>(smem + LDS_XCH) + wave * 2 * XCH_FLOATS;
     uint32_t *qbuf = reinterpret_cast<uint32_t *>(xch_wave);                 // [2][XCH_FLOATS]: powers of the two channels' line
-    const uint32_t lut_mask = ~7u;
-    const unsigned char *lut0 = smem;
+    const unsigned char *lut = smem + LDS_LUT0;
     const uint32_t n_pairs = (a.n_ch + 1) >> 1;
     const uint32_t wave_stride = gridDim.x * WAVES;
     const uint32_t n_frames = u.n_frames;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
         const uint32_t ch_raw = 2 * pair + h;
         const bool ch_ok = ch_raw < a.n_ch;
         const uint32_t ch = ch_ok ? ch_raw : a.n_ch - 1;
-        const float cal_wf = a.consts[ch].wf_cal_lin;
+        const float cal_wf = a.consts[ch].wf_cal_lin * SSDR_LUT_SCALE;
         const uint32_t n_sub = (2 * pair + 1 < a.n_ch) ? 2u : 1u;           // channels of this pair that exist
 
         // The audio chain's carried state of both channels (wave-uniform: 14 words per channel) does not stay in registers
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
             SCHED_FENCE();
             fft_line<false>(z, smem, xch_wave, h, l);
             uint32_t qn[16];
-            quantise32(z, cal_wf, lut0, lut_mask, [&](int j, uint32_t q0, uint32_t q1) { qn[j] = q0 | (q1 << 16); });
+            quantise32(z, cal_wf, lut, [&](int j, uint32_t q01) { qn[j] = q01; });
             float *xch = xch_wave + opaque(h) * XCH_FLOATS;
             int16_t *x16 = reinterpret_cast<int16_t *>(xch) + opaque(l);
 #pragma unroll
@@ -681,18 +682,19 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
     }
 }
 
-// exhaustive quantiser self-test: every positive finite float against a binary search over T[]
-__global__ __launch_bounds__(256) void ssdr_quant_selftest_kernel(const float *thr_g, const uint2 *lut,
+// exhaustive quantiser self-test: every positive finite float p, scaled and clamped as the kernel does it, against a
+// binary search over T[] with the unscaled p
+__global__ __launch_bounds__(256) void ssdr_quant_selftest_kernel(const float *thr_g, const uint32_t *lut_g,
                                                                     unsigned long long *mismatch)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_LUT_END + 16 + 1024];
     float *s_thr = reinterpret_cast<float *>(smem + ((LDS_LUT_END + 15) & ~15));
-    uint2 *s_lut = reinterpret_cast<uint2 *>(smem + LDS_LUT0);
+    uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + LDS_LUT0);
     for (int i = threadIdx.x; i < 256; i += blockDim.x) s_thr[i] = thr_g[i];
-    for (int i = threadIdx.x; i < SSDR_LUT_N; i += blockDim.x) s_lut[i] = lut[i];
+    for (int i = threadIdx.x; i < SSDR_LUT_N; i += blockDim.x) s_lut[i] = lut_g[i];
     __syncthreads();
     unsigned long long bad = 0;
-    const uint32_t lut_mask = ~7u;
+    const unsigned char *lut = smem + LDS_LUT0;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < 0x7F800000ull; u += stride) {
         const float p = __uint_as_float((uint32_t)u);
@@ -701,7 +703,9 @@ __global__ __launch_bounds__(256) void ssdr_quant_selftest_kernel(const float *t
             const int mid = (lo + hi + 1) >> 1;
             if (s_thr[mid] <= p) lo = mid; else hi = mid - 1;
         }
-        bad += (quantise(p, smem, lut_mask) != (uint32_t)lo);
+        float pc;
+        asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(pc) : "v"(p), "v"(SSDR_LUT_SCALE));
+        bad += (quantise(pc, lut) != (uint32_t)lo);
     }
     if (bad) atomicAdd(mismatch, bad);
 }
@@ -746,7 +750,7 @@ hipError_t ssdr_wf_blocks_per_cu(int *blocks)
     return hipSuccess;
 }
 
-hipError_t ssdr_launch_quant_selftest(const float *thr, const uint2 *lut, unsigned long long *mismatch, hipStream_t stream)
+hipError_t ssdr_launch_quant_selftest(const float *thr, const uint32_t *lut, unsigned long long *mismatch, hipStream_t stream)
 {
     hipLaunchKernelGGL(ssdr_quant_selftest_kernel, dim3(2048), dim3(256), 0, stream, thr, lut, mismatch);
     return hipGetLastError();
