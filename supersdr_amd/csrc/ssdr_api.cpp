@@ -782,6 +782,7 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
     a.n_avg = c->n_avg;
     a.phase = c->wf_phase;
     a.n_groups = n_groups;
+    a.grp_run = 1;
     a.out = c->d_wf_out;
     a.acc_in = c->d_wf_acc[c->wf_acc_cur];
     a.acc_out = c->d_wf_acc[c->wf_acc_cur ^ 1];
@@ -789,9 +790,18 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
     a.win = c->d_win;
     a.tw_stage = c->d_tw;
     a.lut = c->d_lut;
-    const uint64_t items = (uint64_t)((c->n_ch + 1) / 2) * n_groups;
-    const uint64_t need = (items + SSDR_WF_BLOCK / 64 - 1) / (SSDR_WF_BLOCK / 64);
+    uint64_t items = (uint64_t)((c->n_ch + 1) / 2) * n_groups;
     const uint32_t wf_grid = c->concurrent ? c->wf_grid_1 : c->wf_grid;
+    if (hop512 && n_groups) {
+        // a wave works through a run of consecutive groups of its channel pair, so the half-line two lines share is read
+        // again by the wave that fetched it one line earlier; runs as long as still leave every resident wave ~8 items
+        const uint64_t waves = (uint64_t)(wf_grid ? wf_grid : 1) * (SSDR_WF_BLOCK / 64);
+        uint64_t run = items / (8 * waves);
+        run = run < 1 ? 1 : (run > n_groups ? n_groups : run);
+        a.grp_run = (uint32_t)run;
+        items = (uint64_t)((c->n_ch + 1) / 2) * ((n_groups + run - 1) / run);
+    }
+    const uint64_t need = (items + SSDR_WF_BLOCK / 64 - 1) / (SSDR_WF_BLOCK / 64);
     const uint32_t grid = (uint32_t)(need < wf_grid ? need : wf_grid);
     int rc;
     if (c->fuse_next) {                      // the fused superframe kernel does this stage's work: ssdr_run_audio launches it

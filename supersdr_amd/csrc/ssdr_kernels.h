@@ -32,6 +32,7 @@ struct SsdrWfArgs {
     const uint32_t *tail;                    // hop 512: [n_ch][512] the half-line before the batch (null: hop 1024)
     uint32_t n_avg, phase;                   // averaging N; lines already summed in `acc`
     uint32_t n_groups;                       // averaging groups touched by this batch
+    uint32_t grp_run;                        // hop 512: consecutive groups of a channel pair one wave works through (>= 1)
     int16_t *out;                            // [n_complete_groups][n_ch][1024]
     const int16_t *acc_in;                   // [n_ch][1024] partial sums carried in from the previous call
     int16_t *acc_out;                        // [n_ch][1024] partial sums carried out (a different buffer: other

@@ -220,13 +220,13 @@ SSDR_DEV void load_line(const uint32_t *__restrict__ src /* + lane */, uint32_t 
 #pragma unroll
     for (int r = 0; r < 32; r++) raw[r] = __builtin_nontemporal_load(src + 32 * r);
 }
-// hop 512: a line is the previous half-line followed by a new one.  The older half is the neighbouring line's newer
-// half: the wave next door (work items of a channel pair are adjacent, see wf_item) loads it at about the same time, so
-// one of the two reads is served by the L2 -- plain loads, not non-temporal ones.
+// hop 512: a line is the previous half-line followed by a new one.  The older half is the previous line's newer half,
+// which this very wave fetched one line earlier (a wave walks a run of consecutive lines of its channel pair, see the
+// item loop of ssdr_wf_kernel): the second read is served by the L2 -- plain loads, not non-temporal ones.
 SSDR_DEV void load_line_halves(const uint32_t *__restrict__ older, const uint32_t *__restrict__ newer, uint32_t (&raw)[32])
 {
 #pragma unroll
-    for (int r = 0; r < 16; r++) raw[r] = older[32 * r];
+    for (int r = 0; r < 16; r++) raw[r] = __builtin_nontemporal_load(older + 32 * r);        // its last use: do not keep it
 #pragma unroll
     for (int r = 0; r < 16; r++) raw[16 + r] = newer[32 * r];
 }
@@ -353,18 +353,10 @@ struct WfItem {                 // one (channel pair, averaging group) work item
     bool ch_ok, carry_in, complete;
 };
 
-template <bool HOP>
-SSDR_DEV WfItem wf_item(const SsdrWfArgs &a, uint32_t item, uint32_t n_pairs, int h)
+SSDR_DEV WfItem wf_item(const SsdrWfArgs &a, uint32_t pair, uint32_t grp, int h)
 {
     WfItem it;
-    uint32_t pair;
-    if (HOP || SSDR_WF_PAIR_MAJOR) { // groups of a channel pair side by side: neighbouring waves share a half-line
-        pair = item / a.n_groups;
-        it.grp = item - pair * a.n_groups;
-    } else {
-        it.grp = item / n_pairs;
-        pair = item - it.grp * n_pairs;
-    }
+    it.grp = grp;
     const uint32_t ch_raw = 2 * pair + h;
     it.ch_ok = ch_raw < a.n_ch;
     it.ch = it.ch_ok ? ch_raw : a.n_ch - 1;
@@ -402,7 +394,11 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
     float *xch_wave = reinterpret_cast<float *>(smem + LDS_XCH) + wave * 2 * XCH_FLOATS;      // wave-uniform
     const unsigned char *lut = smem + LDS_LUT0;
     const uint32_t n_pairs = (a.n_ch + 1) >> 1;
-    const uint32_t n_items = n_pairs * a.n_groups;
+    // work items: hop 1024 -- one (group, channel pair) each, group-major; hop 512 -- a run of a.grp_run consecutive groups
+    // of a channel pair, pair-major: the wave walks the pair's lines in order
+    const uint32_t run = (HOP || SSDR_WF_PAIR_MAJOR) ? a.grp_run : 1u;
+    const uint32_t n_runs = (a.n_groups + run - 1) / run;
+    const uint32_t n_items = n_pairs * n_runs;
     const uint32_t wave_stride = gridDim.x * WAVES;
 
 #if SSDR_WF_BLOCKED_ITEMS
@@ -413,7 +409,22 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
 #else
     for (uint32_t item = blockIdx.x * WAVES + wave; item < n_items; item += wave_stride) {
 #endif
-        const WfItem it = wf_item<HOP>(a, item, n_pairs, h);
+      uint32_t pair, g_begin, g_end;
+      if (HOP || SSDR_WF_PAIR_MAJOR) {
+          pair = item / n_runs;
+          g_begin = (item - pair * n_runs) * run;
+          g_end = min(g_begin + run, a.n_groups);
+      } else {
+          g_begin = item / n_pairs;
+          pair = item - g_begin * n_pairs;
+          g_end = g_begin + 1;
+      }
+      const uint32_t n_trips = (HOP || SSDR_WF_PAIR_MAJOR) ? g_end - g_begin : 1u;
+      for (uint32_t trip = 0; trip < n_trips; trip++) {
+        const uint32_t grp = g_begin + trip;
+        uint32_t pair_now = __builtin_amdgcn_readfirstlane(pair);   // everything derived from the pair is recomputed per group
+        asm volatile("" : "+s"(pair_now));      // (a few scalar ops) rather than hoisted into VGPRs that live across the whole FFT
+        const WfItem it = wf_item(a, pair_now, grp, h);
         const float calq = a.consts[it.ch].wf_cal_lin * SSDR_LUT_SCALE;
         uint32_t acc[AVG ? 16 : 1];
 #pragma unroll
@@ -478,6 +489,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
             if (it.ch_ok) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst) + q * 32 + l);
         }
         wave_lds_sync();
+      }
     }
 }
 
