@@ -568,8 +568,13 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
             // (plain loads here for that reason) -- one read from HBM, and no 32 registers held across the audio chain.
             {
                 uint32_t *q = qbuf + opaque(h) * XCH_FLOATS + opaque(l);
+                uint32_t t[32];                     // all 32 loads in flight, then their powers: left alone the compiler issues
+#pragma unroll                                      // load, wait, power one sample at a time -- 32 round trips to memory per line
+                for (int r = 0; r < 32; r++) t[r] = src[32 * r];
+                SCHED_FENCE();
 #pragma unroll
-                for (int r = 0; r < 32; r++) q[32 * r] = iq_power(src[32 * r]);
+                for (int r = 0; r < 32; r++) q[32 * r] = iq_power(t[r]);
+                SCHED_FENCE();
             }
             wave_lds_sync();
             // ---- audio, phase 2: channel A, then channel B, two frames each, all 64 lanes on one channel
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
             f32x2 z[32];
             window_line(raw, smem, l, z);
             SCHED_FENCE();
-            fft_line<false>(z, smem, xch_wave, h, l);
+            fft_line<true>(z, smem, xch_wave, h, l);          // the averaging kernel's twiddle schedule: fewer registers in flight
             uint32_t qn[16];
             quantise32(z, cal_wf, lut, [&](int j, uint32_t q01) { qn[j] = q01; });
             float *xch = xch_wave + opaque(h) * XCH_FLOATS;
