@@ -54,8 +54,9 @@ SSDR_DEV uint32_t from_prev_lane_u(uint32_t lane0_value, uint32_t x)
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 SSDR_DEV uint32_t iq_power(uint32_t raw)
 {
-    const s16x2 v = __builtin_bit_cast(s16x2, raw);
-    return (uint32_t)__builtin_amdgcn_sdot2(v, v, 0, false);
+    uint32_t p;                                     // the three-operand form with a literal 0: the compiler's choice, the
+    asm("v_dot2_i32_i16 %0, %1, %1, 0" : "=v"(p) : "v"(raw));      // accumulating v_dot2c, needs a v_mov 0 per sample
+    return p;
 }
 SSDR_DEV float lane63(float x) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63)); }
 SSDR_DEV float from_prev_lane(float lane0_value, float x) { return dpp<0x138, 0xF>(lane0_value, x); }   // wave_shr:1

@@ -143,14 +143,15 @@ SSDR_DEV float ssdr_sqrt_rn(float p)
     return r * 0x1p-32f;
 }
 
-// The same for p == 0 or 1 <= p < 2^33 (an integer power I*I + Q*Q rounded to float): the residuals cannot
-// underflow there, so the argument needs no scaling (two multiplies less).  Also checked exhaustively.
+// The same for p == 0 or 1 <= p < 2^33 (an integer power I*I + Q*Q rounded to float), without the neighbours: there one
+// Newton step from the reciprocal square root,  s = p y,  s' = fma(fma(-s, s, p), y/2, s),  already IS the correctly
+// rounded root (checked over every float of [1, 2^33) by tools/ubench/sqrt_variants.hip and by ssdr_selftest_sqrt; it
+// fails only far below 1, where the residual underflows).  p == 0: the clamp bit turns v_rsq's +inf into 1.0 (and leaves
+// every y <= 1, i.e. every p >= 1, alone), so s = 0, residual 0, result +0.  Five instructions instead of eight.
 SSDR_DEV float ssdr_sqrt_rn_int(float p)
 {
-    const float s = __builtin_amdgcn_sqrtf(p);
-    const float sd = __uint_as_float(__float_as_uint(s) - 1u), su = __uint_as_float(__float_as_uint(s) + 1u);
-    const float rd = fmaf(-sd, s, p), ru = fmaf(-su, s, p);
-    float r = (rd <= 0.0f) ? sd : s;            // p == 0: s == 0, sd a NaN pattern, compare false -> stays 0; ru = -0 -> stays 0
-    r = (ru > 0.0f) ? su : r;
-    return r;
+    float y;
+    asm("v_rsq_f32_e64 %0, %1 clamp" : "=v"(y) : "v"(p));
+    const float s = p * y, h = 0.5f * y;
+    return fmaf(fmaf(-s, s, p), h, s);
 }
