@@ -63,7 +63,8 @@ PATH_TEXT = ("general: NCO -> FIR -> demodulator", "full-band lane shift: NCO, n
 F32_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: vector f32 peak (an FMA = 2 flop)
 RIDGE_FLOP_PER_BYTE = F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)          # 19.7
 # Executed vector work per unit: VALU wave-instructions from PMC SQ_INSTS_VALU / wave-units (profiles/r03_*_pmc_summary.txt:
-# 6.477e8 per 524 288 line pairs, 3.931e8 per 327 680, 5.456e8 / 1.872e8 / 9.373e7 per 655 360 / 327 680 / 327 680 frames,
+# 6.477e8 per 524 288 line pairs, 3.931e8 per 327 680, 5.456e8 / 1.872e8 / 8.056e7 per 655 360 / 327 680 / 327 680 frames,
+# the fused superframe kernel 1.171e9 per 1 048 576 channel-superframes,
 # 7.031e8 per 262 144 frames), FMA share from the static opcode mix of the loops (profiles/r02_isa_histograms.txt; the
 # filters' multiply-adds -- 512 per frame for 33 taps, 2000 for 125 at D = 4 -- are dynamic).
 # flops = 64 lanes x (instructions + FMA instructions).
@@ -74,7 +75,8 @@ KERNEL_VALU = {
     "ssdr_wf_kernel<true, true>": ("line", 1200 / 2, 0.62),
     "ssdr_audio_kernel<0>": ("frame", 832, 0.75),
     "ssdr_audio_kernel<1>": ("frame", 571, 0.42),
-    "ssdr_audio_kernel<2>": ("frame", 286, 0.17),
+    "ssdr_audio_kernel<2>": ("frame", 243, 0.23),
+    "ssdr_fused_am_kernel": ("channel-superframe", 1117, 0.44),
     "ssdr_audio_dec_kernel<4>": ("frame", 2682, 0.85),
 }
 
@@ -202,7 +204,7 @@ def spawn_ranks(gpus, argv):
 # ---------------------------------------------------------------------------------------------------------------
 # one measurement
 # ---------------------------------------------------------------------------------------------------------------
-def configure(S, eng, workload, channels, first_channel_id, hop=1024, fused=0, concurrent=0, exact=0):
+def configure(S, eng, workload, channels, first_channel_id, hop=1024, fused=1, concurrent=0, exact=0):
     """channel parameters of `workload` for the block of channels that starts at global id `first_channel_id`
     (mode by channel id mod len(modes), tuning by the generator's carrier formula)"""
     _, _, n_avg, modes, _, _ = WORKLOADS[workload]
@@ -223,25 +225,27 @@ def configure(S, eng, workload, channels, first_channel_id, hop=1024, fused=0, c
     return n_avg, decim
 
 
-def parity_probe(S, local_rank, workload, first_channel_id, channels=256, sframes=4, steps=2):
+def parity_probe(S, local_rank, workload, first_channel_id, channels=256, sframes=4, steps=2, fused=1):
     """SURVEY.md 8e "parity hash": a fresh ctx runs `steps` steps of `workload` on the `channels` channels that start at
     global id `first_channel_id` and returns the checksums of what it produced (ssdr_output_checksum: waterfall sums,
     PCM, RSSI).  Integer arithmetic over the result bytes: the same channel block gives the same three numbers on any
     rank, any GPU, any launch shape -- or the ranks do not compute the same thing."""
     _, _, _, _, do_wf, do_audio = WORKLOADS[workload]
     with S.SsdrEngine(channels, device=local_rank) as eng:
-        configure(S, eng, workload, channels, first_channel_id)
+        configure(S, eng, workload, channels, first_channel_id, fused=fused)
         eng.synth_iq(2 * sframes, seed=0x5D5D, first_channel_id=first_channel_id)
         for _ in range(steps):
-            if do_wf:
+            if do_wf and do_audio:
+                eng.run_chain()
+            elif do_wf:
                 eng.run_wf(fetch=False)
-            if do_audio:
+            elif do_audio:
                 eng.run_audio(fetch=False)
         return eng.output_checksum()
 
 
 def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sframes, steps, warmup, spinup,
-            concurrent=0, host_feed=0, hop=1024, fused=0, exact=0, first_channel_id=None):
+            concurrent=0, host_feed=0, hop=1024, fused=1, exact=0, first_channel_id=None):
     """Spin the clocks up, W warm-up steps, then exactly `steps` timed steps between barrier + synchronize pairs.
     -> dict(value, ms_per_step, stages, ...)."""
     _, _, _, modes, do_wf, do_audio = WORKLOADS[workload]
@@ -259,9 +263,9 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
         if do_audio:
             eng.run_audio(fetch=False)
 
-    if fused and do_wf and do_audio:
-        def step():                                       # noqa: F811  (one kernel when the configuration allows it)
-            eng.run_chain()
+    if do_wf and do_audio:
+        def step():                                       # noqa: F811  (ssdr_run_chain: the fused superframe kernel where the
+            eng.run_chain()                               #  configuration allows it and --fused is not 0, else the two kernels)
 
     inflight = [0]
     if host_feed:
@@ -346,7 +350,8 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     if fu_n:
         avg = fu_ms / fu_n
         b = channels * sframes * 8192.0                 # SURVEY.md 8d, fused budget at N = 1: 4096 in + 2048 + 2048 out
-        stages["fused"] = {"kernel": "ssdr_fused_am_kernel", "avg_ms": avg, "launches": fu_n, "bytes": b, "GBps": b / avg / 1e6}
+        stages["fused"] = {"kernel": "ssdr_fused_am_kernel", "avg_ms": avg, "launches": fu_n, "bytes": b, "GBps": b / avg / 1e6,
+                           "units": channels * sframes}
     return {"value": units / wall / RT_SUPERFRAMES_PER_S, "ms_per_step": wall / steps * 1e3, "stages": stages,
             "n_avg": n_avg, "paths": paths, "decim": decim,
             "own_value": channels * sframes * steps / own_wall / RT_SUPERFRAMES_PER_S}
@@ -364,7 +369,8 @@ def pmc_traffic(workload, channels, sframes, hop=1024):
         except Exception:
             continue
         if (t.get("workload"), t.get("channels_per_gpu"), t.get("superframes_per_step"), t.get("wf_hop", 1024)) == (workload, channels, sframes, hop):
-            found, src = {k: v["hbm_bytes_per_launch"] for k, v in t["kernels"].items()}, os.path.basename(path)
+            found.update({k: v["hbm_bytes_per_launch"] for k, v in t["kernels"].items()})    # (the same shape with other kernels:
+            src = os.path.basename(path) if src is None else src + ", " + os.path.basename(path)  #  --fused 0 / 1 are two files)
     return found, src
 
 
@@ -438,8 +444,9 @@ def main():
                     help="1: inputs come from (pinned) host memory (2: as SND wire bodies, unpacked on the device) and results go back to it through the pipelined feed "
                          "(ssdr_feed_*): the PCIe-inclusive rate of DESIGN.md, never the headline value")
     ap.add_argument("--concurrent", type=int, default=0, help="bit 0: audio stage on a second stream beside the waterfall kernel; bit 1: the audio stage's per-path kernels one after the other")
-    ap.add_argument("--fused", type=int, default=0,
-                    help="1: ssdr_run_chain with the fused superframe kernel where the configuration allows it (full-band AM, N = 1)")
+    ap.add_argument("--fused", type=int, default=1,
+                    help="1 (the library's default): ssdr_run_chain uses the fused superframe kernel where the configuration allows it "
+                         "(every channel full-band AM, N = 1, hop 1024); 0: always the two per-stage kernels")
     ap.add_argument("--hop", type=int, default=1024, choices=[512, 1024],
                     help="samples between waterfall lines: 512 = 23.4 lines/s, the reference's waterfall rate (utils_supersdr.py:597)")
     ap.add_argument("--exact", type=int, default=0, help="1: ssdr_set_exact_bins -- the waterfall stage in float64 (bins equal the float64 oracle bit for bit)")
@@ -505,10 +512,12 @@ def main():
     if args.no_parity_probe:
         parity = {"ranks_agree": True, "skipped": "--no-parity-probe"}
     else:
-        own = parity_probe(S, local_rank, args.workload, first_id)
-        cross = parity_probe(S, local_rank, args.workload, firsts[(rank + 1) % world])
+        own = parity_probe(S, local_rank, args.workload, first_id, fused=args.fused)
+        cross = parity_probe(S, local_rank, args.workload, firsts[(rank + 1) % world], fused=0)
         parity = parity_report(rdv, world, firsts, own, cross,
-                               "fresh ctx, 256 channels from the block's first id x 4 superframes x 2 steps, ssdr_output_checksum (wf, pcm, rssi)")
+                               "fresh ctx, 256 channels from the block's first id x 4 superframes x 2 steps, ssdr_output_checksum (wf, pcm, rssi); "
+                               "own block through ssdr_run_chain as the timed steps run it (the fused kernel where it applies), "
+                               "the neighbour's block through the two per-stage kernels")
     per_rank = [v[0] for v in rdv.gather_floats([m["own_value"]])]
     stages = m["stages"]
     dom = max(stages, key=lambda k: stages[k]["avg_ms"])
@@ -559,13 +568,16 @@ def main():
         # both stages side by side on two streams; the fused superframe kernel; the waterfall at the reference's line rate
         nst = max(20, args.steps // 3)
         ch, sf = WORKLOADS["full"][0], WORKLOADS["full"][1]
-        for key, kw in (("full_concurrent", dict(concurrent=1)), ("full_fused", dict(fused=1))):
+        for key, kw in (("full_two_kernels", dict(fused=0)), ("full_concurrent", dict(concurrent=1))):
             e = measure(S, L, torch, rdv, rank, world, local_rank, "full", ch, sf, nst, 2, 0.5, **kw)
             b = ch * sf * 8192.0
-            extra[key] = {"workload": WORKLOAD_TEXT["full"] + (", waterfall and audio stage side by side (--concurrent 1)" if "concurrent" in kw
-                                                             else ", one fused kernel (--fused 1)"),
+            tr, tsrc = pmc_traffic("full", ch, sf)
+            extra[key] = {"workload": WORKLOAD_TEXT["full"] + (", waterfall and audio stage side by side on two streams (--concurrent 1)" if "concurrent" in kw
+                                                             else ", the two per-stage kernels one after the other (--fused 0)"),
                           "value": e["value"], "unit": "rt_channels", "ms_per_step": e["ms_per_step"], "steps": nst,
                           "chain_GBps": b / e["ms_per_step"] / 1e6, "chain_frac": b / e["ms_per_step"] / 1e6 / HBM_PEAK_GBPS}
+            if "fused" in kw:
+                extra[key]["rooflines"] = [roofline(s_, stage_traffic(tr, s_), tsrc) for s_ in e["stages"].values()]
         ch, sf = WORKLOADS["wf"][0], WORKLOADS["wf"][1]
         e = measure(S, L, torch, rdv, rank, world, local_rank, "wf", ch, sf, nst, 2, 0.5, hop=512)
         tr, tsrc = pmc_traffic("wf", ch, sf, 512)

@@ -174,10 +174,11 @@ int ssdr_audio_flags(ssdr_ctx *ctx, uint8_t *flags_out, int out_is_device);
  * baseband y and the AGC gain g.  Rows of channels in other modes are zero.  SSDR_ESTATE if no channel is in IQ mode. */
 int ssdr_audio_iq(ssdr_ctx *ctx, int16_t *iq_out, int out_is_device);
 /* Both stages on the current batch, results kept on the device (ssdr_wf_device / ssdr_audio_device / ssdr_audio_flags): what
- * ssdr_run_wf followed by ssdr_run_audio do.  With ssdr_set_fused(ctx, 1), and when every channel is on the reference's
- * full-band AM passband, N = 1, hop 1024, 12 kHz IQ, an even frame count (the configuration of the metric), ONE kernel
- * does both: each 4 KB line is read once for its FFT and its two audio frames; results are bit-identical to the two
- * kernels'.  *fused (may be NULL) tells which way it went. */
+ * ssdr_run_wf followed by ssdr_run_audio do.  When every channel is on the reference's full-band AM passband, N = 1, hop
+ * 1024, 12 kHz IQ, no zoom, and the batch holds an even number of at least 8 frames (the configuration of the metric), ONE
+ * kernel does both: each 4 KB line is read once for its FFT and its two audio frames; results are bit-identical to the two
+ * kernels'.  *fused (may be NULL) tells which way it went; ssdr_set_fused(ctx, 0) keeps the two kernels in every case (the
+ * default is 1).  The pipelined feed (ssdr_feed_*) runs its batches through this call. */
 int ssdr_run_chain(ssdr_ctx *ctx, uint32_t *lines_ready, int *fused);
 int ssdr_set_fused(ssdr_ctx *ctx, int on);
 int ssdr_sync(ssdr_ctx *ctx);

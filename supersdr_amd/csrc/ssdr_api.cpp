@@ -55,9 +55,12 @@ struct ssdr_ctx {
     uint32_t *d_chan_list = nullptr;                    // channels sorted by audio frame path (ssdr_audio_path)
     uint32_t path_off[SSDR_PATH_COUNT] = {}, path_n[SSDR_PATH_COUNT] = {};
     bool chan_list_dirty = true;
+    bool summary_dirty = true;                          // path counts / any channel in IQ mode: recounted after the constants change
+    uint32_t sum_paths[SSDR_PATH_COUNT] = {0, 0, 0};
+    bool sum_any_iq = false;
     hipStream_t path_stream[SSDR_PATH_COUNT - 1] = {};  // the audio kernels of different paths run side by side
     hipEvent_t ev_fork = nullptr, ev_path[SSDR_PATH_COUNT - 1] = {};
-    bool fused_enabled = false;                         // ssdr_set_fused
+    bool fused_enabled = true;                          // ssdr_set_fused: ssdr_run_chain may use the fused superframe kernel
     bool fuse_next = false;                             // ssdr_run_chain: run_wf parks its arguments, run_audio launches the fused kernel
     SsdrWfArgs fused_wf;
     uint32_t fused_grid = 0;
@@ -344,6 +347,7 @@ int ssdr_set_params(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan
     for (uint32_t i = 0; i < count; i++) c->h_params[first + i] = p[i];
     for (uint32_t i = 0; i < count; i++) c->h_consts[first + i] = k[i];
     c->chan_list_dirty = true;
+    c->summary_dirty = true;
     HIP_TRY(hipMemcpyAsync(c->d_consts + first, k.data(), count * sizeof(ssdr_chan_consts), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_taps + (size_t)first * SSDR_NTAP_MAX, taps.data(), taps.size() * sizeof(float),
                            hipMemcpyHostToDevice, c->stream));
@@ -665,6 +669,19 @@ static int join_audio(ssdr_ctx *c)
     return SSDR_OK;
 }
 
+// what the per-call decisions need to know about the channels' constants, counted once per change of them
+static void chan_summary(ssdr_ctx *c)
+{
+    if (!c->summary_dirty) return;
+    for (int p = 0; p < SSDR_PATH_COUNT; p++) c->sum_paths[p] = 0;
+    c->sum_any_iq = false;
+    for (uint32_t ch = 0; ch < c->n_ch; ch++) {
+        c->sum_paths[ssdr_audio_path(c->h_consts[ch])]++;
+        c->sum_any_iq = c->sum_any_iq || c->h_consts[ch].mode == SSDR_MODE_IQ;
+    }
+    c->summary_dirty = false;
+}
+
 // input samples (dwords) per channel of a batch of n_frames frames: a frame yields 512 PCM samples and takes 512 * D of IQ
 static inline size_t in_len(const ssdr_ctx *c, uint32_t n_frames) { return (size_t)n_frames * SSDR_FRAME * c->decim; }
 
@@ -863,8 +880,8 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
     a.iq_out = nullptr;
     c->iq_out_valid = false;
     {
-        bool any_iq = false;
-        for (uint32_t ch = 0; ch < c->n_ch && !any_iq; ch++) any_iq = c->h_consts[ch].mode == SSDR_MODE_IQ;
+        chan_summary(c);
+        const bool any_iq = c->sum_any_iq;
         if (any_iq && c->feed.empty()) {          // (the pipelined feed hands out PCM rows only: an IQ channel's row carries I)
             if (c->iq_out_frames < c->in_frames) {
                 HIP_TRY(hipStreamSynchronize(c->stream));
@@ -962,10 +979,12 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
 {
     if (!c) return SSDR_EINVAL;
     if (!c->have_input) return SSDR_ESTATE;
-    uint32_t n_am = 0;
-    for (uint32_t ch = 0; ch < c->n_ch; ch++) n_am += ssdr_audio_path(c->h_consts[ch]) == SSDR_PATH_AM_RAW;
-    // the fused kernel covers the metric's configuration: every channel on the full-band AM path, N = 1, hop 1024, 12 kHz IQ
+    chan_summary(c);
+    const uint32_t n_am = c->sum_paths[SSDR_PATH_AM_RAW];
+    // the fused kernel covers the metric's configuration: every channel on the full-band AM path, N = 1, hop 1024, 12 kHz IQ;
+    // from four lines per call on (a wave sets a channel pair's carried state up once per call: measured ahead from there)
     const bool eligible = n_am == c->n_ch && c->n_avg == 1 && c->hop == SSDR_NFFT && c->decim == 1 && !(c->in_frames & 1u) &&
+                          c->in_frames >= 8 &&
                           !c->concurrent && c->fused_grid != 0 && c->fused_enabled && !c->exact_bins && c->zoom == 1;
     if (fused) *fused = eligible ? 1 : 0;
     c->fuse_next = eligible;
@@ -985,8 +1004,8 @@ int ssdr_set_fused(ssdr_ctx *c, int on)
 int ssdr_audio_paths(ssdr_ctx *c, uint32_t counts[3])
 {
     if (!c || !counts) return SSDR_EINVAL;
-    for (int p = 0; p < SSDR_PATH_COUNT; p++) counts[p] = 0;
-    for (uint32_t ch = 0; ch < c->n_ch; ch++) counts[ssdr_audio_path(c->h_consts[ch])]++;
+    chan_summary(c);
+    for (int p = 0; p < SSDR_PATH_COUNT; p++) counts[p] = c->sum_paths[p];
     return SSDR_OK;
 }
 
@@ -1176,8 +1195,7 @@ int ssdr_feed_submit(ssdr_ctx *c)
     c->d_flags = s.d_flags; c->flags_frames = nf;
     uint32_t lines = 0;
     s.n_avg = c->n_avg;
-    int rc = ssdr_run_wf(c, nullptr, &lines, 0);
-    if (rc == SSDR_OK) rc = ssdr_run_audio(c, nullptr, nullptr, 0);
+    int rc = ssdr_run_chain(c, &lines, nullptr);           // the fused superframe kernel where the batch allows it
     if (rc == SSDR_OK && c->feed_post) rc = [&]() -> int {
         // spectrum_db2col of this batch's lines and play_buffer of its frames, on the slot's buffers, in batch order
         if (lines) {
@@ -1429,6 +1447,7 @@ int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob, uint64_t bytes)
     c->audio_started = h.audio_started != 0;
     c->kiwi_rate = h.kiwi_rate;
     c->synth_sample0 = h.synth_sample0;
+    c->summary_dirty = true;
     c->chan_list_dirty = true;
     c->pending_play_hist.clear();
     if (h.has_play && !c->d_play_hist) {                    // play_buffer state arrives before its buffers exist: applied at first use
