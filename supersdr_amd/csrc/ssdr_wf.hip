@@ -563,17 +563,17 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                 for (int i = 0; i < 4; i++) tail_q[c][i] = __float_as_uint(pad(c, 10 + i));
             }
             wave_lds_sync();
-            // ---- audio, phase 1: integer powers of this half's channel into the (still unused) transpose buffer.  The
-            // samples themselves are not kept: the FFT fetches the line again below, out of the L2 it was just pulled into
-            // (plain loads here for that reason) -- one read from HBM, and no 32 registers held across the audio chain.
+            // ---- audio, phase 1: the line's raw samples into the (still unused) transpose buffer, in the FFT's layout (lane l
+            // of a half: samples 32 r + l).  The audio chain reads them back eight consecutive samples per lane, the FFT takes
+            // them out of the LDS again afterwards: one read from HBM (streaming), none from the L2, and no 32 registers held
+            // across the audio chain.
             {
                 uint32_t *q = qbuf + opaque(h) * XCH_FLOATS + opaque(l);
-                uint32_t t[32];                     // all 32 loads in flight, then their powers: left alone the compiler issues
-#pragma unroll                                      // load, wait, power one sample at a time -- 32 round trips to memory per line
-                for (int r = 0; r < 32; r++) t[r] = src[32 * r];
+                uint32_t t[32];                     // all 32 loads in flight, then the stores: left alone the compiler issues
+                load_line(src, t);                  // load, wait, store one sample at a time -- 32 round trips to memory per line
                 SCHED_FENCE();
 #pragma unroll
-                for (int r = 0; r < 32; r++) q[32 * r] = iq_power(t[r]);
+                for (int r = 0; r < 32; r++) q[32 * r] = t[r];
                 SCHED_FENCE();
             }
             wave_lds_sync();
@@ -590,8 +590,10 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                     const uint32_t frame = 2 * line + f;
                     const u32x4 *qp = reinterpret_cast<const u32x4 *>(qbuf + c * XCH_FLOATS + SSDR_FRAME * f) + 2 * opaque(lane);
                     const u32x4 q0 = qp[0], q1 = qp[1];
-                    const uint32_t qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-                    uint32_t d[8];
+                    const uint32_t rw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                    uint32_t qv[8], d[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) qv[j] = iq_power(rw[j]);
                     float p[8], aud[8];
 #pragma unroll
                     for (int j = 0; j < 4; j++) { d[j] = from_prev_lane_u(tail_q[c][j], qv[4 + j]); d[4 + j] = qv[j]; }
@@ -602,22 +604,20 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                     const float pmx = vmax3(vmax3(vmax3(p[0], p[1], p[2]), p[3], p[4]), vmax3(p[5], p[6], p[7]), 0.0f);
                     const bool trig = wave_any(pmx >= 1073676160.0f) || tail_q[c][0] >= 0x3FFF0001u || tail_q[c][1] >= 0x3FFF0001u ||
                                       tail_q[c][2] >= 0x3FFF0001u || tail_q[c][3] >= 0x3FFF0001u;
-                    bool clip = false;
-                    if (trig) {                                                // the exact check, on the raw samples in the FFT's layout
-                        bool mine = false;
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const uint32_t w = src[32 * (16 * f + r)];
-                            const int lo = (int16_t)(w & 0xFFFFu), hi = (int32_t)w >> 16;
-                            mine = mine || lo >= 32767 || lo <= -32767 || hi >= 32767 || hi <= -32767;
-                        }
-                        clip = wave_any(mine && h == c);
-                    }
+                    const bool clip = trig ? wave_any(raw_clipped(rw)) : false;    // the exact check, only then
                     demod_am<true>(p, dc[c], aud);
                     agc_pack_store(p, aud, lane, agc_c, agc_d[c], agc_m[c], u.pcm + ((uint64_t)cc * n_frames + frame) * SSDR_FRAME + 8 * lane);
                     rssi_flag_step(p, clip, frame, n_frames, lane, cal_c, rssi_sum[c], flag_keep[c],
                                    u.rssi + (uint64_t)cc * n_frames, u.flags + (uint64_t)cc * n_frames);
                 }
+            }
+            wave_lds_sync();
+            // ---- waterfall: the line out of the LDS (before the carried state takes its resting place in it again)
+            uint32_t raw[32];
+            {
+                const uint32_t *q = qbuf + opaque(h) * XCH_FLOATS + opaque(l);
+#pragma unroll
+                for (int r = 0; r < 32; r++) raw[r] = q[32 * r];
             }
             wave_lds_sync();
             if (lane < 2) {                                                    // ... and back to rest
@@ -633,9 +633,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
             }
             wave_lds_sync();
             SCHED_FENCE();
-            // ---- waterfall: exactly as ssdr_wf_kernel<false, false>
-            uint32_t raw[32];
-            load_line(src, raw);
+            // ---- ... from here on exactly as ssdr_wf_kernel<false, false>
             // the raw tail of the call's last frame (its samples 384..511 = this line's 896..1023) is the next call's history
             if (line + 1 == a.n_lines && ch_ok) {
 #pragma unroll
