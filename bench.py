@@ -361,23 +361,29 @@ def pmc_traffic(workload, channels, sframes, hop=1024):
     """HBM bytes per launch from the PMC passes committed under profiles/ (collected with rocprofv3 in separate
     runs, corrected as MI355X_MICROARCH.md prescribes; tools/profile_round.sh + tools/traffic_json.py).
     Only used when it was measured on exactly this workload shape; the newest round wins."""
-    import glob
-    found, src = {}, None
+    import glob, re
+    hits = []
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic*.json"))):
         try:
             t = json.load(open(path))
         except Exception:
             continue
         if (t.get("workload"), t.get("channels_per_gpu"), t.get("superframes_per_step"), t.get("wf_hop", 1024)) == (workload, channels, sframes, hop):
-            found.update({k: v["hbm_bytes_per_launch"] for k, v in t["kernels"].items()})    # (the same shape with other kernels:
-            src = os.path.basename(path) if src is None else src + ", " + os.path.basename(path)  #  --fused 0 / 1 are two files)
+            m = re.match(r"r(\d+)_", os.path.basename(path))
+            hits.append((int(m.group(1)) if m else 0, os.path.basename(path), t))
+    found, src = {}, None
+    newest = max((h[0] for h in hits), default=None)
+    for rnd, name, t in hits:                       # the newest round's files (--fused 0 / 1 of one shape are two of them)
+        if rnd == newest:
+            found.update({k: v["hbm_bytes_per_launch"] for k, v in t["kernels"].items()})
+            src = name if src is None else src + ", " + name
     return found, src
 
 
 def stage_traffic(traffic, stage):
     """PMC bytes of a stage: its kernel's, or the sum over the kernels a multi-kernel audio stage names"""
     import re
-    names = re.findall(r"ssdr_\w+_kernel<[^>]*>", stage["kernel"])
+    names = re.findall(r"ssdr_\w+_kernel(?:<[^>]*>)?", stage["kernel"])
     vals = [traffic.get(n) for n in names]
     return sum(vals) if vals and all(v is not None for v in vals) else None
 
