@@ -465,6 +465,47 @@ def test_pipelined_feed_equals_push_and_run(S):
             assert np.array_equal(got[b][k], want[b][k]), (b, k)
 
 
+def test_pipelined_feed_through_the_fused_kernel_equals_the_two_kernels(S):
+    """The feed runs its batches through ssdr_run_chain: with every channel on the full-band AM path, N = 1 and 8-frame batches
+    that is the fused superframe kernel.  Its waterfall lines, PCM, RSSI and ADC flags, batch after batch with the state
+    carried, equal what the two per-stage kernels give synchronously (odd channel count: a half-empty wave; one clipping
+    sample; one channel with the AGC hang)."""
+    n_ch, nf, n_batches = 5, 8, 4
+    iq = O.synth_iq(n_ch, n_batches * nf * 512, seed=313)
+    iq[3, 9 * 512 + 17, 0] = 32767
+    ps = [S.default_params("am", f_shift_hz=100.0 * c, agc_hang=int(c == 2)) for c in range(n_ch)]
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.set_fused(False)
+        want = []
+        for b in range(n_batches):
+            eng.push_iq(iq[:, b * nf * 512:(b + 1) * nf * 512])
+            lines, fused = eng.run_chain()
+            assert not fused
+            wf = eng.fetch_wf(lines)
+            pcm, rssi = eng.fetch_audio()
+            want.append((wf, pcm, rssi, eng.audio_flags()))
+    assert sum(int(w[3].sum()) for w in want) == 1
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.set_profiling(True)
+        eng.feed_open(nf, depth=2)
+        got = []
+        for b in range(n_batches):
+            if b >= 2:
+                got.append(tuple(x.copy() for x in eng.feed_collect()) + (eng.feed_flags.copy(),))
+            eng.feed_slot()[:] = iq[:, b * nf * 512:(b + 1) * nf * 512]
+            eng.feed_submit()
+        while len(got) < n_batches:
+            got.append(tuple(x.copy() for x in eng.feed_collect()) + (eng.feed_flags.copy(),))
+        eng.feed_close()
+        from supersdr_amd import _lib as L
+        assert eng.kernel_stats(L.K_FUSED)[1] == n_batches and eng.kernel_stats(L.K_WF)[1] == 0      # it WAS the fused kernel
+    for b in range(n_batches):
+        for k in range(4):
+            assert np.array_equal(got[b][k], want[b][k]), (b, k)
+
+
 def test_pipelined_feed_wire_mode(S):
     """SSDR_FEED_WIRE: SND bodies (big-endian, 17-byte header) in, same results as the int16 path, header rssi out"""
     import struct
