@@ -162,6 +162,24 @@ def test_wf_calibration_and_edges(S, twin):
     assert not ((wf[:, 3] != o3) & ~g3).any()
 
 
+def test_wf_calibration_extremes(S, twin):
+    """The quantiser folds 2^-48 into the calibration factor and clamps with the multiply: the whole allowed calibration
+    range (+-200 dB) gives the twin's bytes -- next to all 0 at the bottom, next to all 255 at the top -- and anything beyond is refused."""
+    dbs = (-200.0, -120.0, -60.0, 0.0, 60.0, 120.0, 200.0)
+    iq = O.synth_iq(len(dbs), 2 * 1024, seed=77)
+    with S.SsdrEngine(len(dbs)) as eng:
+        eng.set_params(0, [S.default_params("am", wf_cal_db=db) for db in dbs])
+        eng.push_iq(iq)
+        wf = eng.run_wf()
+        consts, _ = eng.get_consts()
+        assert np.array_equal(wf, twin.wf(iq, 1, consts["wf_cal_lin"]))
+        means = wf.reshape(2, len(dbs), -1).mean(axis=(0, 2))
+        assert (np.diff(means) >= 0).all() and means[0] < means[3] < means[-1], means
+        for db in (200.5, -201.0, float("nan")):
+            with pytest.raises(S.SsdrError):
+                eng.set_params(0, [S.default_params("am", wf_cal_db=db)])
+
+
 @pytest.mark.parametrize("n_ch,n_frames", [(1, 1), (4, 2), (16, 5), (67, 3), (2, 64), (3, 130)])   # > 64 frames: RSSI is converted in batches of 64
 def test_audio_bit_exact_vs_twin_and_oracle(S, twin, n_ch, n_frames):
     iq = O.synth_iq(n_ch, n_frames * 512, seed=21 + n_ch)

@@ -53,6 +53,17 @@ def test_host_only_entry_points(S):
     assert (p.low_cut, p.high_cut, p.agc_decay, p.smeter_cal_db) == (-3000.0, -30.0, 4000.0, -13.0)
     bad = L.ChanParams()
     assert L.lib.ssdr_default_params(9, C.byref(bad)) == L.EINVAL
+    # the waterfall calibration must stay within +-200 dB (the quantiser scales its factor by 2^-48), here and in the oracle
+    for db, ok in ((200.0, True), (-200.0, True), (200.5, False), (-1e9, False)):
+        p = S.default_params("am", wf_cal_db=db)
+        if ok:
+            assert S.compile_params(p)[0]["wf_cal_lin"] == np.float32(10.0 ** (db / 10.0))
+            O.compile_params(O.ChanParams(mode="am", wf_cal_db=db))
+        else:
+            with pytest.raises(S.SsdrError):
+                S.compile_params(p)
+            with pytest.raises(ValueError):
+                O.compile_params(O.ChanParams(mode="am", wf_cal_db=db))
 
 
 def test_tables_equal_oracle(S):
