@@ -87,8 +87,12 @@ SSDR_DEV void bfly_1(f32x2 &u, f32x2 &v)                          // w = 1 (stag
 }
 SSDR_DEV void bfly_mj(f32x2 &u, f32x2 &v)                         // w = -j: t = (vi, -vr) (stages 1..5 only)
 {
-    const f32x2 t = {v.y, -v.x}, x = u;
-    u = x + t; v = x - t;
+    // two packed adds whose operand modifiers swap and negate v's halves: a = (ur + vi, ui - vr), b = (ur - vi, ui + vr)
+    // (written as x + t, x - t with t = {v.y, -v.x} the compiler builds t with two moves and a sign flip per butterfly)
+    f32x2 a, b;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,0] neg_hi:[0,1]" : "=v"(a) : "v"(u), "v"(v));
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(b) : "v"(u), "v"(v));
+    u = a; v = b;
 }
 
 // stages 1..5 on a[0..31] (a-index order), twiddle W_1024[k * (1024 >> s)] = W32[k * (32 >> s)]
@@ -237,25 +241,61 @@ SSDR_DEV void load_line_halves(const uint32_t *__restrict__ older, const uint32_
 // Stage 1 pairs sample n with sample n + 512 (registers r and r + 16 of a lane), twiddle 1: a = x w + x' w', b = x w - x' w'.
 // The second product is not rounded on its own: t = x w, a = fma(x', w', t), b = fma(-x', w', t) -- three operations per
 // pair and component instead of four (the twin states the same).
+// Packed multiply / multiply-add of a complex sample by ONE real factor that sits in half H of a register pair: the
+// operand modifiers broadcast that half to both lanes of the packed operation (the compiler only knows the broadcast
+// of a pair's low half and moves a factor there first: one v_mov per window value).
+template <int H>
+SSDR_DEV f32x2 pk_mul_half(f32x2 x, f32x2 wpair)
+{
+    f32x2 r;
+    if (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(wpair));
+    else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(x), "v"(wpair));
+    return r;
+}
+template <int H, bool NEG>
+SSDR_DEV f32x2 pk_fma_half(f32x2 x, f32x2 wpair, f32x2 t)          // (NEG ? -x : x) * wpair[H] + t
+{
+    f32x2 r;
+    if (H == 0 && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r) : "v"(x), "v"(wpair), "v"(t));
+    if (H == 1 && !NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(x), "v"(wpair), "v"(t));
+    if (H == 0 && NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(x), "v"(wpair), "v"(t));
+    if (H == 1 && NEG) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(x), "v"(wpair), "v"(t));
+    return r;
+}
+
 SSDR_DEV void window_line(const uint32_t (&raw)[32], const unsigned char *smem, int l, f32x2 (&z)[32])
 {
     const int ll = opaque(l);
     const float *win_up = reinterpret_cast<const float *>(smem + LDS_WIN) + ll;
     const float *win_dn = reinterpret_cast<const float *>(smem + LDS_WIN) - ll;
-    // all 32 window values first: their LDS latency hides under the HBM latency of the line's samples
-    float w[32];
+    // all 32 window values first: their LDS latency hides under the HBM latency of the line's samples.  Pairs of rows
+    // (2k, 2k + 1) share a register pair (one ds_read2_b32 each): wu for samples n < 512, wd for their partners n + 512
+    // (the mirrored half of the table: its pair is held in address order, row 2k + 1 in the low half).
+    f32x2 wu[8], wd[8];
 #pragma unroll
-    for (int r = 0; r < 32; r++) w[r] = (r < 16) ? win_up[32 * r] : win_dn[32 * (32 - r)];
+    for (int k = 0; k < 8; k++) {
+        wu[k] = f32x2{win_up[32 * (2 * k)], win_up[32 * (2 * k + 1)]};
+        wd[k] = f32x2{win_dn[32 * (16 - (2 * k + 1))], win_dn[32 * (16 - 2 * k)]};      // ascending addresses: row 2k+1 first
+    }
     SCHED_FENCE();
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const f32x2 xa = {(float)(int16_t)(raw[r] & 0xFFFFu), (float)((int32_t)raw[r] >> 16)};
-        const f32x2 xb = {(float)(int16_t)(raw[r + 16] & 0xFFFFu), (float)((int32_t)raw[r + 16] >> 16)};
-        const f32x2 t = xa * w[r];
-        const float wb = w[r + 16];
-        z[brev5(r)] = f32x2{fmaf(xb.x, wb, t.x), fmaf(xb.y, wb, t.y)};
-        z[brev5(r) + 1] = f32x2{fmaf(-xb.x, wb, t.x), fmaf(-xb.y, wb, t.y)};
-        if ((r & 3) == 3) SCHED_FENCE();
+    for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+            const int r = 2 * k + hh;
+            const f32x2 xa = {(float)(int16_t)(raw[r] & 0xFFFFu), (float)((int32_t)raw[r] >> 16)};
+            const f32x2 xb = {(float)(int16_t)(raw[r + 16] & 0xFFFFu), (float)((int32_t)raw[r + 16] >> 16)};
+            if (hh == 0) {
+                const f32x2 t = pk_mul_half<0>(xa, wu[k]);
+                z[brev5(r)] = pk_fma_half<1, false>(xb, wd[k], t);
+                z[brev5(r) + 1] = pk_fma_half<1, true>(xb, wd[k], t);
+            } else {
+                const f32x2 t = pk_mul_half<1>(xa, wu[k]);
+                z[brev5(r)] = pk_fma_half<0, false>(xb, wd[k], t);
+                z[brev5(r) + 1] = pk_fma_half<0, true>(xb, wd[k], t);
+            }
+        }
+        if (k & 1) SCHED_FENCE();
     }
 }
 
