@@ -63,20 +63,20 @@ PATH_TEXT = ("general: NCO -> FIR -> demodulator", "full-band lane shift: NCO, n
 F32_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: vector f32 peak (an FMA = 2 flop)
 RIDGE_FLOP_PER_BYTE = F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)          # 19.7
 # Executed vector work per unit: VALU wave-instructions from PMC SQ_INSTS_VALU / wave-units (profiles/r03_*_pmc_summary.txt:
-# 6.477e8 per 524 288 line pairs, 3.931e8 per 327 680, 5.456e8 / 1.872e8 / 8.056e7 per 655 360 / 327 680 / 327 680 frames,
-# the fused superframe kernel 1.176e9 per 1 048 576 channel-superframes,
+# 6.152e8 per 524 288 line pairs, 3.727e8 per 327 680, 5.456e8 / 1.872e8 / 8.056e7 per 655 360 / 327 680 / 327 680 frames,
+# the fused superframe kernel 1.144e9 per 1 048 576 channel-superframes,
 # 7.031e8 per 262 144 frames), FMA share from the static opcode mix of the loops (profiles/r02_isa_histograms.txt; the
 # filters' multiply-adds -- 512 per frame for 33 taps, 2000 for 125 at D = 4 -- are dynamic).
 # flops = 64 lanes x (instructions + FMA instructions).
 KERNEL_VALU = {
-    "ssdr_wf_kernel<false, false>": ("line", 1235 / 2, 0.62),
-    "ssdr_wf_kernel<true, false>": ("line", 1200 / 2, 0.62),
-    "ssdr_wf_kernel<false, true>": ("line", 1235 / 2, 0.62),
-    "ssdr_wf_kernel<true, true>": ("line", 1200 / 2, 0.62),
+    "ssdr_wf_kernel<false, false>": ("line", 1173.5 / 2, 0.64),
+    "ssdr_wf_kernel<true, false>": ("line", 1137.5 / 2, 0.64),
+    "ssdr_wf_kernel<false, true>": ("line", 1173.5 / 2, 0.64),
+    "ssdr_wf_kernel<true, true>": ("line", 1137.5 / 2, 0.64),
     "ssdr_audio_kernel<0>": ("frame", 832, 0.75),
     "ssdr_audio_kernel<1>": ("frame", 571, 0.42),
     "ssdr_audio_kernel<2>": ("frame", 243, 0.23),
-    "ssdr_fused_am_kernel": ("channel-superframe", 1122, 0.44),
+    "ssdr_fused_am_kernel": ("channel-superframe", 1091, 0.45),
     "ssdr_audio_dec_kernel<4>": ("frame", 2682, 0.85),
 }
 
