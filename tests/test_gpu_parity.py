@@ -768,9 +768,20 @@ def test_parity_at_the_timed_shape_full_chain(S, twin):
         wf = eng.run_wf()
         pcm, rssi = eng.run_audio()
         flags = eng.audio_flags()
+        sums1 = eng.output_checksum()
         pcm2, rssi2 = eng.run_audio()                       # the bench's next step: same input, carried state
+        sums2 = eng.output_checksum()
         consts, taps = eng.get_consts()
         st_g, hist_g = eng.get_state()
+        # ... and the way the bench takes since round 3: ssdr_run_chain = the fused superframe kernel on this configuration.
+        # Two steps from the same fresh state must give the two kernels' bytes: checksums of everything, state, history
+        eng.reset_state()
+        lines, fused = eng.run_chain()
+        assert fused and lines == sf and eng.output_checksum() == sums1
+        lines, fused = eng.run_chain()
+        assert fused and eng.output_checksum() == sums2
+        st_f, hist_f = eng.get_state()
+        assert st_f.tobytes() == st_g.tobytes() and np.array_equal(hist_f, hist_g)
     k, t = consts[sub], taps[sub]
     assert wf.shape == (sf, n_ch, 1024) and np.array_equal(wf[:, sub], twin.wf(iq_sub, 1, k["wf_cal_lin"]))
     st, hist = twinlib.fresh_state(k)
