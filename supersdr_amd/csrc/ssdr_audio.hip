@@ -160,6 +160,7 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
         float p[8], aud[8];
         float yr[8], yi[8];                                 // the channel filter's output (unused on the full-band AM path)
         bool clip;
+        float pm_am = -1.0f;                                // full-band AM path: the block peak, known before the AGC asks for it
 
         if constexpr (PATH == PATH_AM_RAW) {
             uint32_t q[8], d[8];
@@ -173,8 +174,8 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
             for (int j = 0; j < 8; j++) p[j] = (float)d[j];
             // ADC overflow: a component at the rails makes I*I + Q*Q >= 32767^2; the exact check runs only then
             // (the delayed window of the lanes misses this frame's last four samples: those are in tail_q, scalar)
-            const float pmx = vmax3(vmax3(vmax3(p[0], p[1], p[2]), p[3], p[4]), vmax3(p[5], p[6], p[7]), 0.0f);
-            const bool trig = wave_any(pmx >= 1073676160.0f) || tail_q[0] >= 0x3FFF0001u || tail_q[1] >= 0x3FFF0001u ||
+            pm_am = block_peak(p);                          // (the AGC's block peak: the floor is far below the trigger)
+            const bool trig = wave_any(pm_am >= 1073676160.0f) || tail_q[0] >= 0x3FFF0001u || tail_q[1] >= 0x3FFF0001u ||
                               tail_q[2] >= 0x3FFF0001u || tail_q[3] >= 0x3FFF0001u;
             clip = trig ? wave_any(raw_clipped(rw)) : false;
             demod_am<true>(p, dc, aud);
@@ -295,7 +296,7 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
         }
 
         // 4./5. AGC, pack, store; 6. RSSI and overflow flag
-        const float g = agc_pack_store(p, aud, l, agc, agc_d, agc_m, dst);
+        const float g = agc_pack_store(p, aud, l, agc, agc_d, agc_m, dst, pm_am);
         if constexpr (PATH == PATH_GENERAL) {
             if (mode == SSDR_MODE_IQ && a.iq_out)           // wave-uniform: I,Q pairs of the filtered baseband under the same gain
                 iq_pack_store(yr, yi, g, a.iq_out + ((uint64_t)ch * a.n_frames + f) * SSDR_FRAME + 8 * l);

@@ -254,12 +254,18 @@ SSDR_DEV void demod_fm(const float (&yr)[8], const float (&yi)[8], float prev_re
     }
 }
 
+SSDR_DEV float block_peak(const float (&p)[8])
+{
+    return vmax3(vmax3(vmax3(p[0], p[1], p[2]), p[3], p[4]), vmax3(p[5], p[6], p[7]), SSDR_P_FLOOR);
+}
+
 // AGC (block peak -> log2 -> (max,+) follower across lanes -> gain), round-half-even, saturate, pack, store
+// (pm_known >= 0: the caller already holds max(p[0..7], SSDR_P_FLOOR))
 SSDR_DEV float agc_pack_store(const float (&p)[8], const float (&aud)[8], int l, const AgcK &k, float &agc_d,
-                              float (&agc_m)[8], int16_t *dst)
+                              float (&agc_m)[8], int16_t *dst, float pm_known = -1.0f)
 {
     // max of the eight powers and the floor in four three-input maxima (max is exact: any grouping gives the same value)
-    const float pm = vmax3(vmax3(vmax3(p[0], p[1], p[2]), p[3], p[4]), vmax3(p[5], p[6], p[7]), SSDR_P_FLOOR);
+    const float pm = pm_known >= 0.0f ? pm_known : block_peak(p);
     const float al = ssdr_log2p(pm);
     const float fl = (float)l;
     const float d8 = k.d8;

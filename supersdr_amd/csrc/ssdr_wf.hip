@@ -641,12 +641,12 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                     for (int j = 0; j < 4; j++) tail_q[c][j] = lane63_u(qv[4 + j]);
 #pragma unroll
                     for (int j = 0; j < 8; j++) p[j] = (float)d[j];
-                    const float pmx = vmax3(vmax3(vmax3(p[0], p[1], p[2]), p[3], p[4]), vmax3(p[5], p[6], p[7]), 0.0f);
+                    const float pmx = block_peak(p);                          // (also what the AGC takes as the block's peak)
                     const bool trig = wave_any(pmx >= 1073676160.0f) || tail_q[c][0] >= 0x3FFF0001u || tail_q[c][1] >= 0x3FFF0001u ||
                                       tail_q[c][2] >= 0x3FFF0001u || tail_q[c][3] >= 0x3FFF0001u;
                     const bool clip = trig ? wave_any(raw_clipped(rw)) : false;    // the exact check, only then
                     demod_am<true>(p, dc[c], aud);
-                    agc_pack_store(p, aud, lane, agc_c, agc_d[c], agc_m[c], u.pcm + ((uint64_t)cc * n_frames + frame) * SSDR_FRAME + 8 * lane);
+                    agc_pack_store(p, aud, lane, agc_c, agc_d[c], agc_m[c], u.pcm + ((uint64_t)cc * n_frames + frame) * SSDR_FRAME + 8 * lane, pmx);
                     rssi_flag_step(p, clip, frame, n_frames, lane, cal_c, rssi_sum[c], flag_keep[c],
                                    u.rssi + (uint64_t)cc * n_frames, u.flags + (uint64_t)cc * n_frames);
                 }
