@@ -29,6 +29,9 @@
 #include "ssdr_kernels.h"
 #include "ssdr_audio_dev.h"
 
+#ifndef SSDR_FUSED_ABLATE
+#define SSDR_FUSED_ABLATE 0                  // timing ablations of the fused kernel only (1: no FFT, 2: no audio chain)
+#endif
 #ifndef SSDR_WF_PAIR_MAJOR
 #define SSDR_WF_PAIR_MAJOR 0
 #endif
@@ -619,9 +622,11 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
             wave_lds_sync();
             // ---- audio, phase 2: channel A, then channel B, two frames each, all 64 lanes on one channel
 #pragma unroll
-            for (int c = 0; c < 2; c++) {
+            for (int c = 0; c < (SSDR_FUSED_ABLATE == 2 ? 0 : 2); c++) {      // (timing ablation 2: no audio chain)
                 if ((uint32_t)c >= n_sub) continue;                           // wave-uniform
-                const uint32_t cc = 2 * pair + c;
+                uint32_t pair_now = __builtin_amdgcn_readfirstlane(pair);     // per line: the channel's constants and output rows are
+                asm volatile("" : "+s"(pair_now));                              // fetched again (scalar loads) rather than kept across the FFT
+                const uint32_t cc = 2 * pair_now + c;
                 const ssdr_chan_consts &kc = u.consts[cc];
                 const AgcK agc_c = {kc.agc_c0, kc.agc_c1, kc.agc_knee, kc.agc_delta8, kc.hang_frames};
                 const float cal_c = kc.smeter_cal_db;
@@ -680,12 +685,17 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                 for (int r = 28; r < 32; r++) u.hist[(size_t)ch * SSDR_HIST + 32 * (r - 28) + l] = raw[r];
             }
             last_raw31 = raw[31];
+            uint32_t qn[16];
+#if SSDR_FUSED_ABLATE == 1              // timing ablation: no FFT (the audio phase, the loads and the stores remain)
+#pragma unroll
+            for (int j = 0; j < 16; j++) qn[j] = raw[j] ^ raw[j + 16];
+#else
             f32x2 z[32];
             window_line(raw, smem, l, z);
             SCHED_FENCE();
             fft_line<true>(z, smem, xch_wave, h, l);          // the averaging kernel's twiddle schedule: fewer registers in flight
-            uint32_t qn[16];
             quantise32(z, cal_wf, lut, [&](int j, uint32_t q01) { qn[j] = q01; });
+#endif
             float *xch = xch_wave + opaque(h) * XCH_FLOATS;
             int16_t *x16 = reinterpret_cast<int16_t *>(xch) + opaque(l);
 #pragma unroll
