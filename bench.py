@@ -538,6 +538,9 @@ def main():
                    "channels_per_gpu": channels, "superframes_per_step": sframes, "averaging_n": n_avg, "wf_hop": args.hop,
                    "audio_paths": {PATH_TEXT[p]: m["paths"][p] for p in range(3) if m["paths"][p]} if do_audio else {},
                    "input_decimation": m["decim"], "wf_exact_bins": bool(args.exact),
+                   "chain": ("ssdr_run_chain: one fused kernel for both stages (one read of the input; bit-identical to the two per-stage "
+                             "kernels, which extra.full_two_kernels times)" if "fused" in m["stages"] else
+                             "the per-stage kernels" + (" side by side on two streams" if args.concurrent & 1 else " one after the other")),
                    "clock_spinup_s": args.spinup,
                    "input": "pinned host memory, pipelined H2D / kernels / D2H (PCIe-inclusive)" if args.host_feed else "resident in HBM",
                    "sharding": "channel blocks per GPU, no collectives",
