@@ -865,6 +865,43 @@ def test_checkpoint_restore_continues_bit_exactly(S):
     assert np.array_equal(want2[0], got2[0]) and np.array_equal(want2[1], got2[1]) and want2[0].shape[0] == 4
 
 
+@pytest.mark.parametrize("n_avg", [1, 3])
+def test_wf_hop_512_runs_of_groups_per_wave(S, twin, n_avg):
+    """Hop 512 at a size where the host hands every wave a RUN of consecutive groups of its channel pair (grp_run > 1:
+    more than 8 work items per resident wave) -- the layout the streaming-load scheme of the kernel relies on.  Two calls
+    (the second starts inside an averaging group and on the carried half-line), odd channel count; a strided subset of
+    channels bit-exact vs the twin, and every channel's lines through a checksum against a second engine fed frame by
+    frame (runs of one)."""
+    n_ch, calls = 1031, (601, 423)               # 516 pairs x 601 / 201 groups: runs of 9 / 3 groups at the first call
+    n_frames = sum(calls)
+    sub = np.arange(0, n_ch, 97)
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_hop(512)
+        eng.set_averaging(n_avg)
+        eng.synth_iq(n_frames, seed=99)
+        iq = eng.read_input()
+        outs, pos = [], 0
+        for k in calls:
+            eng.push_iq(iq[:, pos * 512:(pos + k) * 512])
+            outs.append(eng.run_wf())
+            pos += k
+        consts, _ = eng.get_consts()
+    got = np.concatenate(outs, axis=0)
+    stream = np.concatenate([np.zeros((len(sub), 512, 2), np.int16), iq[sub]], axis=1)
+    ref = twin.wf_hop(stream, 512, n_avg, consts["wf_cal_lin"][sub])
+    assert got.shape == (n_frames // n_avg, n_ch, 1024) and np.array_equal(got[:, sub], ref)
+    with S.SsdrEngine(n_ch) as eng:                  # the same stream in small pushes: one group per work item
+        eng.set_hop(512)
+        eng.set_averaging(n_avg)
+        small, pos = [], 0
+        while pos < n_frames:
+            k = min(61, n_frames - pos)
+            eng.push_iq(iq[:, pos * 512:(pos + k) * 512])
+            small.append(eng.run_wf())
+            pos += k
+    assert np.array_equal(got, np.concatenate(small, axis=0))
+
+
 @pytest.mark.parametrize("n_ch,n_avg", [(1, 1), (5, 1), (6, 3), (33, 10)])
 def test_wf_hop_512_bit_exact_vs_twin_and_oracle(S, twin, n_ch, n_avg):
     """ssdr_set_hop(512): lines overlap by half (23.4 lines/s, the reference's MAX_FPS = 23, utils_supersdr.py:597).  One
