@@ -64,7 +64,7 @@ F32_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: vector f
 RIDGE_FLOP_PER_BYTE = F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)          # 19.7
 # Executed vector work per unit: VALU wave-instructions from PMC SQ_INSTS_VALU / wave-units (profiles/r03_*_pmc_summary.txt:
 # 6.152e8 per 524 288 line pairs, 3.727e8 per 327 680, 5.456e8 / 1.872e8 / 8.056e7 per 655 360 / 327 680 / 327 680 frames,
-# the fused superframe kernel 1.144e9 per 1 048 576 channel-superframes,
+# the fused superframe kernel 1.130e9 per 1 048 576 channel-superframes,
 # 7.031e8 per 262 144 frames), FMA share from the static opcode mix of the loops (profiles/r02_isa_histograms.txt; the
 # filters' multiply-adds -- 512 per frame for 33 taps, 2000 for 125 at D = 4 -- are dynamic).
 # flops = 64 lanes x (instructions + FMA instructions).
@@ -76,7 +76,7 @@ KERNEL_VALU = {
     "ssdr_audio_kernel<0>": ("frame", 832, 0.75),
     "ssdr_audio_kernel<1>": ("frame", 571, 0.42),
     "ssdr_audio_kernel<2>": ("frame", 243, 0.23),
-    "ssdr_fused_am_kernel": ("channel-superframe", 1091, 0.45),
+    "ssdr_fused_am_kernel": ("channel-superframe", 1077, 0.45),
     "ssdr_audio_dec_kernel<4>": ("frame", 2682, 0.85),
 }
 
