@@ -259,24 +259,27 @@ __global__ __launch_bounds__(256) void ssdr_smeter_kernel(SsdrSmeterArgs a)
 {
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= a.n_ch) return;
-    ssdr_smeter_chan st = a.chans[ch];
+    ssdr_smeter_chan *g = a.chans + ch;             // the ten-deep history is indexed by a run-time position: it stays in global
     const double rssi = a.rssi_in ? a.rssi_in[ch] : (double)a.rssi[(uint64_t)ch * a.n_frames + (a.n_frames - 1)];
-    st.hist[st.hist_pos] = rssi;                                     // deque(maxlen=10).append
-    st.hist_pos = (st.hist_pos + 1) % 10;
-    if (fabs(rssi) > fabs(st.rssi_smooth)) {
+    const uint32_t pos = g->hist_pos;               // memory (a private copy would live in scratch)
+    g->hist[pos] = rssi;                                             // deque(maxlen=10).append
+    g->hist_pos = (pos + 1) % 10;
+    double smooth = g->rssi_smooth;
+    if (fabs(rssi) > fabs(smooth)) {
         const double v0 = -20 + 135;
-        const double t = log(v0 / (st.rssi_smooth + 135));
-        st.rssi_smooth += -v0 / (st.decay_ms / (1000 / (2 * a.fps))) * exp(-t);
+        const double t = log(v0 / (smooth + 135));
+        smooth += -v0 / (g->decay_ms / (1000 / (2 * a.fps))) * exp(-t);
     } else {
-        st.rssi_smooth += fmin((rssi - st.rssi_smooth) / 5, 3.0);
+        smooth += fmin((rssi - smooth) / 5, 3.0);
     }
-    if (st.run_index % 20 == 0) {
-        double m = st.hist[0];
-        for (int i = 1; i < 10; i++) m = fmax(m, st.hist[i]);
-        st.rssi_smooth_slow = m;
+    g->rssi_smooth = smooth;
+    const uint32_t run_index = g->run_index;
+    if (run_index % 20 == 0) {
+        double m = pos == 0 ? rssi : g->hist[0];
+        for (uint32_t i = 1; i < 10; i++) m = fmax(m, i == pos ? rssi : g->hist[i]);
+        g->rssi_smooth_slow = m;
     }
-    st.run_index++;
-    a.chans[ch] = st;
+    g->run_index = run_index + 1;
 }
 
 // SND body in IQ mode: 7 bytes (flags, seq, smeter) + 10 bytes GPS + 512 x (I,Q) big-endian int16.
