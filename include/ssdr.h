@@ -150,7 +150,7 @@ int ssdr_read_zoom(ssdr_ctx *ctx, uint32_t first, uint32_t count, int16_t *iq_ou
 /* Exact bins.  The waterfall kernel computes in float32; ~3e-4 of its bins, those whose |X| lies within the fp32 FFT's rounding
  * error of a 1-dB threshold, land one step away from where the float64 definition (oracle/ssdr_oracle.py: NumPy float64
  * FFT) puts them.  on = 1: ssdr_run_wf evaluates the stage in float64 instead (same window table, same thresholds) and
- * its int16 sums equal the float64 definition's bit for bit.  Roughly 25x slower than the default kernel; off by default;
+ * its int16 sums equal the float64 definition's bit for bit.  About 1.9x the default kernel's time (csrc/ssdr_wf_exact.hip); off by default;
  * not available to the fused kernel of ssdr_run_chain (which then runs the two stages). */
 int ssdr_set_exact_bins(ssdr_ctx *ctx, int on);
 

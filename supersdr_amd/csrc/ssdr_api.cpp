@@ -43,7 +43,7 @@ struct ssdr_ctx {
     uint32_t *d_zoom_dphi = nullptr, *d_zoom_phase = nullptr, *d_zoom_hist = nullptr, *d_zoom_out = nullptr;
     size_t zoom_out_samples = 0;                        // capacity of d_zoom_out per channel
     uint32_t zoom_run_samples = 0;                      // zoomed samples per channel of the last ssdr_run_wf
-    double2 *d_tw64 = nullptr;                          // [512] e^{-2 pi j m / 1024} in double
+    double2 *d_tw64 = nullptr;                          // [SSDR_TW64_N] stage twiddles of the float64 waterfall kernel (ssdr_make_tw64)
     float2 *d_tw = nullptr;
     uint32_t *d_lut = nullptr;
     // per-channel
@@ -579,13 +579,10 @@ int ssdr_set_exact_bins(ssdr_ctx *c, int on)
     if (!c) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
     if (on && !c->d_tw64) {
-        std::vector<double2> tw(512);
-        const double kPi = 3.14159265358979323846;
-        for (int m = 0; m < 512; m++) tw[m] = make_double2(std::cos(2.0 * kPi * m / SSDR_NFFT), -std::sin(2.0 * kPi * m / SSDR_NFFT));
-        tw[0] = make_double2(1.0, 0.0);
-        tw[256] = make_double2(0.0, -1.0);
-        HIP_TRY(hipMalloc(&c->d_tw64, 512 * sizeof(double2)));
-        HIP_TRY(hipMemcpy(c->d_tw64, tw.data(), 512 * sizeof(double2), hipMemcpyHostToDevice));
+        std::vector<double> tw(2 * SSDR_TW64_N);
+        ssdr_make_tw64(tw.data());
+        HIP_TRY(hipMalloc(&c->d_tw64, SSDR_TW64_N * sizeof(double2)));
+        HIP_TRY(hipMemcpy(c->d_tw64, tw.data(), SSDR_TW64_N * sizeof(double2), hipMemcpyHostToDevice));
     }
     c->exact_bins = on != 0;
     return SSDR_OK;
@@ -825,7 +822,7 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
         c->fused_wf = a;
     } else {
         if ((rc = timed_begin(c)) != SSDR_OK) return rc;
-        if (c->exact_bins) { if (n_groups) HIP_TRY(ssdr_launch_wf_exact(a, c->d_tw64, c->d_thr, c->stream)); }
+        if (c->exact_bins) HIP_TRY(ssdr_launch_wf_exact(a, c->d_tw64, c->stream));
         else HIP_TRY(ssdr_launch_wf(a, grid ? grid : 1, c->stream));
         if ((rc = timed_end(c, SSDR_K_WF)) != SSDR_OK) return rc;
     }

@@ -146,7 +146,10 @@ struct SsdrFusedArgs { SsdrWfArgs wf; SsdrAudioArgs au; };
 hipError_t ssdr_launch_fused_am(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream);
 hipError_t ssdr_fused_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream);
-hipError_t ssdr_launch_wf_exact(const SsdrWfArgs &a, const double2 *tw, const float *thr, hipStream_t stream);   // ssdr_wf_exact.hip
+// float64 waterfall stage (ssdr_wf_exact.hip): twiddle tables of FFT stages 5..10, double2 entries (ssdr_make_tw64):
+//   T5[lo4] 16 | T6[q][lo4] 32 | T7[q][lo4] 64 | T8[q][lo4] 128 | T9[m][b4][lo4] 256 | T10[mm][b4][b5][lo4] 256
+#define SSDR_TW64_N 752
+hipError_t ssdr_launch_wf_exact(const SsdrWfArgs &a, const double2 *tw, hipStream_t stream);   // ssdr_wf_exact.hip; chooses grid and a.grp_run itself
 hipError_t ssdr_wf_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_audio(const SsdrAudioArgs &a, int path, hipStream_t stream);
 hipError_t ssdr_launch_audio_dec(const SsdrAudioArgs &a, uint32_t decim, hipStream_t stream);
@@ -160,6 +163,7 @@ void ssdr_make_window(float *win);                    // [1024]
 void ssdr_make_twiddles(float *wr, float *wi);        // [512] each
 void ssdr_make_tw_stage(float2 *tw);                  // [992]
 void ssdr_make_thresholds(float *thr);                // [256]
+void ssdr_make_tw64(double *tw);                      // [SSDR_TW64_N][2] (re, im)
 int ssdr_make_quant_lut(uint32_t *lut);               // [SSDR_LUT_N]; returns 0, or -1 if a segment held two thresholds
 int ssdr_compile_params_host(const ssdr_chan_params *p, ssdr_chan_consts *c, float *taps, uint32_t decim, uint32_t rate_hz = SSDR_RATE);
 int ssdr_design_lowpass(double fl, double fs, int n_max, double *h);   // utils_supersdr.py:334-344; returns tap count

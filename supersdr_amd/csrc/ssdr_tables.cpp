@@ -40,6 +40,32 @@ void ssdr_make_tw_stage(float2 *tw)
     }
 }
 
+// Twiddles of the float64 waterfall kernel's stages 5..10 (ssdr_wf_exact.hip), W_1024^m = exp(-2 pi j m / 1024) in double,
+// laid out the way the lanes read them (lo4 = a-index bits 3..0, b4 / b5 = lane bits 4 / 5):
+//   stage 5: T5[lo4]            m = 32 lo4
+//   stage 6: T6[q][lo4]         m = 16 (lo4 + 16 q), q < 2          stage 7: m = 8 (lo4 + 16 q), q < 4
+//   stage 8: T8[q][lo4]         m = 4 (lo4 + 16 q), q < 8
+//   stage 9: T9[mr][b4][lo4]    m = 2 (16 (mr + 8 b4) + lo4), mr < 8
+//   stage 10: T10[mm][b4][b5][lo4]  m = 16 (mm + 4 b5 + 8 b4) + lo4, mm < 4   (the partner W^(m + 256) = -j W^m is not stored)
+void ssdr_make_tw64(double *tw)
+{
+    int n = 0;
+    auto put = [&](int m) { tw[2 * n] = std::cos(2.0 * kPi * m / SSDR_NFFT); tw[2 * n + 1] = -std::sin(2.0 * kPi * m / SSDR_NFFT);
+                            if (m == 0) { tw[2 * n] = 1.0; tw[2 * n + 1] = 0.0; }
+                            if (m == 256) { tw[2 * n] = 0.0; tw[2 * n + 1] = -1.0; }
+                            n++; };
+    for (int s = 5; s <= 8; s++)
+        for (int q = 0; q < (1 << (s - 5)); q++)
+            for (int lo4 = 0; lo4 < 16; lo4++) put((lo4 + 16 * q) << (10 - s));
+    for (int mr = 0; mr < 8; mr++)
+        for (int b4 = 0; b4 < 2; b4++)
+            for (int lo4 = 0; lo4 < 16; lo4++) put(2 * (16 * (mr + 8 * b4) + lo4));
+    for (int mm = 0; mm < 4; mm++)
+        for (int b4 = 0; b4 < 2; b4++)
+            for (int b5 = 0; b5 < 2; b5++)
+                for (int lo4 = 0; lo4 < 16; lo4++) put(16 * (mm + 4 * b5 + 8 * b4) + lo4);
+}
+
 void ssdr_make_thresholds(float *thr)
 {
     for (int k = 0; k < 256; k++) thr[k] = (float)(std::pow(10.0, (k - 255) / 10.0) * 281474976710656.0 /* 2^48 */);

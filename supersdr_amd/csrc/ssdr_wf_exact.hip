@@ -1,85 +1,455 @@
 // ssdr_wf_exact.hip -- the waterfall stage in float64 (ssdr_set_exact_bins): the same definition as ssdr_wf.hip
 // (Hann window -> 1024-pt FFT -> |X|^2 cal -> byte = #{k : T[k] <= p} -> fftshift -> sum of N lines), evaluated the way the
-// normative float64 definition (NumPy) evaluates it: samples times the float32 window table in float64 (exact products), a float64 FFT,
-// float64 power, float32 thresholds compared in float64.  An fp32 FFT lands ~3e-4 of the bins one step off where |X| sits
-// within its rounding error of a 1-dB threshold (the guard band of DESIGN.md section 3); a float64 FFT's error (1e-15
-// relative) is ten orders of magnitude below the spacing of anything that can sit there, so these bins equal the
-// float64 definition's bit for bit -- north_star's "bit-exact int16 waterfall bins" taken literally.
+// normative float64 definition (NumPy) evaluates it: samples times the float32 window table in float64 (exact products), a
+// float64 FFT, float64 power, float32 thresholds compared exactly.  An fp32 FFT lands ~3e-4 of the bins one step off where
+// |X| sits within its rounding error of a 1-dB threshold (the guard band of DESIGN.md section 3); a float64 FFT's error
+// (1e-15 relative) is ten orders of magnitude below the spacing of anything that can sit there, so these bins equal the
+// float64 definition's bit for bit -- north_star's "bit-exact int16 waterfall bins" taken literally.  (Nothing here has to
+// follow NumPy's butterfly order for that: any float64 FFT with 1e-15 accuracy gives the same bytes.)
 //
-// Not the fast path: one 256-thread workgroup per (channel, averaging group), the line in LDS as 1024 double complex,
-// textbook radix-2 DIT with __syncthreads between stages.  ~25x slower than ssdr_wf_kernel (profiles/README.md); opt-in.
+// Round 4: the kernel has the fp32 kernel's structure instead of a textbook LDS radix-2.
+//   * one wave64 per line, 16 complex doubles per lane (64 VGPRs); lane L loads samples 64 q + L, q = 0..15: every load
+//     instruction covers 256 contiguous bytes of the line;
+//   * DIT stages 1-4 in registers on the bit-reversed group the lane owns (stage 1 fused with the window, compile-time W_16
+//     twiddles), ONE transpose through LDS (re, then im through the same 8.1 KB: row stride 65 doubles and a slot
+//     permutation lo4 ^ hi2 make the b64 writes and the b64 reads conflict-free), stages 5-8 in registers with per-lane
+//     twiddles from per-stage LDS tables (lanes that share a twiddle read one address: broadcast);
+//   * stages 9 and 10 pair lanes 16 and 32 apart: v_permlane16_swap / v_permlane32_swap (new on gfx950) exchange half of
+//     the registers so that every lane holds both operands of eight butterflies -- no second trip through the LDS;
+//     stage 10's twiddles W^k and W^(k+256) = -j W^k share one table entry (the -j is a different static FMA form);
+//   * quantiser: p = (re^2 + im^2) cal in double, truncated TOWARD ZERO to float32 (clear the low 29 mantissa bits, then the
+//     conversion is exact): for float32 thresholds T[k] <= p  <=>  T[k] <= trunc32(p), so the fp32 kernel's carry-into-the-
+//     count table (ssdr_wf.hip:quantise, exhaustively verified) gives the exact count;
+//   * the int16 line is staged through the transpose buffer so that every lane stores 2 x 16 contiguous bytes.
+// 256-thread workgroups, three per CU (LDS: 4 x 8.1 KB transpose buffers + 16 KB of tables each), persistent grid.
 #include "ssdr_kernels.h"
+
+#ifndef SSDR_WFX_BLOCK
+#define SSDR_WFX_BLOCK 256
+#endif
+#ifndef SSDR_WFX_WAVES_PER_EU
+#define SSDR_WFX_WAVES_PER_EU 3
+#endif
 
 namespace {
 
-__device__ __forceinline__ uint32_t brev10(uint32_t v) { return __builtin_bitreverse32(v) >> 22; }
+#define XDEV __device__ __forceinline__
+#define XFENCE() __builtin_amdgcn_sched_barrier(0)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void ssdr_wf_exact_kernel(SsdrWfArgs a, const double2 *tw /*[512] e^{-2 pi j m/1024}*/,
-                                                           const float *thr /*[256]*/)
+constexpr int WAVES = SSDR_WFX_BLOCK / 64;
+constexpr int XROW = 65;                                     // row stride of the transpose buffer, doubles
+constexpr int XCH_BYTES = 16 * XROW * 8;                     // 8320 per wave
+// LDS map: window (513 floats), quantiser words, twiddle tables (double2), per-wave transpose buffers
+constexpr int LDS_WIN = 0;
+constexpr int LDS_LUT0 = 2064;
+constexpr int LDS_LUT_END = LDS_LUT0 + SSDR_LUT_N * 4;
+constexpr int LDS_TW = (LDS_LUT_END + 15) & ~15;
+constexpr int LDS_XCH = LDS_TW + SSDR_TW64_N * 16;
+constexpr int LDS_TOTAL = LDS_XCH + WAVES * XCH_BYTES;
+static_assert(LDS_XCH % 16 == 0, "alignment");
+static_assert(LDS_TOTAL * 3 <= 163840 || SSDR_WFX_BLOCK != 256, "three workgroups per CU");
+// table offsets in entries (ssdr_make_tw64)
+constexpr int T5 = 0, T6 = 16, T7 = 48, T8 = 112, T9 = 240, T10 = 496;
+static_assert(T10 + 256 == SSDR_TW64_N, "table size");
+
+XDEV int opaque(int v)
 {
-    __shared__ double2 z[SSDR_NFFT];
-    __shared__ double s_thr[256];
-    const uint32_t t = threadIdx.x;
-    const uint32_t ch = blockIdx.x % a.n_ch, grp = blockIdx.x / a.n_ch;
-    s_thr[t] = (double)thr[t];
-    const int64_t g0 = (int64_t)grp * a.n_avg - a.phase;
-    const uint32_t l0 = g0 < 0 ? 0u : (uint32_t)g0;
-    const uint32_t l1 = min((uint32_t)(g0 + a.n_avg), a.n_lines);
-    const bool carry_in = (grp == 0) && (a.phase != 0);
-    const bool complete = (g0 + (int64_t)a.n_avg) <= (int64_t)a.n_lines;
-    const double cal = (double)a.consts[ch].wf_cal_lin;
-    const uint32_t step = a.tail ? SSDR_NFFT / 2 : SSDR_NFFT;
-    const uint32_t *base = a.iq + (uint64_t)ch * a.ch_stride;
-    int acc[4] = {0, 0, 0, 0};
-    for (uint32_t line = l0; line < l1; line++) {
-        __syncthreads();
-        for (uint32_t i = t; i < SSDR_NFFT; i += 256) {
-            uint32_t raw;
-            if (a.tail) {                            // hop 512: half-line (line - 1) then half-line (line); half-line -1 is the carried tail
-                const uint32_t half = i >> 9, o = i & 511u;
-                raw = (half == 0) ? (line ? base[(uint64_t)(line - 1) * 512 + o] : a.tail[(uint64_t)ch * 512 + o])
-                                  : base[(uint64_t)line * 512 + o];
-            } else {
-                raw = base[(uint64_t)line * step + i];
-            }
-            const double w = (double)a.win[i];
-            z[brev10(i)] = make_double2((double)(int16_t)(raw & 0xFFFFu) * w, (double)((int32_t)raw >> 16) * w);
-        }
-        for (uint32_t s = 1; s <= 10; s++) {
-            __syncthreads();
-            const uint32_t half = 1u << (s - 1);
-            for (uint32_t b = t; b < SSDR_NFFT / 2; b += 256) {
-                const uint32_t k = b & (half - 1), i = ((b >> (s - 1)) << s) + k, j = i + half;
-                const double2 w = tw[k << (10 - s)], u = z[i], v = z[j];
-                const double tr = w.x * v.x - w.y * v.y, ti = w.x * v.y + w.y * v.x;
-                z[i] = make_double2(u.x + tr, u.y + ti);
-                z[j] = make_double2(u.x - tr, u.y - ti);
-            }
-        }
-        __syncthreads();
+    asm volatile("" : "+v"(v));
+    return v;
+}
+XDEV void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct cd { double r, i; };
+
+// a = u + w v, b = u - w v in the 6-FMA form (b = 2u - a)
+XDEV void bfly(cd &u, cd &v, double wr, double wi)
+{
+    const double sr = fma(-wi, v.i, u.r), si = fma(wi, v.r, u.i);
+    const double ar = fma(wr, v.r, sr), ai = fma(wr, v.i, si);
+    const double br = fma(2.0, u.r, -ar), bi = fma(2.0, u.i, -ai);
+    u = cd{ar, ai};
+    v = cd{br, bi};
+}
+// the same with the twiddle -j w: (wr', wi') = (wi, -wr)
+XDEV void bfly_mjw(cd &u, cd &v, double wr, double wi)
+{
+    const double sr = fma(wr, v.i, u.r), si = fma(-wr, v.r, u.i);
+    const double ar = fma(wi, v.r, sr), ai = fma(wi, v.i, si);
+    const double br = fma(2.0, u.r, -ar), bi = fma(2.0, u.i, -ai);
+    u = cd{ar, ai};
+    v = cd{br, bi};
+}
+XDEV void bfly_1(cd &u, cd &v)
+{
+    const cd x = u, t = v;
+    u = cd{x.r + t.r, x.i + t.i};
+    v = cd{x.r - t.r, x.i - t.i};
+}
+XDEV void bfly_mj(cd &u, cd &v)                               // w = -j: t = (v.i, -v.r)
+{
+    const cd x = u, t = v;
+    u = cd{x.r + t.i, x.i - t.r};
+    v = cd{x.r - t.i, x.i + t.r};
+}
+
+__device__ constexpr int brev4(int v) { return ((v & 1) << 3) | ((v & 2) << 1) | ((v & 4) >> 1) | ((v & 8) >> 3); }
+
+// stages 2..4 on the lane's 16 registers, twiddle W_16^(k (16 >> S))
+template <int S>
+XDEV void stage_const(cd (&z)[16])
+{
+    constexpr double C1 = 0x1.d906bcf328d46p-1, S1 = 0x1.87de2a6aea963p-2, C2 = 0x1.6a09e667f3bcdp-1;      // cos pi/8, sin pi/8, sqrt 1/2
+    constexpr double WR[8] = {1.0, C1, C2, S1, 0.0, -S1, -C2, -C1};
+    constexpr double WI[8] = {0.0, -S1, -C2, -C1, -1.0, -C1, -C2, -S1};
+    constexpr int half = 1 << (S - 1);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const uint32_t j = 4 * t + q;            // output bin (ascending frequency) <- FFT bin (j + 512) mod 1024
-            const double2 x = z[(j + 512) & 1023];
-            const double p = (x.x * x.x + x.y * x.y) * cal;
-            int lo = 0, hi = 255;                    // byte = #{k in 1..255 : T[k] <= p}
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (s_thr[mid] <= p) lo = mid; else hi = mid - 1;
-            }
-            acc[q] += lo;
+    for (int k = 0; k < half; k++) {
+        const int mi = k * (16 >> S);
+#pragma unroll
+        for (int blk = 0; blk < 16; blk += 2 * half) {
+            const int i = blk + k, j = i + half;
+            if (mi == 0) bfly_1(z[i], z[j]);
+            else if (mi == 4) bfly_mj(z[i], z[j]);
+            else bfly(z[i], z[j], WR[mi], WI[mi]);
         }
     }
-    int16_t *dst = complete ? a.out + ((uint64_t)grp * a.n_ch + ch) * SSDR_NFFT : a.acc_out + (uint64_t)ch * SSDR_NFFT;
-    const int16_t *cin = a.acc_in + (uint64_t)ch * SSDR_NFFT;
+}
+
+// stages 5..8 (T = s - 5) on x[rho], rho = bits 7..4 of the a-index; the lane's twiddles w[q] = W_(2^s)^(lo4 + 16 q)
+template <int T>
+XDEV void stage_lane(cd (&z)[16], const f64x2 (&w)[1 << T])
+{
+    constexpr int half = 1 << T;
 #pragma unroll
-    for (int q = 0; q < 4; q++) dst[4 * t + q] = (int16_t)(acc[q] + (carry_in ? (int)cin[4 * t + q] : 0));
+    for (int q = 0; q < half; q++) {
+#pragma unroll
+        for (int blk = 0; blk < 16; blk += 2 * half) {
+            const int i = blk + q, j = i + half;
+            bfly(z[i], z[j], w[q].x, w[q].y);
+        }
+    }
+}
+
+XDEV void swap16(double &a, double &b)                        // rows of 16 lanes: a's odd rows <-> b's even rows
+{
+    uint32_t alo = (uint32_t)__double_as_longlong(a), ahi = (uint32_t)(__double_as_longlong(a) >> 32);
+    uint32_t blo = (uint32_t)__double_as_longlong(b), bhi = (uint32_t)(__double_as_longlong(b) >> 32);
+    asm("v_permlane16_swap_b32 %0, %1" : "+v"(alo), "+v"(blo));
+    asm("v_permlane16_swap_b32 %0, %1" : "+v"(ahi), "+v"(bhi));
+    a = __longlong_as_double((long long)(((uint64_t)ahi << 32) | alo));
+    b = __longlong_as_double((long long)(((uint64_t)bhi << 32) | blo));
+}
+XDEV void swap32(double &a, double &b)                        // a's lanes 32..63 <-> b's lanes 0..31
+{
+    uint32_t alo = (uint32_t)__double_as_longlong(a), ahi = (uint32_t)(__double_as_longlong(a) >> 32);
+    uint32_t blo = (uint32_t)__double_as_longlong(b), bhi = (uint32_t)(__double_as_longlong(b) >> 32);
+    asm("v_permlane32_swap_b32 %0, %1" : "+v"(alo), "+v"(blo));
+    asm("v_permlane32_swap_b32 %0, %1" : "+v"(ahi), "+v"(bhi));
+    a = __longlong_as_double((long long)(((uint64_t)ahi << 32) | alo));
+    b = __longlong_as_double((long long)(((uint64_t)bhi << 32) | blo));
+}
+
+// the fp32 kernel's threshold counter (ssdr_wf.hip:quantise) on a float that is already scaled by 2^-48 and clamped
+XDEV uint32_t quant_addr(float pc) { return (__float_as_uint(pc) >> (SSDR_LUT_SHIFT - 2)) & ~3u; }
+XDEV uint32_t quant_pair(uint32_t w0, uint32_t w1) { return __builtin_amdgcn_perm(w1, w0, 0x0C070C03u); }
+
+// |X|^2 cal in double -> the largest float32 not above it, scaled by 2^-48 and clamped to [0, 1]
+XDEV float scaled_power_trunc(cd x, double cal)
+{
+    const double p = fma(x.r, x.r, x.i * x.i) * cal;
+    const long long bits = __double_as_longlong(p) & ~0x1FFFFFFFll;       // 23 mantissa bits stay: the conversion below is exact
+    const float pf = (float)__longlong_as_double(bits);
+    float pc;
+    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(pc) : "v"(pf), "v"(SSDR_LUT_SCALE));
+    return pc;
+}
+
+XDEV double dbl_i16lo(uint32_t raw) { return (double)(int)(int16_t)(raw & 0xFFFFu); }
+XDEV double dbl_i16hi(uint32_t raw) { return (double)((int32_t)raw >> 16); }
+
+// AVG: averaging N > 1 (accumulators); HOP: lines overlap by half (hop 512)
+template <bool AVG, bool HOP>
+__global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_wf_exact_kernel(SsdrWfArgs a, const double2 *tw_g)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];
+    {
+        float *s_win = reinterpret_cast<float *>(smem + LDS_WIN);
+        uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + LDS_LUT0);
+        f64x2 *s_tw = reinterpret_cast<f64x2 *>(smem + LDS_TW);
+        for (int i = threadIdx.x; i < 513; i += blockDim.x) s_win[i] = a.win[i];
+        for (int i = threadIdx.x; i < SSDR_LUT_N; i += blockDim.x) s_lut[i] = a.lut[i];
+        for (int i = threadIdx.x; i < SSDR_TW64_N; i += blockDim.x) s_tw[i] = f64x2{tw_g[i].x, tw_g[i].y};
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char *xch = smem + LDS_XCH + wave * XCH_BYTES;                      // wave-uniform
+    const unsigned char *lut = smem + LDS_LUT0;
+    const uint32_t run = HOP ? a.grp_run : 1u;
+    const uint32_t n_runs = (a.n_groups + run - 1) / run;
+    const uint32_t n_items = a.n_ch * n_runs;
+    const uint32_t wave_stride = gridDim.x * WAVES;
+
+    for (uint32_t item = blockIdx.x * WAVES + wave; item < n_items; item += wave_stride) {
+        uint32_t ch, g_begin, g_end;
+        if (HOP) {                                   // a run of consecutive groups of one channel: the wave walks its lines in order
+            ch = item / n_runs;
+            g_begin = (item - ch * n_runs) * run;
+            g_end = min(g_begin + run, a.n_groups);
+        } else {                                     // group-major
+            g_begin = item / a.n_ch;
+            ch = item - g_begin * a.n_ch;
+            g_end = g_begin + 1;
+        }
+        for (uint32_t grp = g_begin; grp < g_end; grp++) {
+            uint32_t ch_now = __builtin_amdgcn_readfirstlane(ch);
+            asm volatile("" : "+s"(ch_now));
+            const int64_t g0 = (int64_t)grp * a.n_avg - a.phase;
+            const uint32_t l0 = g0 < 0 ? 0u : (uint32_t)g0;
+            const uint32_t l1 = min((uint32_t)(g0 + a.n_avg), a.n_lines);
+            const bool carry_in = (grp == 0) && (a.phase != 0);
+            const bool complete = (g0 + (int64_t)a.n_avg) <= (int64_t)a.n_lines;
+            const double cal = (double)a.consts[ch_now].wf_cal_lin;
+            uint32_t acc[AVG ? 8 : 1];
+#pragma unroll
+            for (int j = 0; j < (AVG ? 8 : 1); j++) acc[j] = 0;
+            constexpr uint32_t LINE_STEP = HOP ? SSDR_NFFT / 2 : SSDR_NFFT;
+            const uint32_t *src = a.iq + (uint64_t)ch_now * a.ch_stride + (uint64_t)l0 * LINE_STEP + lane;
+
+            for (uint32_t line = l0; line < l1; line++, src += LINE_STEP) {
+                // ---- the line: lane L holds samples 64 q + L
+                uint32_t raw[16];
+                if (HOP) {
+                    const uint32_t *older = line ? src - SSDR_NFFT / 2 : a.tail + (uint64_t)ch_now * (SSDR_NFFT / 2) + lane;
+#pragma unroll
+                    for (int q = 0; q < 8; q++) raw[q] = __builtin_nontemporal_load(older + 64 * q);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) raw[8 + q] = src[64 * q];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; q++) raw[q] = __builtin_nontemporal_load(src + 64 * q);
+                }
+                // ---- window (float32 table, products exact in double) with stage 1 folded in: sample n = 64 q + L pairs with
+                //      n + 512; w[n + 512] = w[512 - n] (symmetric table of 513)
+                cd z[16];
+                {
+                    const int ll = opaque(lane);
+                    const float *win_up = reinterpret_cast<const float *>(smem + LDS_WIN) + ll;
+                    const float *win_dn = reinterpret_cast<const float *>(smem + LDS_WIN) + 512 - ll;
+                    float wu[8], wd[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) { wu[q] = win_up[64 * q]; wd[q] = win_dn[-64 * q]; }
+                    XFENCE();
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const double w0 = (double)wu[q], w1 = (double)wd[q];
+                        const double xr = dbl_i16lo(raw[q]), xi = dbl_i16hi(raw[q]);
+                        const double yr = dbl_i16lo(raw[q + 8]), yi = dbl_i16hi(raw[q + 8]);
+                        const double tr = xr * w0, ti = xi * w0;
+                        z[brev4(q)] = cd{fma(yr, w1, tr), fma(yi, w1, ti)};
+                        z[brev4(q) + 1] = cd{fma(-yr, w1, tr), fma(-yi, w1, ti)};
+                    }
+                }
+                XFENCE();
+                stage_const<2>(z);
+                stage_const<3>(z);
+                stage_const<4>(z);
+                XFENCE();
+                // ---- transpose.  Register r of lane L is a-index 16 G + r, G = brev6(L) = hi2 << 4 | rho.  It goes to lane
+                //      L' = hi2 << 4 | lo4 (lo4 = r), register rho.  Slot of (rho, hi2, lo4): rho * 65 + hi2 * 16 + (lo4 ^ hi2).
+                {
+                    const int lx = opaque(lane);
+                    const int G = (int)(__builtin_bitreverse32((uint32_t)lx) >> 26);
+                    const int hi2w = G >> 4, rho_w = G & 15;
+                    double *wbase[4];
+#pragma unroll
+                    for (int x = 0; x < 4; x++)
+                        wbase[x] = reinterpret_cast<double *>(xch) + rho_w * XROW + hi2w * 16 + (x ^ hi2w);
+                    const int hi2r = lx >> 4, lo4r = lx & 15;
+                    const double *rbase = reinterpret_cast<const double *>(xch) + hi2r * 16 + (lo4r ^ hi2r);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) wbase[r & 3][r & 12] = z[r].r;
+                    wave_lds_sync();
+#pragma unroll
+                    for (int j = 0; j < 16; j++) z[j].r = rbase[j * XROW];
+                    wave_lds_sync();
+#pragma unroll
+                    for (int r = 0; r < 16; r++) wbase[r & 3][r & 12] = z[r].i;
+                    wave_lds_sync();
+#pragma unroll
+                    for (int j = 0; j < 16; j++) z[j].i = rbase[j * XROW];
+                    wave_lds_sync();
+                }
+                // ---- stages 5..8: per-lane twiddles T_s[q][lo4]
+                {
+                    const f64x2 *twl = reinterpret_cast<const f64x2 *>(smem + LDS_TW) + (opaque(lane) & 15);
+                    f64x2 w5[1], w6[2], w7[4], w8[8];
+                    w5[0] = twl[T5];
+#pragma unroll
+                    for (int q = 0; q < 2; q++) w6[q] = twl[T6 + 16 * q];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) w7[q] = twl[T7 + 16 * q];
+                    XFENCE();
+                    stage_lane<0>(z, w5);
+                    stage_lane<1>(z, w6);
+                    XFENCE();
+#pragma unroll
+                    for (int q = 0; q < 8; q++) w8[q] = twl[T8 + 16 * q];
+                    XFENCE();
+                    stage_lane<2>(z, w7);
+                    XFENCE();
+                    stage_lane<3>(z, w8);
+                    XFENCE();
+                }
+                // ---- stage 9: pairs a-index bit 8 = lane bit 4.  After the swap lanes with bit 4 clear hold u, v of elements
+                //      rho = m (registers m, m + 8), the others of rho = m + 8; twiddle W_512^(16 rho + lo4)
+                {
+                    const int lx = opaque(lane);
+                    const f64x2 *t9 = reinterpret_cast<const f64x2 *>(smem + LDS_TW) + T9 + (lx & 31);     // [m][b4][lo4]
+                    f64x2 w9[8];
+#pragma unroll
+                    for (int m = 0; m < 8; m++) w9[m] = t9[32 * m];
+#pragma unroll
+                    for (int m = 0; m < 8; m++) { swap16(z[m].r, z[m + 8].r); swap16(z[m].i, z[m + 8].i); }
+                    XFENCE();
+#pragma unroll
+                    for (int m = 0; m < 8; m++) bfly(z[m], z[m + 8], w9[m].x, w9[m].y);
+                    XFENCE();
+                }
+                // ---- stage 10: pairs bit 9 = lane bit 5; register pairs (8 t + mm, 8 t + 4 + mm).  Afterwards the lane holds
+                //      elements rho = mm + 4 b5 + 8 b4 of both t; twiddle W_1024^(256 t + 16 rho + lo4) = (-j)^t W^(16 rho + lo4)
+                {
+                    const int lx = opaque(lane);
+                    const int e = ((lx >> 4) & 1) * 32 + (lx >> 5) * 16 + (lx & 15);                         // [mm][b4][b5][lo4]
+                    const f64x2 *t10 = reinterpret_cast<const f64x2 *>(smem + LDS_TW) + T10 + e;
+                    f64x2 w10[4];
+#pragma unroll
+                    for (int mm = 0; mm < 4; mm++) w10[mm] = t10[64 * mm];
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int mm = 0; mm < 4; mm++) {
+                            swap32(z[8 * t + mm].r, z[8 * t + 4 + mm].r);
+                            swap32(z[8 * t + mm].i, z[8 * t + 4 + mm].i);
+                        }
+                    XFENCE();
+#pragma unroll
+                    for (int mm = 0; mm < 4; mm++) {
+                        bfly(z[mm], z[4 + mm], w10[mm].x, w10[mm].y);
+                        bfly_mjw(z[8 + mm], z[12 + mm], w10[mm].x, w10[mm].y);
+                    }
+                    XFENCE();
+                }
+                // ---- power, exact threshold count.  Register 8 t + 4 c + mm holds FFT bin
+                //      k = 512 c + 256 t + 128 b4 + 64 b5 + 16 mm + lo4; pairs (c = 0, c = 1) share a dword: byte_c0 | byte_c1 << 16
+                uint32_t q01[8];
+                {
+                    float pc[16];
+                    uint32_t e[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        pc[r] = scaled_power_trunc(z[r], cal);
+                        e[r] = *reinterpret_cast<const uint32_t *>(lut + quant_addr(pc[r]));
+                    }
+                    XFENCE();
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int mm = 0; mm < 4; mm++) {
+                            const int r0 = 8 * t + mm, r1 = r0 + 4;
+                            q01[4 * t + mm] = quant_pair(__float_as_uint(pc[r0]) + e[r0], __float_as_uint(pc[r1]) + e[r1]);
+                        }
+                }
+                if (AVG) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc[j] += q01[j];
+                }
+                if (!AVG || line + 1 == l1) {
+                    // ---- the int16 line through the transpose buffer: output position j = k ^ 512 (fftshift)
+                    const int lx = opaque(lane);
+                    int16_t *x16 = reinterpret_cast<int16_t *>(xch) + ((lx >> 4) & 1) * 128 + (lx >> 5) * 64 + (lx & 15);
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int mm = 0; mm < 4; mm++) {
+                            const uint32_t v = AVG ? acc[4 * t + mm] : q01[4 * t + mm];
+                            x16[512 + 256 * t + 16 * mm] = (int16_t)(v & 0xFFFFu);       // c = 0: bin k < 512 -> upper half of the line
+                            x16[256 * t + 16 * mm] = (int16_t)(v >> 16);                // c = 1 -> lower half
+                        }
+                    wave_lds_sync();
+                    const u32x4 *x128 = reinterpret_cast<const u32x4 *>(xch);
+                    int16_t *dst = complete ? a.out + ((uint64_t)grp * a.n_ch + ch_now) * SSDR_NFFT : a.acc_out + (uint64_t)ch_now * SSDR_NFFT;
+                    const int16_t *cin = a.acc_in + (uint64_t)ch_now * SSDR_NFFT;
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+                        u32x4 v = x128[q * 64 + lx];
+                        if (AVG && carry_in) v += reinterpret_cast<const u32x4 *>(cin)[q * 64 + lx];     // sums < 2^15: a packed 2 x 16 add
+                        __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst) + q * 64 + lx);
+                    }
+                    wave_lds_sync();
+                }
+            }
+        }
+    }
 }
 
 } // namespace
 
-hipError_t ssdr_launch_wf_exact(const SsdrWfArgs &a, const double2 *tw, const float *thr, hipStream_t stream)
+// resident workgroups of the kernel on the current device (persistent grid)
+static hipError_t wfx_resident(uint32_t *blocks)
 {
-    hipLaunchKernelGGL(ssdr_wf_exact_kernel, dim3(a.n_ch * a.n_groups), dim3(256), 0, stream, a, tw, thr);
+    static uint32_t cached = 0;
+    if (!cached) {
+        int dev = 0, per_cu = 0, b = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+        per_cu = 1 << 30;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ssdr_wf_exact_kernel<false, false>, SSDR_WFX_BLOCK, 0)) != hipSuccess) return e;
+        per_cu = b < per_cu ? b : per_cu;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ssdr_wf_exact_kernel<true, false>, SSDR_WFX_BLOCK, 0)) != hipSuccess) return e;
+        per_cu = b < per_cu ? b : per_cu;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ssdr_wf_exact_kernel<false, true>, SSDR_WFX_BLOCK, 0)) != hipSuccess) return e;
+        per_cu = b < per_cu ? b : per_cu;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ssdr_wf_exact_kernel<true, true>, SSDR_WFX_BLOCK, 0)) != hipSuccess) return e;
+        per_cu = b < per_cu ? b : per_cu;
+        cached = (uint32_t)prop.multiProcessorCount * (uint32_t)(per_cu < 1 ? 1 : per_cu);
+    }
+    *blocks = cached;
+    return hipSuccess;
+}
+
+hipError_t ssdr_launch_wf_exact(const SsdrWfArgs &a_in, const double2 *tw, hipStream_t stream)
+{
+    SsdrWfArgs a = a_in;
+    if (a.n_groups == 0 || a.n_ch == 0) return hipSuccess;
+    uint32_t resident = 0;
+    hipError_t e = wfx_resident(&resident);
+    if (e != hipSuccess) return e;
+    constexpr uint32_t waves = SSDR_WFX_BLOCK / 64;
+    uint64_t items = (uint64_t)a.n_ch * a.n_groups;
+    a.grp_run = 1;
+    if (a.tail) {            // hop 512: runs of consecutive groups per wave (the shared half-line is re-read by the wave that fetched it)
+        uint64_t run = items / (8ull * resident * waves);
+        run = run < 1 ? 1 : (run > a.n_groups ? a.n_groups : run);
+        a.grp_run = (uint32_t)run;
+        items = (uint64_t)a.n_ch * ((a.n_groups + run - 1) / run);
+    }
+    const uint64_t need = (items + waves - 1) / waves;
+    const dim3 g((uint32_t)(need < resident ? need : resident)), b(SSDR_WFX_BLOCK);
+    if (a.tail) {
+        if (a.n_avg > 1) hipLaunchKernelGGL((ssdr_wf_exact_kernel<true, true>), g, b, 0, stream, a, tw);
+        else hipLaunchKernelGGL((ssdr_wf_exact_kernel<false, true>), g, b, 0, stream, a, tw);
+    } else {
+        if (a.n_avg > 1) hipLaunchKernelGGL((ssdr_wf_exact_kernel<true, false>), g, b, 0, stream, a, tw);
+        else hipLaunchKernelGGL((ssdr_wf_exact_kernel<false, false>), g, b, 0, stream, a, tw);
+    }
     return hipGetLastError();
 }
