@@ -312,6 +312,15 @@ int ssdr_adpcm_decode(ssdr_ctx *ctx, const uint8_t *data, uint32_t n_streams, ui
 int ssdr_feed_open(ssdr_ctx *ctx, uint32_t n_frames, uint32_t depth, uint32_t flags);
 int ssdr_feed_slot(ssdr_ctx *ctx, void **host_in);
 int ssdr_feed_submit(ssdr_ctx *ctx);
+/* The same, but the batch is taken from the caller's own host buffer instead of the slot ssdr_feed_slot hands out (layout and
+ * size of that slot).  For an ingest that assembles its batches in place (supersdr_amd/workers.py:IQHub, whose ring of
+ * superframe slots is the thing KiwiSDRStream._process_iq_samples fills, kiwi/client.py:493-494): no copy into the slot.
+ * The buffer must stay untouched until ssdr_feed_collect has returned that batch; pinned memory (ssdr_host_alloc) keeps
+ * the copy asynchronous.  SSDR_ESTATE while a slot from ssdr_feed_slot is outstanding or every slot is in flight. */
+int ssdr_feed_submit_from(ssdr_ctx *ctx, const void *host_in);
+/* Pinned host memory for such buffers (hipHostMalloc); freed by ssdr_host_free, not by ssdr_destroy. */
+int ssdr_host_alloc(ssdr_ctx *ctx, uint64_t bytes, void **out);
+int ssdr_host_free(ssdr_ctx *ctx, void *ptr);
 int ssdr_feed_collect(ssdr_ctx *ctx, int16_t **wf_sum, uint32_t *lines, int16_t **pcm, float **rssi, float **wire_rssi,
                       uint8_t **flags, uint32_t *n_avg);
 int ssdr_feed_post(ssdr_ctx *ctx, const ssdr_db2col_chan *chans, const ssdr_play_chan *play);

@@ -106,6 +106,9 @@ _SIGS = {
     "ssdr_feed_open": (C.c_int, [_P, C.c_uint32, C.c_uint32, C.c_uint32]),
     "ssdr_feed_slot": (C.c_int, [_P, C.POINTER(_P)]),
     "ssdr_feed_submit": (C.c_int, [_P]),
+    "ssdr_feed_submit_from": (C.c_int, [_P, _P]),
+    "ssdr_host_alloc": (C.c_int, [_P, C.c_uint64, C.POINTER(_P)]),
+    "ssdr_host_free": (C.c_int, [_P, _P]),
     "ssdr_feed_collect": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_uint32), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P),
                                     C.POINTER(_P), C.POINTER(C.c_uint32)]),
     "ssdr_feed_post": (C.c_int, [_P, C.POINTER(Db2colChan), C.POINTER(PlayChan)]),

@@ -1154,17 +1154,16 @@ int ssdr_feed_slot(ssdr_ctx *c, void **host_iq)
     return SSDR_OK;
 }
 
-int ssdr_feed_submit(ssdr_ctx *c)
+// host_in: where the batch lies (the slot's own pinned buffer, or the caller's -- ssdr_feed_submit_from)
+static int feed_submit_impl(ssdr_ctx *c, const void *host_in)
 {
-    if (!c) return SSDR_EINVAL;
-    if (c->feed.empty() || !c->feed_taken) return SSDR_ESTATE;
     HIP_TRY(hipSetDevice(c->device));
     auto &s = c->feed[c->feed_head];
     const uint32_t nf = c->feed_frames;
     if (c->feed_wire)
-        HIP_TRY(hipMemcpyAsync(s.d_wire, s.h_in, (size_t)c->n_ch * nf * SSDR_WIRE_BODY, hipMemcpyHostToDevice, c->feed_s_in));
+        HIP_TRY(hipMemcpyAsync(s.d_wire, host_in, (size_t)c->n_ch * nf * SSDR_WIRE_BODY, hipMemcpyHostToDevice, c->feed_s_in));
     else
-        HIP_TRY(hipMemcpyAsync(s.d_in, s.h_in, (size_t)c->n_ch * nf * SSDR_FRAME * 4, hipMemcpyHostToDevice, c->feed_s_in));
+        HIP_TRY(hipMemcpyAsync(s.d_in, host_in, (size_t)c->n_ch * nf * SSDR_FRAME * 4, hipMemcpyHostToDevice, c->feed_s_in));
     HIP_TRY(hipEventRecord(s.ev_in, c->feed_s_in));
     HIP_TRY(hipStreamWaitEvent(c->stream, s.ev_in, 0));
     if (c->feed_wire) {                                  // header strip + big-endian -> little-endian on the device
@@ -1247,6 +1246,39 @@ int ssdr_feed_submit(ssdr_ctx *c)
     c->feed_head = (c->feed_head + 1) % (uint32_t)c->feed.size();
     c->feed_inflight++;
     c->feed_taken = false;
+    return SSDR_OK;
+}
+
+int ssdr_feed_submit(ssdr_ctx *c)
+{
+    if (!c) return SSDR_EINVAL;
+    if (c->feed.empty() || !c->feed_taken) return SSDR_ESTATE;
+    return feed_submit_impl(c, c->feed[c->feed_head].h_in);
+}
+
+int ssdr_feed_submit_from(ssdr_ctx *c, const void *host_in)
+{
+    if (!c || !host_in) return SSDR_EINVAL;
+    if (c->feed.empty() || c->feed_taken) return SSDR_ESTATE;
+    if (c->feed_inflight == c->feed.size()) return SSDR_ESTATE;      // collect first: every slot is in flight
+    return feed_submit_impl(c, host_in);
+}
+
+int ssdr_host_alloc(ssdr_ctx *c, uint64_t bytes, void **out)
+{
+    if (!c || !out || bytes == 0) return SSDR_EINVAL;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
+    return SSDR_OK;
+}
+
+int ssdr_host_free(ssdr_ctx *c, void *ptr)
+{
+    if (!c) return SSDR_EINVAL;
+    if (!ptr) return SSDR_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipHostFree(ptr));
     return SSDR_OK;
 }
 

@@ -60,9 +60,11 @@ class SsdrEngine:
         self.zoom = 1
         self.kiwi_rate = L.RATE
         self.audio_frames = 0          # frames of the last run_audio / set_pcm (extent of the device PCM / RSSI / flags)
+        self._pinned = []              # host_alloc()
 
     def close(self):
         if self._ctx:
+            self.host_free_all()
             lib.ssdr_destroy(self._ctx)
             self._ctx = L._P()
 
@@ -219,13 +221,15 @@ class SsdrEngine:
 
     # ---- the reference's post-processing on the GPU
     def run_db2col(self, chans, lines, fetch=True):
-        """spectrum_db2col for the lines of the last run_wf.  chans: list of Db2colChan (updated in place).
+        """spectrum_db2col for the lines of the last run_wf.  chans: list of Db2colChan, or a ctypes array
+        (Db2colChan * n_ch) that goes to the library as it is (no per-channel Python work); updated in place.
         -> float32 [lines, n_ch, 1024] wf_color."""
-        arr = (Db2colChan * self.n_ch)(*chans)
+        arr = chans if isinstance(chans, C.Array) else (Db2colChan * self.n_ch)(*chans)
         out = np.empty((lines, self.n_ch, L.NFFT), np.float32) if fetch else None
         check(lib.ssdr_run_db2col(self._ctx, arr, out.ctypes.data if fetch else None, 0), "ssdr_run_db2col")
-        for i in range(self.n_ch):
-            chans[i] = arr[i]
+        if arr is not chans:
+            for i in range(self.n_ch):
+                chans[i] = arr[i]
         return out
 
     # ---- pipelined host feed (copy-in / kernels / copy-out of consecutive batches overlap)
@@ -238,8 +242,8 @@ class SsdrEngine:
 
     def feed_post(self, chans=None, play=None):
         """display state for the batches submitted from now on: lists of Db2colChan / PlayChan (None keeps the previous)"""
-        a = (Db2colChan * self.n_ch)(*chans) if chans is not None else None
-        b = (PlayChan * self.n_ch)(*play) if play is not None else None
+        a = chans if chans is None or isinstance(chans, C.Array) else (Db2colChan * self.n_ch)(*chans)
+        b = play if play is None or isinstance(play, C.Array) else (PlayChan * self.n_ch)(*play)
         check(lib.ssdr_feed_post(self._ctx, a, b), "ssdr_feed_post")
 
     def feed_collect_post(self):
@@ -251,7 +255,7 @@ class SsdrEngine:
         color = chans = mono = None
         if nl and col.value:
             color = np.ctypeslib.as_array(C.cast(col, C.POINTER(C.c_float)), shape=(nl * self.n_ch * L.NFFT,)).reshape(nl, self.n_ch, L.NFFT)
-            chans = list((Db2colChan * self.n_ch).from_address(ch.value))
+            chans = (Db2colChan * self.n_ch).from_address(ch.value)        # indexable view of the slot's pinned copy
         play = np.ctypeslib.as_array(C.cast(pl, C.POINTER(C.c_int16)), shape=(self.n_ch * nf * P * 2,)).reshape(self.n_ch, nf * P, 2)
         if mo.value:
             mono = np.ctypeslib.as_array(C.cast(mo, C.POINTER(C.c_int16)), shape=(self.n_ch * nf * P,)).reshape(self.n_ch, nf * P)
@@ -270,6 +274,32 @@ class SsdrEngine:
 
     def feed_submit(self):
         check(lib.ssdr_feed_submit(self._ctx), "ssdr_feed_submit")
+
+    def feed_submit_from(self, batch):
+        """queue a batch that lies in the caller's own host array (layout of feed_slot(); ideally from host_alloc): no copy
+        into a slot.  The array must stay untouched until feed_collect has returned this batch."""
+        if not (batch.flags.c_contiguous and batch.nbytes == self._feed_bytes()):
+            raise ValueError("feed_submit_from: the batch must be C-contiguous and exactly one slot in size")
+        check(lib.ssdr_feed_submit_from(self._ctx, batch.ctypes.data), "ssdr_feed_submit_from")
+
+    def _feed_bytes(self):
+        return self.n_ch * self._feed_frames * (L.WIRE_BODY if self._feed_wire else L.FRAME * 4)
+
+    def host_alloc(self, shape, dtype):
+        """-> NumPy array over pinned host memory (hipHostMalloc): H2D copies from it are asynchronous.  Freed with the
+        engine (close()) or by host_free(array)."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        check(lib.ssdr_host_alloc(self._ctx, n, C.byref(p)), "ssdr_host_alloc")
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n,)).view(dtype).reshape(shape)
+        self._pinned.append(p.value)
+        return arr
+
+    def host_free_all(self):
+        for p in self._pinned:
+            lib.ssdr_host_free(self._ctx, C.c_void_p(p))
+        self._pinned = []
 
     def feed_collect(self):
         """Oldest submitted batch -> (wf int16 [lines, n_ch, 1024], pcm int16 [n_ch, n_frames*512], rssi float32
@@ -341,8 +371,8 @@ class SsdrEngine:
 
     def run_playbuffer(self, chans, fetch=True):
         """play_buffer for the frames of the last run_audio -> int16 [n_ch, n_frames*L, 2], L = playbuffer_frame_len()
-        (2048 at 12 kHz, 1213 at 20.25 kHz)."""
-        arr = (PlayChan * self.n_ch)(*chans)
+        (2048 at 12 kHz, 1213 at 20.25 kHz).  chans: list of PlayChan or a ctypes array (PlayChan * n_ch)."""
+        arr = chans if isinstance(chans, C.Array) else (PlayChan * self.n_ch)(*chans)
         out = np.empty((self.n_ch, self.audio_frames * self.playbuffer_frame_len(), 2), np.int16) if fetch else None
         check(lib.ssdr_run_playbuffer(self._ctx, arr, out.ctypes.data if fetch else None, 0), "ssdr_run_playbuffer")
         return out

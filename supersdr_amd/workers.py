@@ -28,6 +28,7 @@ raises, and play_buffer() (a PortAudio callback, which must not raise) plays sil
 error in `kiwi_sound.error`.
 """
 import contextlib
+import ctypes as C
 import logging
 import queue
 import struct
@@ -65,33 +66,94 @@ class Frame(np.ndarray):
         return f
 
 
+class SuperframeResult:
+    """What one GPU run of the hub produced, as the arrays the engine returned (all channels, no per-channel objects):
+    wf int16 [lines, n_ch, 1024] sums of n_avg byte lines, pcm int16 [n_ch, frames*512], rssi float32 [n_ch, frames],
+    flags uint8 [n_ch, frames]; with gpu_post also color float32 [lines, n_ch, 1024], chans (Db2colChan per channel, as
+    spectrum_db2col left them), play int16 [n_ch, frames*L, 2], mono (recording) -- or None where that stage did not run.
+    In pipeline mode the arrays are views of the feed's pinned slots: valid until `depth - 1` further superframes have
+    been collected (copy what must live longer)."""
+    __slots__ = ("seq", "wf", "n_avg", "color", "chans", "pcm", "rssi", "flags", "play", "mono", "iq", "wire_rssi")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+class _ClientSlots(list):
+    """hub.wf_clients / hub.snd_clients: the worker object of every channel (None: nobody).  Assigning an entry attaches
+    the channel: from then on its results are queued for that worker."""
+
+    def __init__(self, n, on_change):
+        super().__init__([None] * n)
+        self._on_change = on_change
+
+    def __setitem__(self, c, obj):
+        old = self[c]
+        super().__setitem__(c, obj)
+        self._on_change(int(c), old, obj)
+
+
+class _Queues:
+    """hub.wf_queue / hub.snd_queue: one bounded queue per ATTACHED channel.  A hub of a few receivers attaches every channel
+    at start (`lazy=False`); a hub of 10^5 channels creates a queue -- and per-channel result objects -- only for the
+    channels somebody listens to: indexing a channel attaches it (results produced from then on are queued)."""
+
+    def __init__(self, hub, kind, maxsize):
+        self._hub, self._kind, self._max, self._q = hub, kind, maxsize, {}
+
+    def __getitem__(self, c):
+        q = self._q.get(c)
+        return q if q is not None else self._hub.attach(c, **{self._kind: True})[self._kind]
+
+    def __len__(self):
+        return self._hub.n_ch
+
+    def attached(self, c):
+        return self._q.get(c)
+
+
 class IQHub:
     """Batches per-channel IQ into superframes and runs the GPU path for all channels at once.
 
-    feed(channel, iq_int16[n,2]) appends samples of one channel (any n) to that channel's ring buffer; whenever
-    every channel has >= 1024 samples buffered, one superframe is pushed, both kernels run, and the results land
-    in per-channel queues:
+    Ingest (KiwiSDRStream._process_iq_samples, kiwi/client.py:493-494, for a whole block of receivers):
+        feed(channel, iq[n, 2])                      samples of one channel, any n
+        feed_block(first_channel, iq[k, n, 2])       the same n samples for k consecutive channels: ONE strided copy
+        reserve(first_channel, k) / commit(...)      the block's place in the open superframe slot, to be filled in place
+        feed_wire_block(first_channel, bodies[k, f, 2065])   hubs built with wire=True: SND bodies as they come off the socket
+    The ring is a short ring of SUPERFRAME SLOTS, each laid out as the batch the engine takes ([n_ch, samples, 2], pinned
+    host memory when the hub is pipelined): a channel's samples are written once, where the H2D copy will read them.
+    Per-channel state is NumPy (write positions, stall / drop counters); whether a superframe can run is decided from
+    two incrementally kept numbers (channels that completed the open slot, the furthest write position), not by a scan.
+    Whenever every channel has a superframe buffered, it is pushed, the kernels run, and the results are kept as the
+    arrays the engine returned (`last`, `subscribe()`); per-channel queues and Frame objects exist only for ATTACHED
+    channels -- those with a kiwi_waterfall / kiwi_sound / GpuStream on them (or attach()):
         wf_queue[c]  : (int16[1024] sum of N byte lines, N, db2col result or None)
         snd_queue[c] : Frame (int16[512] pcm + rssi, ADC-overflow flag, 48 kHz blocks) per audio frame
+    `lazy=None` attaches every channel at start on hubs of up to 1024 channels (a receiver UI) and none above that.
 
     A receiver that stalls or reconnects (KiwiWorker sleeps 5-15 s on its retry paths, kiwi/worker.py:58, 66) does not
     stop the others: once a healthy channel is `stall_superframes` ahead, the hub runs anyway and the lagging channel's
-    superframe is zero-filled (`stalled[c]` counts them).  A ring holds `backlog_superframes`; beyond that the oldest
-    samples of that channel are dropped (`dropped[c]` counts samples).
+    superframe is zero-filled (`stalled[c]` counts them; what it had buffered moves to the next slot).  A channel may
+    run `backlog_superframes` ahead; beyond that its oldest buffered superframe is dropped (`dropped[c]` counts samples).
 
     Time binning: every kiwi_waterfall asks for its own N (the reference keeps averaging_n per instance,
     utils_supersdr.py:881-886).  The GPU sums N lines when all clients agree; when they disagree it delivers single
-    lines and the clients that want N > 1 take the reference's own mean of N of them (a group is never restarted by
-    another client's call).
+    lines and the clients that want N > 1 take the reference's own mean of N of them.
 
-    pipeline=True sends the superframes through ssdr_feed_*: pinned slots, copy-in / kernels / copy-out of consecutive
-    superframes overlapped, ONE C-ABI submit and one collect per superframe; with gpu_post the slot pipeline also runs
-    spectrum_db2col and play_buffer (SSDR_FEED_POST) with the display state latched at submit.  Results arrive
+    pipeline=True sends the superframes through ssdr_feed_*: copy-in / kernels / copy-out of consecutive superframes
+    overlapped, the copy-in straight from the hub's (pinned) slot (ssdr_feed_submit_from); with gpu_post the slot pipeline
+    also runs spectrum_db2col and play_buffer (SSDR_FEED_POST) with the display state latched at submit.  Results arrive
     `depth - 1` superframes late (flush() drains) and are bit-identical to the synchronous hub's.
+    `batch_superframes=K` runs K superframes per GPU call (K lines + 2K audio frames per channel and call): latency for
+    launch efficiency at very large channel counts.
     """
 
+    LAZY_ABOVE = 1024
+
     def __init__(self, n_channels, device=0, engine=None, max_queue=64, gpu_post=True, kiwi_rate=12000, trace_rows=0,
-                 backlog_superframes=8, stall_superframes=4, pipeline=False, depth=3, hop=1024, zoom=1):
+                 backlog_superframes=8, stall_superframes=4, pipeline=False, depth=3, hop=1024, zoom=1, lazy=None,
+                 batch_superframes=1, wire=False):
         self.n_ch = int(n_channels)
         self.engine = engine if engine is not None else SsdrEngine(self.n_ch, device)
         # waterfall zoom ("SET zoom=", utils_supersdr.py:741, 839): the lines then span 1/zoom of the IQ band around each
@@ -101,7 +163,8 @@ class IQHub:
             if pipeline:
                 raise ValueError("zoom needs the synchronous hub (the pipelined feed's slots hold un-zoomed lines)")
             self.engine.set_wf_zoom(self.zoom)
-        self._sf = L.NFFT * self.zoom                # samples per channel and GPU run
+        self.batch_superframes = max(1, int(batch_superframes))
+        self._sf = L.NFFT * self.zoom * self.batch_superframes       # samples per channel and GPU run
         if hop != L.NFFT:                            # 512: two waterfall lines per superframe, 23.4 lines/s (MAX_FPS = 23, utils:597)
             self.engine.set_hop(hop)
         # spectrum_db2col and play_buffer run on the GPU with every superframe
@@ -119,39 +182,126 @@ class IQHub:
         if self.trace_rows:
             self.engine.set_wfdata_rows(self.trace_rows)
         self._smeter = None
-        self.wf_clients = [None] * self.n_ch        # kiwi_waterfall objects: display state for db2col
-        self.snd_clients = [None] * self.n_ch       # kiwi_sound objects: volume / balance for play_buffer
-        self._cap = max(2, int(backlog_superframes)) * self._sf
-        self._stall = max(1, int(stall_superframes)) * self._sf
-        self._ring = np.zeros((self.n_ch, self._cap, 2), np.int16)
-        self._rd = [0] * self.n_ch                  # absolute sample counters; ring index = counter % cap
-        self._wr = [0] * self.n_ch
-        self._batch = np.zeros((self.n_ch, self._sf, 2), np.int16)
-        self.dropped = [0] * self.n_ch
-        self.stalled = [0] * self.n_ch
-        self.wf_queue = [queue.Queue(max_queue) for _ in range(self.n_ch)]
-        self.snd_queue = [queue.Queue(2 * max_queue) for _ in range(self.n_ch)]
-        self._params = [default_params("am") for _ in range(self.n_ch)]
-        self._want_n = [1] * self.n_ch              # averaging_n asked for by each channel's waterfall client
-        self.averaging_n = 1                        # what the GPU sums right now
-        self._recording = False
-        self._lock = threading.Lock()
-        self.superframes = 0
         self.pipeline = bool(pipeline)
         self._inflight, self._depth = 0, int(depth)
+        self.wire = bool(wire)                       # slots hold SND bodies (kiwi/client.py:443-454), unpacked on the device
+        # ---- the ring of superframe slots.  Unit = what a channel's write position counts: samples, or SND frames (wire)
+        if self.wire:
+            self._U, self._row = self._sf // L.FRAME, (L.WIRE_BODY,)
+            dtype = np.uint8
+        else:
+            self._U, self._row = self._sf, (2,)
+            dtype = np.int16
+        self._cap = max(2, int(backlog_superframes) // self.batch_superframes)          # slots a channel may run ahead (incl. the open one)
+        self._stall = max(1, int(stall_superframes) // self.batch_superframes) * self._U
+        # a pipelined hub may not rewrite a slot before the batch that left from it has been collected: depth - 1 more slots
+        self._nslots = self._cap + (self._depth - 1 if self.pipeline else 0)
+        alloc = getattr(self.engine, "host_alloc", None) if self.pipeline else None
+        shape = (self.n_ch, self._U) + self._row
+        self._slots = [alloc(shape, dtype) if alloc else np.zeros(shape, dtype) for _ in range(self._nslots)]
+        if alloc:
+            for sl in self._slots:
+                sl[...] = 0
+        self._base = 0                               # index of the next superframe to run == slot self._base % nslots
+        self._gw = np.zeros(self.n_ch, np.int64)     # write positions on the hub's time axis, units (>= base * U)
+        self._nfull = 0                              # channels with gw >= (base + 1) * U, kept incrementally
+        self._gmax = 0                               # max(gw), kept incrementally
+        self.dropped = np.zeros(self.n_ch, np.int64)
+        self.stalled = np.zeros(self.n_ch, np.int64)
+        # ---- results
+        self.last = None                             # SuperframeResult of the newest GPU run
+        self._subscribers = []
+        self._lazy = (self.n_ch > self.LAZY_ABOVE) if lazy is None else bool(lazy)
+        self._max_queue = int(max_queue)
+        self.wf_queue = _Queues(self, "wf", self._max_queue)
+        self.snd_queue = _Queues(self, "snd", 2 * self._max_queue)
+        self._wf_att, self._snd_att = [], []         # attached channels, sorted
+        self._n_wf_clients = self._n_snd_clients = 0
+        self.wf_clients = _ClientSlots(self.n_ch, self._wf_client_changed)      # kiwi_waterfall objects: display state for db2col
+        self.snd_clients = _ClientSlots(self.n_ch, self._snd_client_changed)    # kiwi_sound objects: volume / balance for play_buffer
+        self._db_arr = (Db2colChan * self.n_ch)()
+        self._play_arr = (PlayChan * self.n_ch)()
+        d0 = self._db2col_chan(None)
+        _fill_struct_array(self._db_arr, d0)
+        _fill_struct_array(self._play_arr, PlayChan(100.0, 0.0))
+        self._params = {}                            # channel -> ChanParams, for the channels that were given any
+        self._default_params = default_params("am")
+        self._n_iq_mode = 0
+        self._want_n = np.ones(self.n_ch, np.int32)  # averaging_n asked for by each channel's waterfall client
+        self._want_all = {1: self.n_ch}              # N -> channels that want it (all channels / channels with a client)
+        self._want_cli = {}
+        self.averaging_n = 1                         # what the GPU sums right now
+        self._recording = False
+        self._lock = threading.RLock()
+        self.superframes = 0
         if self.pipeline:
-            self.engine.feed_open(2, self._depth, post=self.gpu_post)
+            self.engine.feed_open(2 * self.zoom * self.batch_superframes, self._depth, post=self.gpu_post, **({"wire": True} if self.wire else {}))
+        if not self._lazy:
+            for c in range(self.n_ch):
+                self.attach(c, wf=True, snd=True)
+
+    # ---- who listens
+    def attach(self, channel, wf=False, snd=False):
+        """create the result queue(s) of a channel: its waterfall lines / audio frames are queued from now on"""
+        c = int(channel)
+        if not 0 <= c < self.n_ch:
+            raise IndexError("channel %d of %d" % (c, self.n_ch))
+        with self._lock:
+            import bisect
+            if wf and c not in self.wf_queue._q:
+                self.wf_queue._q[c] = queue.Queue(self._max_queue)
+                bisect.insort(self._wf_att, c)
+            if snd and c not in self.snd_queue._q:
+                self.snd_queue._q[c] = queue.Queue(2 * self._max_queue)
+                bisect.insort(self._snd_att, c)
+        return {"wf": self.wf_queue._q.get(c), "snd": self.snd_queue._q.get(c)}
+
+    def detach(self, channel, wf=True, snd=True):
+        c = int(channel)
+        with self._lock:
+            if wf and self.wf_queue._q.pop(c, None) is not None:
+                self._wf_att.remove(c)
+            if snd and self.snd_queue._q.pop(c, None) is not None:
+                self._snd_att.remove(c)
+
+    def subscribe(self, fn):
+        """fn(SuperframeResult) after every GPU run, on the feeding thread, with the hub's lock held: the bulk consumer's
+        hook (a recorder, a detector over all channels); per-channel consumers use the queues"""
+        self._subscribers.append(fn)
+
+    def _wf_client_changed(self, c, old, new):
+        with self._lock:
+            self._n_wf_clients += (new is not None) - (old is not None)
+            n = int(self._want_n[c])
+            if (new is not None) != (old is not None):
+                self._want_cli[n] = self._want_cli.get(n, 0) + (1 if new is not None else -1)
+                if not self._want_cli[n]:
+                    del self._want_cli[n]
+            if new is not None:
+                self.attach(c, wf=True)
+                self._db_arr[c] = self._db2col_chan(new)
+            else:
+                self._db_arr[c] = self._db2col_chan(None)
+
+    def _snd_client_changed(self, c, old, new):
+        with self._lock:
+            self._n_snd_clients += (new is not None) - (old is not None)
+            if new is not None:
+                self.attach(c, snd=True)
+            else:
+                self._play_arr[c] = PlayChan(100.0, 0.0)
 
     # ---- control plane (forwarded SET commands)
     def params(self, channel):
-        return self._params[channel]
+        return self._params.get(int(channel), self._default_params)
 
     def set_params(self, channel, p):
         if self.pipeline and p.mode == L.MODE_IQ:    # the feed's slots hand out PCM rows only (an IQ channel's row carries I)
             raise ValueError("mod=iq needs the synchronous hub: the pipelined feed does not return I,Q pairs")
         with self._lock:
             self.engine.set_params(channel, [p])     # raises for parameters the library refuses; the old ones stay
-            self._params[channel] = p
+            self._n_iq_mode += (p.mode == L.MODE_IQ) - (self.params(channel).mode == L.MODE_IQ)
+            self._params[int(channel)] = p
 
     def set_wf_center(self, channel, offset_hz):
         """zoom centre of one channel, Hz from the centre of its IQ band (restarts that channel's zoomed stream)"""
@@ -163,116 +313,236 @@ class IQHub:
         n = int(min(max(n, 1), 100))
         with self._lock:
             if channel is None:
-                self._want_n = [n] * self.n_ch
+                self._want_n[:] = n
+                self._want_all = {n: self.n_ch}
+                self._want_cli = {n: self._n_wf_clients} if self._n_wf_clients else {}
             else:
-                self._want_n[channel] = n
-            wants = {self._want_n[c] for c in range(self.n_ch) if self.wf_clients[c] is not None} or set(self._want_n)
-            eff = wants.pop() if len(wants) == 1 else 1
+                c, old = int(channel), int(self._want_n[channel])
+                if old != n:
+                    self._want_n[c] = n
+                    for cnt in (self._want_all,) + ((self._want_cli,) if self.wf_clients[c] is not None else ()):
+                        cnt[n] = cnt.get(n, 0) + 1
+                        cnt[old] -= 1
+                        if not cnt[old]:
+                            del cnt[old]
+            wants = self._want_cli or self._want_all
+            eff = next(iter(wants)) if len(wants) == 1 else 1
             if eff != self.averaging_n:
                 self.averaging_n = eff
                 self.engine.set_averaging(eff)
 
-    # ---- data plane
-    def feed(self, channel, iq):
-        iq = np.asarray(iq, np.int16).reshape(-1, 2)
-        with self._lock:
-            pos = 0
-            while pos < len(iq):                                 # ring-sized pieces, pumping in between
-                n = min(len(iq) - pos, self._sf)
-                over = (self._wr[channel] - self._rd[channel]) + n - self._cap
-                if over > 0:                                     # nobody consumes: drop-oldest, like the result queues
-                    self._rd[channel] += over
-                    self.dropped[channel] += over
-                w = self._wr[channel] % self._cap
-                first = min(n, self._cap - w)
-                self._ring[channel, w:w + first] = iq[pos:pos + first]
-                if first < n:
-                    self._ring[channel, :n - first] = iq[pos + first:pos + n]
-                self._wr[channel] += n
-                pos += n
-                self._pump()
+    # ---- data plane: ingest
+    def backlog(self, channel):
+        """samples (wire hubs: frames) of `channel` that are buffered and not yet run"""
+        return int(self._gw[channel]) - self._base * self._U
 
-    def _take(self, c):
-        """next superframe of channel c into the batch; False (zero-filled) if the channel does not have one"""
-        if self._wr[c] - self._rd[c] < self._sf:
-            self._batch[c] = 0
-            return False
-        r = self._rd[c] % self._cap
-        first = min(self._sf, self._cap - r)
-        self._batch[c, :first] = self._ring[c, r:r + first]
-        if first < self._sf:
-            self._batch[c, first:] = self._ring[c, :self._sf - first]
-        self._rd[c] += self._sf
-        return True
+    @property
+    def ring_capacity(self):
+        """what a channel may have buffered at most, samples (wire hubs: frames)"""
+        return self._cap * self._U
+
+    def feed(self, channel, iq):
+        """samples of one channel: int16 [n, 2] (any n)"""
+        iq = np.asarray(iq, np.int16).reshape(1, -1, 2)
+        if self.wire:
+            raise ValueError("this hub takes SND bodies (feed_wire_block)")
+        with self._lock:
+            self._feed_run(int(channel), iq)
+
+    def feed_block(self, first_channel, iq):
+        """the same number of samples for k consecutive channels: int16 [k, n, 2].  Channels that stand at the same write
+        position (receivers fed in step) take one strided copy per slot they touch."""
+        iq = np.asarray(iq, np.int16)
+        if self.wire or iq.ndim != 3 or iq.shape[2] != 2 or not 0 <= first_channel <= self.n_ch - iq.shape[0]:
+            raise ValueError("feed_block takes int16 [k, n, 2] for channels [first, first + k) of a sample hub")
+        with self._lock:
+            self._feed_runs(int(first_channel), iq)
+
+    def feed_wire_block(self, first_channel, bodies):
+        """wire hubs: f SND bodies (7-byte header, 10-byte GNSS stamp, 512 big-endian I,Q pairs: kiwi/client.py:443-454)
+        for k consecutive channels, uint8 [k, f, 2065]; header strip and byte swap run on the device"""
+        bodies = np.asarray(bodies, np.uint8)
+        if not self.wire or bodies.ndim != 3 or bodies.shape[2] != L.WIRE_BODY or not 0 <= first_channel <= self.n_ch - bodies.shape[0]:
+            raise ValueError("feed_wire_block takes uint8 [k, f, %d] for channels [first, first + k) of a wire hub" % L.WIRE_BODY)
+        with self._lock:
+            self._feed_runs(int(first_channel), bodies)
+
+    def reserve(self, first_channel, k):
+        """-> writable view [k, room, 2] (wire: [k, room, 2065]) of where the next samples of channels [first, first + k) go,
+        or None when they do not stand at one write position (use feed_block then).  Fill view[:, :n] and commit(first, k, n):
+        the ingest writes where the H2D copy reads, no copy in between."""
+        with self._lock:
+            g = self._gw[first_channel:first_channel + k]
+            g0 = int(g[0])
+            if k > 1 and (g != g0).any():
+                return None
+            b, off = divmod(g0, self._U)
+            if b >= self._base + self._cap:
+                return None
+            self._await_slot(b)
+            return self._slots[b % self._nslots][first_channel:first_channel + k, off:]
+
+    def commit(self, first_channel, k, n):
+        with self._lock:
+            g0 = int(self._gw[first_channel])
+            b, off = divmod(g0, self._U)
+            if n < 0 or off + n > self._U:
+                raise ValueError("commit beyond the reserved room")
+            self._advance(first_channel, k, g0, n)
+            self._pump()
+
+    def _feed_runs(self, first, data):
+        """split a block into runs of channels that stand at the same write position"""
+        g = self._gw[first:first + data.shape[0]]
+        if data.shape[0] == 1 or (g == g[0]).all():
+            return self._feed_run(first, data)
+        cuts = np.flatnonzero(g[1:] != g[:-1]) + 1
+        lo = 0
+        for hi in list(cuts) + [data.shape[0]]:
+            self._feed_run(first + lo, data[lo:hi])
+            lo = int(hi)
+
+    def _advance(self, first, k, g0, n):
+        U = self._U
+        self._gw[first:first + k] += n
+        if g0 < (self._base + 1) * U <= g0 + n:
+            self._nfull += k
+        if g0 + n > self._gmax:
+            self._gmax = g0 + n
+
+    def _feed_run(self, first, data):
+        """data [k, n, ...] for k channels at ONE write position: slot-sized pieces, pumping in between"""
+        k, n = data.shape[0], data.shape[1]
+        U, pos = self._U, 0
+        while pos < n:
+            g0 = int(self._gw[first])
+            b, off = divmod(g0, U)
+            if b >= self._base + self._cap:                      # nobody consumes: the oldest buffered superframe goes
+                self._drop_oldest(first, k)
+                continue
+            self._await_slot(b)
+            m = min(n - pos, U - off)
+            self._slots[b % self._nslots][first:first + k, off:off + m] = data[:, pos:pos + m]
+            self._advance(first, k, g0, m)
+            pos += m
+            self._pump()
+
+    def _await_slot(self, b):
+        """pipelined hub: slot b % nslots last left as batch b - nslots; it may be rewritten once that batch was collected"""
+        if self.pipeline:
+            while self._inflight and b - self._nslots >= self.superframes - self._inflight:
+                self._collect()
+
+    def _drop_oldest(self, first, k):
+        """channels [first, first + k) stand at the end of the ring: their buffered superframes move one slot down"""
+        U, ns = self._U, self._nslots
+        for j in range(self._cap - 1):
+            self._slots[(self._base + j) % ns][first:first + k] = self._slots[(self._base + j + 1) % ns][first:first + k]
+        self._gw[first:first + k] -= U
+        self.dropped[first:first + k] += U
+        self._gmax = int(self._gw.max())
 
     def _pump(self):
+        U = self._U
         while True:
-            avail = [self._wr[c] - self._rd[c] for c in range(self.n_ch)]
-            if min(avail) < self._sf and max(avail) < self._stall + self._sf:
+            if self._nfull < self.n_ch and self._gmax - self._base * U < self._stall + U:
                 return                                           # wait for the slowest channel, but not for ever
-            for c in range(self.n_ch):
-                if not self._take(c):
-                    self.stalled[c] += 1
+            cur = self._slots[self._base % self._nslots]
+            if self._nfull < self.n_ch:                          # somebody is `stall` ahead: the laggards get silence
+                lim = (self._base + 1) * U
+                lag = np.flatnonzero(self._gw < lim)
+                fill = self._gw[lag] - self._base * U
+                nxt = self._slots[(self._base + 1) % self._nslots]
+                for c, f in zip(lag[fill > 0].tolist(), fill[fill > 0].tolist()):     # what they had buffered waits for the next run
+                    nxt[c, :f] = cur[c, :f]
+                cur[lag] = 0
+                self._gw[lag] += U
+                self.stalled[lag] += 1
             if self.pipeline:
-                self._run_pipelined()
+                self._run_pipelined(cur)
             else:
-                self._run_superframe()
+                self._run_superframe(cur)
+            self._base += 1
+            self._nfull = int(np.count_nonzero(self._gw >= (self._base + 1) * U))
 
-    def _play_chans(self):
-        return [PlayChan(float(s.volume), float(s.audio_balance)) if s is not None else PlayChan(100.0, 0.0)
-                for s in self.snd_clients]
+    # ---- data plane: the GPU run and what becomes of its results
+    def _sync_display_state(self):
+        """the attached workers' display state into the two per-channel arrays the post kernels read"""
+        for c in self._wf_att:
+            w = self.wf_clients[c]
+            if w is not None:
+                self._db_arr[c] = self._db2col_chan(w)
+        for c in self._snd_att:
+            s = self.snd_clients[c]
+            if s is not None:
+                self._play_arr[c] = PlayChan(float(s.volume), float(s.audio_balance))
 
     def _sync_recording(self):
-        rec = any(s is not None and s.audio_rec.recording_flag for s in self.snd_clients)
+        rec = any(self.snd_clients[c] is not None and self.snd_clients[c].audio_rec.recording_flag for c in self._snd_att)
         if rec != self._recording:
             self.engine.set_recording(rec)
             self._recording = rec
         return rec
 
-    def _run_superframe(self):
+    def _run_superframe(self, batch):
         eng = self.engine
-        eng.push_iq(self._batch)
+        wire_rssi = eng.push_iq_wire(batch) if self.wire else eng.push_iq(batch)
         n_avg = self.averaging_n
         wf = eng.run_wf()                             # [lines, n_ch, 1024]
         color = chans = None
-        if self.gpu_post and len(wf) and any(w is not None for w in self.wf_clients):
-            chans = [self._db2col_chan(w) for w in self.wf_clients]
+        if self.gpu_post and (self._n_wf_clients or self._n_snd_clients):
+            self._sync_display_state()
+        if self.gpu_post and len(wf) and self._n_wf_clients:
+            chans = self._db_arr
             color = eng.run_db2col(chans, len(wf))    # [lines, n_ch, 1024] float32 0..254
-        pcm, rssi = eng.run_audio()                   # [n_ch, 1024], [n_ch, 2]
-        flags = eng.audio_flags()                     # [n_ch, 2] SND header bit 1 (utils_supersdr.py:1066-1067)
-        iqo = eng.audio_iq() if any(p.mode == L.MODE_IQ for p in self._params) else None     # channels in "SET mod=iq"
+        pcm, rssi = eng.run_audio()                   # [n_ch, frames*512], [n_ch, frames]
+        flags = eng.audio_flags()                     # [n_ch, frames] SND header bit 1 (utils_supersdr.py:1066-1067)
+        iqo = eng.audio_iq() if self._n_iq_mode else None                        # channels in "SET mod=iq"
         play = mono = None
-        if self.gpu_post and any(s is not None for s in self.snd_clients):
+        if self.gpu_post and self._n_snd_clients:
             rec = self._sync_recording()
-            play = eng.run_playbuffer(self._play_chans())
+            play = eng.run_playbuffer(self._play_arr)
             if rec:
                 mono = eng.playbuffer_mono()
         self.superframes += 1
-        self._hand_out(wf, n_avg, color, chans, pcm, rssi, flags, play, mono, iqo)
+        self._hand_out(SuperframeResult(seq=self.superframes, wf=wf, n_avg=n_avg, color=color, chans=chans, pcm=pcm, rssi=rssi,
+                                        flags=flags, play=play, mono=mono, iq=iqo, wire_rssi=wire_rssi))
 
-    def _hand_out(self, wf, n_avg, color, chans, pcm, rssi, flags, play, mono, iqo=None):
-        P = self.play_len
-        for c in range(self.n_ch):
-            for i, line in enumerate(wf):
+    def _hand_out(self, r):
+        self.last = r
+        for fn in self._subscribers:
+            fn(r)
+        P, wf, pcm = self.play_len, r.wf, r.pcm
+        for c in self._wf_att:
+            q = self.wf_queue._q[c]
+            has_post = r.color is not None and self.wf_clients[c] is not None
+            for i in range(len(wf)):
                 post = None
-                if color is not None and self.wf_clients[c] is not None:
-                    k = chans[c]
-                    post = (color[i, c].copy(), k.low_clip_db, k.high_clip_db, k.dynamic_range, k.wf_min_db, k.wf_max_db)
-                _put_drop_oldest(self.wf_queue[c], (line[c].copy(), n_avg, post))
+                if has_post:
+                    k = r.chans[c]
+                    post = (r.color[i, c].copy(), k.low_clip_db, k.high_clip_db, k.dynamic_range, k.wf_min_db, k.wf_max_db)
+                _put_drop_oldest(q, (wf[i, c].copy(), r.n_avg, post))
+        for c in self._snd_att:
+            q = self.snd_queue._q[c]
+            iq_mode = r.iq is not None and self.params(c).mode == L.MODE_IQ
             for f in range(pcm.shape[1] // L.FRAME):
-                _put_drop_oldest(self.snd_queue[c], Frame.make(
-                    pcm[c, f * L.FRAME:(f + 1) * L.FRAME], rssi[c, f],
-                    play[c, f * P:(f + 1) * P].copy() if play is not None else None,
-                    mono[c, f * P:(f + 1) * P].copy() if mono is not None else None, flags[c, f],
-                    iqo[c, f * L.FRAME:(f + 1) * L.FRAME].copy() if iqo is not None and self._params[c].mode == L.MODE_IQ else None))
+                _put_drop_oldest(q, Frame.make(
+                    pcm[c, f * L.FRAME:(f + 1) * L.FRAME], r.rssi[c, f],
+                    r.play[c, f * P:(f + 1) * P].copy() if r.play is not None else None,
+                    r.mono[c, f * P:(f + 1) * P].copy() if r.mono is not None else None, r.flags[c, f],
+                    r.iq[c, f * L.FRAME:(f + 1) * L.FRAME].copy() if iq_mode else None))
 
-    def _run_pipelined(self):
+    def _run_pipelined(self, batch):
         eng = self.engine
-        eng.feed_slot()[:] = self._batch
         if self.gpu_post:                             # the display state this superframe is converted with, latched now
             self._sync_recording()
-            eng.feed_post([self._db2col_chan(w) for w in self.wf_clients], self._play_chans())
-        eng.feed_submit()
+            self._sync_display_state()
+            eng.feed_post(self._db_arr, self._play_arr)
+        if hasattr(eng, "feed_submit_from"):
+            eng.feed_submit_from(batch)               # the H2D copy reads the hub's slot itself
+        else:
+            eng.feed_slot()[:] = batch
+            eng.feed_submit()
         self._inflight += 1
         self.superframes += 1
         if self._inflight == self._depth:
@@ -280,17 +550,19 @@ class IQHub:
 
     def _collect(self):
         eng = self.engine
-        wf, pcm, rssi = eng.feed_collect()[:3]
+        got = eng.feed_collect()
+        wf, pcm, rssi = got[:3]
         self._inflight -= 1
         n_avg, flags = eng.feed_n_avg, eng.feed_flags          # per slot: the N in force at submit, this batch's flags
         color = chans = play = mono = None
         if self.gpu_post:
             color, chans, play, mono = eng.feed_collect_post()
-            if not any(w is not None for w in self.wf_clients):
+            if not self._n_wf_clients:
                 color = None
-            if not any(s is not None for s in self.snd_clients):
+            if not self._n_snd_clients:
                 play = mono = None
-        self._hand_out(wf, n_avg, color, chans, pcm, rssi, flags, play, mono)
+        self._hand_out(SuperframeResult(seq=self.superframes - self._inflight, wf=wf, n_avg=n_avg, color=color, chans=chans, pcm=pcm,
+                                        rssi=rssi, flags=flags, play=play, mono=mono, wire_rssi=got[3] if len(got) > 3 else None))
 
     def flush(self):
         """pipeline mode: wait for the superframes still in flight and hand their results out"""
@@ -342,7 +614,16 @@ class IQHub:
                 self.engine.feed_close()
             except Exception:
                 pass
+        self._slots = []
         self.engine.close()
+
+
+def _fill_struct_array(arr, proto):
+    """every element of a ctypes array = proto, without a Python loop over the channels"""
+    n, size = len(arr), C.sizeof(proto)
+    if n:
+        buf = (C.c_char * (n * size)).from_buffer(arr)
+        buf[:] = bytes(proto) * n
 
 
 def _put_drop_oldest(q, item):
@@ -381,6 +662,8 @@ class GpuStream:
         self.seq = 0
         self.closed = False
         self._greeting = deque()
+        if hasattr(hub, "attach"):                   # this channel has a listener now: its results are queued from here on
+            hub.attach(self.channel, wf=(kind != "SND"), snd=(kind == "SND"))
         if kind == "SND":
             rate = int(getattr(hub, "kiwi_rate", L.RATE))
             # every server announces its rate first; the reference takes KIWI_RATE, KIWI_RATE_TRUE, SAMPLE_RATIO from it (:988-994)

@@ -656,6 +656,63 @@ def test_hub_pipelined_feed_equals_the_synchronous_hub_and_flags_reach_the_seam(
     hub.close()
 
 
+def test_hub_bulk_ingest_on_the_gpu_equals_the_engine_run_directly(S):
+    """Round 4: the hub's bulk paths on the real engine -- feed_block / reserve + commit into (pinned) superframe slots,
+    ssdr_feed_submit_from straight out of them, SND bodies into a wire hub, K superframes per GPU run -- give bit for bit
+    what ssdr_push_iq + ssdr_run_wf + ssdr_run_audio give on the same stream; on a lazy hub only the attached channel
+    gets queue entries, and the whole-batch arrays (`last`, subscribe()) carry everybody's results."""
+    from supersdr_amd.workers import IQHub
+    from supersdr_amd.iqstream import int16_to_wire
+    n_ch, n_sf = 2048, 6
+    with S.SsdrEngine(n_ch) as e0:
+        ps, _ = mixed_params(S, 8)
+        e0.set_params(0, [ps[c % 8] for c in range(n_ch)])
+        e0.synth_iq(2 * n_sf)
+        iq = e0.read_input()                                                    # [n_ch, n_sf * 1024, 2]
+        e0.push_iq(iq)
+        wf_ref = e0.run_wf()
+        pcm_ref, rssi_ref = e0.run_audio()
+        flags_ref = e0.audio_flags()
+    bodies = np.zeros((n_ch, 2 * n_sf, 2065), np.uint8)
+    bodies[:, :, 17:] = iq.reshape(n_ch, 2 * n_sf, 512, 2).astype(">i2").view(np.uint8).reshape(n_ch, 2 * n_sf, 2048)
+    assert bytes(bodies[3, 5, 17:]) == int16_to_wire(iq[3, 5 * 512: 6 * 512])[17:]
+    for kw in (dict(), dict(pipeline=True, depth=3), dict(pipeline=True, depth=2, batch_superframes=2), dict(wire=True),
+               dict(wire=True, pipeline=True, depth=3), dict(batch_superframes=3)):
+        hub = IQHub(n_ch, gpu_post=False, lazy=True, **kw)
+        hub.engine.set_params(0, [ps[c % 8] for c in range(n_ch)])           # (the engine takes blocks; the hub's set_params one channel)
+        got = []
+        hub.subscribe(lambda r: got.append((r.wf.copy(), r.pcm.copy(), r.rssi.copy(), r.flags.copy())))
+        q = hub.attach(1234, wf=True, snd=True)
+        K = kw.get("batch_superframes", 1)
+        if kw.get("wire"):
+            for f in range(0, 2 * n_sf, 2):
+                hub.feed_wire_block(0, bodies[:1000, f:f + 1])                  # ragged: the first thousand run a frame ahead
+                hub.feed_wire_block(1000, bodies[1000:, f:f + 2])
+                hub.feed_wire_block(0, bodies[:1000, f + 1:f + 2])
+        else:
+            for k in range(n_sf):
+                blk = iq[:, k * 1024:(k + 1) * 1024]
+                if k % 2:
+                    v = hub.reserve(0, n_ch)
+                    assert v is not None
+                    v[:, :1024] = blk
+                    hub.commit(0, n_ch, 1024)
+                else:
+                    hub.feed_block(0, blk[:, :700])
+                    hub.feed_block(0, blk[:700, 700:])
+                    hub.feed_block(700, blk[700:, 700:])
+        hub.flush()
+        assert hub.superframes == n_sf // K and len(got) == n_sf // K and not hub.stalled.any()
+        wf = np.concatenate([g[0] for g in got])
+        pcm = np.concatenate([g[1] for g in got], axis=1)
+        assert np.array_equal(wf, wf_ref) and np.array_equal(pcm, pcm_ref), kw
+        assert np.array_equal(np.concatenate([g[2] for g in got], axis=1), rssi_ref)
+        assert np.array_equal(np.concatenate([g[3] for g in got], axis=1), flags_ref)
+        assert q["wf"].qsize() == n_sf and q["snd"].qsize() == 2 * n_sf and hub.wf_queue.attached(0) is None
+        assert np.array_equal(q["wf"].get_nowait()[0], wf_ref[0, 1234]) and np.array_equal(q["snd"].get_nowait(), pcm_ref[1234, :512])
+        hub.close()
+
+
 def test_full_size_batch_properties(S, twin):
     """BASELINE configs[2]/[3] size (65536 channels, mixed modes, 10x binning): device-generated input,
     (i) a strided subset of channels bit-exact vs the twin on the same bytes, (ii) a channel's result does not

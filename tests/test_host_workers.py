@@ -632,7 +632,7 @@ def test_a_stalled_receiver_does_not_freeze_the_hub_and_backlogs_are_bounded():
     for k in range(1, 8):                                          # channel 1 goes quiet
         hub.feed(0, iq[0, k * 1024:(k + 1) * 1024])
     assert hub.superframes >= 4 and hub.stalled[1] == hub.superframes - 1 and hub.stalled[0] == 0
-    assert hub._wr[0] - hub._rd[0] <= 4 * 1024                    # backlog bounded by the stall threshold
+    assert hub.backlog(0) <= 4 * 1024                            # backlog bounded by the stall threshold
     got0 = np.concatenate([hub.snd_queue[0].get_nowait() for _ in range(2 * hub.superframes)])
     st, hist = twinlib.fresh_state(hub.engine.consts[:1])
     ref, _ = twinlib.load().audio(iq[:1, :hub.superframes * 1024], hub.engine.consts[:1], hub.engine.taps[:1], st, hist)
@@ -640,7 +640,7 @@ def test_a_stalled_receiver_does_not_freeze_the_hub_and_backlogs_are_bounded():
     # a burst far beyond the ring on a hub whose other channel stays silent: bounded memory, oldest dropped, counted
     hub2 = IQHub(2, engine=TwinEngine(2), gpu_post=False, backlog_superframes=4, stall_superframes=100)
     hub2.feed(0, iq[0])
-    assert hub2._ring.shape[1] == 4 * 1024 and hub2.dropped[0] == 8 * 1024 and hub2.superframes == 0
+    assert hub2.ring_capacity == 4 * 1024 and hub2.dropped[0] == 8 * 1024 and hub2.superframes == 0
 
 
 def test_mod_iq_frames_reach_a_kiwiclient_through_the_gpu_stream():
@@ -683,3 +683,228 @@ def test_mod_iq_frames_reach_a_kiwiclient_through_the_gpu_stream():
     st1 = GpuStream(hub, 1, "SND", 7100.0, timeout=0.2)
     st1.receive_message(), st1.receive_message()
     assert len(st1.receive_message()) == 3 + 7 + 1024
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 4: the hub's bulk ingest (slot ring, NumPy bookkeeping, queues only for attached channels)
+# ---------------------------------------------------------------------------------------------------------------
+class RecordingEngine:
+    """Zero-cost engine double: remembers the batches it was pushed and answers with arrays that name them (so a test can
+    tell which batch a result belongs to).  No arithmetic: what is tested is the hub."""
+
+    def __init__(self, n_ch, keep=True):
+        self.n_ch, self.keep, self.batches, self.runs = n_ch, keep, [], 0
+        self.pcm = np.zeros((n_ch, 1024), np.int16)
+        self.rssi = np.zeros((n_ch, 2), np.float32)
+        self.fl = np.zeros((n_ch, 2), np.uint8)
+
+    def set_kiwi_rate(self, rate):
+        pass
+
+    def set_averaging(self, n):
+        pass
+
+    def playbuffer_frame_len(self):
+        return 2048
+
+    def push_iq(self, batch):
+        assert batch.flags.c_contiguous and batch.dtype == np.int16 and batch.shape[0] == self.n_ch
+        self.runs += 1
+        if self.keep:
+            self.batches.append(batch.copy())
+        self.frames = batch.shape[1] // 512
+
+    def push_iq_wire(self, bodies):
+        assert bodies.flags.c_contiguous and bodies.dtype == np.uint8 and bodies.shape[2] == 2065
+        self.runs += 1
+        self.batches.append(bodies.copy())
+        self.frames = bodies.shape[1]
+        return np.zeros((self.n_ch, self.frames), np.float32)
+
+    def run_wf(self):
+        if getattr(self, "wf", None) is None or len(self.wf) != self.frames // 2:
+            self.wf = np.zeros((self.frames // 2, self.n_ch, 1024), np.int16)
+        self.wf[:, :, 0] = self.runs
+        return self.wf
+
+    def run_audio(self):
+        nf = self.frames
+        if self.pcm.shape[1] != nf * 512:
+            self.pcm, self.rssi, self.fl = np.zeros((self.n_ch, nf * 512), np.int16), np.zeros((self.n_ch, nf), np.float32), np.zeros((self.n_ch, nf), np.uint8)
+        self.pcm[:, 0] = self.runs
+        return self.pcm, self.rssi
+
+    def audio_flags(self):
+        return self.fl
+
+    def close(self):
+        pass
+
+
+class ScanHub:
+    """The hub's batching rule stated the slow way, one Python list per channel (rounds 1-3's implementation without the
+    drop path): run when every channel has a superframe, or when one is `stall` superframes ahead -- then a channel that has
+    none gets silence and keeps what it had."""
+
+    def __init__(self, n_ch, stall=4, sf=1024):
+        self.n, self.sf, self.stall = n_ch, sf, stall * sf
+        self.buf = [np.zeros((0, 2), np.int16) for _ in range(n_ch)]
+        self.batches, self.stalled = [], [0] * n_ch
+
+    def feed(self, c, iq):
+        pos = 0
+        while pos < len(iq):
+            m = min(len(iq) - pos, self.sf)
+            self.buf[c] = np.concatenate([self.buf[c], iq[pos:pos + m]])
+            pos += m
+            self.pump()
+
+    def pump(self):
+        while True:
+            avail = [len(b) for b in self.buf]
+            if min(avail) < self.sf and max(avail) < self.stall + self.sf:
+                return
+            batch = np.zeros((self.n, self.sf, 2), np.int16)
+            for c in range(self.n):
+                if len(self.buf[c]) >= self.sf:
+                    batch[c] = self.buf[c][:self.sf]
+                    self.buf[c] = self.buf[c][self.sf:]
+                else:
+                    self.stalled[c] += 1
+            self.batches.append(batch)
+
+
+def test_hub_batches_equal_the_per_channel_scan_on_ragged_stalling_feeds():
+    """The slot ring forms exactly the batches the per-channel scan forms: ragged feeds, receivers that fall behind and
+    come back with half a superframe buffered, blocks of channels fed in step, in-place reserve / commit."""
+    from supersdr_amd.workers import IQHub
+    rng = np.random.default_rng(20)
+    n = 7
+    for trial in range(6):
+        eng = RecordingEngine(n)
+        hub = IQHub(n, engine=eng, gpu_post=False, backlog_superframes=8, stall_superframes=3)
+        ref = ScanHub(n, stall=3)
+        for step in range(120):
+            kind = rng.integers(0, 10)
+            m = int(rng.choice([1, 37, 512, 700, 1024, 1500, 2300]))
+            if kind < 5:                                           # one channel; channel 6 is often silent for long
+                c = int(rng.integers(0, n if step % 40 < 10 else n - 1))
+                iq = rng.integers(-3000, 3000, (m, 2)).astype(np.int16)
+                hub.feed(c, iq)
+                ref.feed(c, iq)
+            else:                                                  # a block of channels, whatever their positions
+                f = int(rng.integers(0, n - 1))
+                k = int(rng.integers(1, n - f))
+                iq = rng.integers(-3000, 3000, (k, m, 2)).astype(np.int16)
+                v = hub.reserve(f, k) if kind == 9 else None
+                if v is not None and v.shape[1] >= m:
+                    v[:, :m] = iq
+                    hub.commit(f, k, m)
+                else:
+                    hub.feed_block(f, iq)
+                for i in range(k):                                 # the scan hub takes the block channel by channel, run by run:
+                    pass                                           # (see below: same order of pump calls per run of equal positions)
+                _feed_block_like_the_hub(ref, hub, f, iq)
+        assert eng.runs == len(ref.batches) and eng.runs > 20
+        for a, b in zip(eng.batches, ref.batches):
+            assert np.array_equal(a, b)
+        assert list(hub.stalled) == ref.stalled and sum(ref.stalled) > 0 and not hub.dropped.any()
+
+
+def _feed_block_like_the_hub(ref, hub, first, iq):
+    """the reference scan has no block call: a block is its channels' feeds, piece by slot-sized piece, all channels of a
+    run of equal write positions advancing together (which is what a block of receivers fed in step means)"""
+    k, m = iq.shape[0], iq.shape[1]
+    lens = [len(ref.buf[first + i]) for i in range(k)]
+    runs, lo = [], 0
+    for i in range(1, k + 1):
+        if i == k or lens[i] != lens[lo]:
+            runs.append((lo, i))
+            lo = i
+    for lo, hi in runs:
+        pos = 0
+        while pos < m:
+            have = len(ref.buf[first + lo]) % ref.sf
+            step = min(m - pos, ref.sf - have)
+            for i in range(lo, hi):
+                ref.buf[first + i] = np.concatenate([ref.buf[first + i], iq[i, pos:pos + step]])
+            pos += step
+            ref.pump()
+
+
+def test_hub_scales_to_131072_channels_and_makes_objects_only_for_attached_channels():
+    """VERDICT r3 'missing #1': one superframe of 131 072 receivers through the hub's own API inside the 85.3 ms that real
+    time allows (zero-cost engine: what is timed is the host side).  In place (reserve / commit) the hub's share is
+    bookkeeping; through feed_block it is one copy of the 512 MiB, held against a bare np.copyto of the same arrays."""
+    import time
+    from supersdr_amd.workers import IQHub
+    n = 131072
+    eng = RecordingEngine(n, keep=False)
+    hub = IQHub(n, engine=eng, gpu_post=False, backlog_superframes=2, stall_superframes=1)
+    assert hub.wf_queue.attached(7) is None and not hub._snd_att          # nobody listens: no queue, no Frame, anywhere
+    q = hub.attach(77, wf=True, snd=True)
+    blk = np.ones((n, 1024, 2), np.int16)
+    for _ in range(2):
+        hub.feed_block(0, blk)                                             # first touch of both slots
+    t0 = time.perf_counter()
+    np.copyto(hub._slots[0], blk)
+    bare = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(3):
+        hub.feed_block(0, blk)
+    block_s = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    for _ in range(3):
+        v = hub.reserve(0, n)
+        assert v.shape == (n, 1024, 2)
+        hub.commit(0, n, 1024)
+    inplace_s = (time.perf_counter() - t0) / 3
+    print("131072 ch: feed_block %.1f ms / superframe (bare copy %.1f ms), reserve+commit %.2f ms" % (block_s * 1e3, bare * 1e3, inplace_s * 1e3))
+    assert eng.runs == 8 and hub.superframes == 8
+    assert inplace_s < 0.0853 / 4, "the hub's own share of a superframe"
+    assert block_s < 1.5 * bare + 0.010, "feed_block = one copy + bookkeeping"
+    assert q["snd"].qsize() == 16 and q["wf"].qsize() == 8 and hub.last.pcm.shape == (n, 1024)
+    # a block of 1000 receivers goes quiet: the others keep running, the quiet ones are counted, all of it vectorised
+    t0 = time.perf_counter()
+    for _ in range(3):
+        hub.feed_block(0, blk[:50000])
+        hub.feed_block(51000, blk[51000:])
+    stall_s = (time.perf_counter() - t0) / 3
+    assert hub.superframes == 8 + 2 and hub.stalled[50500] == 2 and hub.stalled[0] == 0 and stall_s < 0.5
+    hub.close()
+
+
+def test_wire_hub_batches_snd_bodies_and_lazy_queues_follow_clients(gpu):
+    """a hub built with wire=True takes SND bodies (2065 B per frame) into its slots as they are; and on a lazy hub a
+    channel gets queues exactly when a worker (or a GpuStream) attaches to it"""
+    from supersdr_amd.workers import IQHub, GpuStream
+    eng = RecordingEngine(6)
+    hub = IQHub(6, engine=eng, gpu_post=False, wire=True, lazy=True)
+    rng = np.random.default_rng(3)
+    bodies = rng.integers(0, 256, (6, 4, 2065)).astype(np.uint8)
+    hub.feed_wire_block(0, bodies[:, :1])
+    assert eng.runs == 0
+    hub.feed_wire_block(0, bodies[:4, 1:3])                              # four channels run ahead
+    hub.feed_wire_block(4, bodies[4:, 1:2])
+    assert eng.runs == 1 and np.array_equal(eng.batches[0], bodies[:, :2])
+    with pytest.raises(ValueError):
+        hub.feed(0, np.zeros((10, 2), np.int16))
+    assert hub.snd_queue.attached(2) is None
+    st = GpuStream(hub, 2, "SND", 7100.0, timeout=0.1)
+    assert hub.snd_queue.attached(2) is not None and hub.wf_queue.attached(2) is None and hub._snd_att == [2]
+    hub.feed_wire_block(4, bodies[4:, 2:4])
+    hub.feed_wire_block(0, bodies[:4, 3:4])
+    assert eng.runs == 2 and np.array_equal(eng.batches[1], bodies[:, 2:4])
+    st.receive_message(), st.receive_message()
+    assert st.receive_message()[:3] == b"SND" and hub.snd_queue[2].qsize() == 1
+    # a worker pair on a lazy sample hub: its channel, and only its channel, is attached
+    hub2 = IQHub(5, engine=TwinEngine(5), lazy=True)
+    wf = gpu.kiwi_waterfall("gpu", 0, "", 10, 7100.0, Eibi(), Disp(), hub=hub2, channel=3, timeout=0.2)
+    snd = gpu.kiwi_sound(7100.0, "USB", 30, 3000, "", wf, 4)
+    assert hub2._wf_att == [3] and hub2._snd_att == [3] and hub2._n_wf_clients == 1 and hub2._n_snd_clients == 1
+    iq = O.synth_iq(5, 2048, seed=5)
+    hub2.feed_block(0, iq)
+    wf.step(), wf.step()
+    assert snd.process_audio_stream().shape == (512,) and wf.run_index == 2
+    hub2.detach(3)
+    assert hub2._wf_att == [] and hub2.wf_queue.attached(3) is None
