@@ -47,8 +47,9 @@ WORKLOADS = {
     "full":  (65536,     16,          1,     ("am",),               True, True),      # >= 16 superframes
     "wf":    (4096,      256,         1,     ("am",),               True, False),
     "mixed": (65536,     10,          10,    ("am", "usb", "lsb", "nbfm"), True, True),
-    # configs[4]: 2^20 channels in total, 2^20 / N per GPU (strong scaling; 16 GiB of input on one GPU at N = 1)
-    "million": (1 << 20, 4,           1,     ("am",),               True, True),
+    # configs[4]: 2^20 channels in total, 2^20 / N per GPU (strong scaling; 16 superframes per call on every rank: 64 GiB of input on
+    # one GPU at N = 1, 8 GiB per GPU at N = 8 -- a wave sets a channel pair's state up once per call, SURVEY.md 8d ">= 16 superframes")
+    "million": (1 << 20, 16,          1,     ("am",),               True, True),
     # the decimating front end (ssdr_set_decimation(4)): IQ at 48 kHz, 125-tap channel filters, waterfall lines from the wide stream
     "decim4": (16384,    8,           1,     ("usb", "lsb"),        True, True),
 }
@@ -357,6 +358,117 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
             "own_value": channels * sframes * steps / own_wall / RT_SUPERFRAMES_PER_S}
 
 
+# reference timings of the two functions the post kernels stand for (the reference's own code, survey
+# container, one core, 2000 iterations) -- the one like-for-like comparison this path has
+REFERENCE_US = {"ssdr_db2col_kernel": (141.0, "line", "kiwi_waterfall.spectrum_db2col, utils_supersdr.py:787-813"),
+                "ssdr_play_kernel": (43.8, "frame", "kiwi_sound.play_buffer, utils_supersdr.py:1106-1148")}
+
+
+def measure_post(S, L, local_rank, channels=65536, sframes=16, steps=10, spinup=0.3):
+    """SURVEY.md 8f on the metric's shape: spectrum_db2col of the 16 lines and play_buffer (x4 branch, then the 64/27 branch of
+    20.25 kHz KiwiSDRs) of the 32 frames a 65 536-channel chain run leaves on the device, and the IQ wire unpack of 8 frames
+    per channel.  Kernel times from HIP events around each launch (ssdr_set_profiling); results stay on the device.
+    Algorithmic bytes: db2col 2048 B in + 4096 B out per line; play_buffer 1024 B in + 8192 B out per frame (x4),
+    1024 + 4852 (64/27); wire 2065 B in + 2048 B out per frame."""
+    from supersdr_amd._lib import Db2colChan, PlayChan
+    from supersdr_amd.workers import _fill_struct_array
+    n_frames = 2 * sframes
+    db, play = (Db2colChan * channels)(), (PlayChan * channels)()
+    _fill_struct_array(db, Db2colChan(auto_scale=1, low_clip_db=-120.0, high_clip_db=-60.0, dynamic_range=40.0))
+    _fill_struct_array(play, PlayChan(100.0, 0.0))
+    stages = {}
+
+    def timed(eng, which, call, name, units, nbytes):
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < spinup:
+            call()
+        eng.kernel_stats(which, reset=True)
+        for _ in range(steps):
+            call()
+        ms, n = eng.kernel_stats(which)
+        avg = ms / max(n, 1)
+        st = {"kernel": name, "avg_ms": avg, "launches": n, "bytes": float(nbytes), "GBps": nbytes / avg / 1e6, "units": units,
+              "us_per_unit": avg * 1e3 / units}
+        if name in REFERENCE_US:
+            us, unit, what = REFERENCE_US[name]
+            st["reference_cpu"] = {"us_per_" + unit: us, "what": what, "where": "BASELINE.md section 2 (survey container, 1 core)",
+                                   "units_per_s_one_core": 1e6 / us, "units_per_s_gpu": units / avg * 1e3}
+        return st
+
+    for rate in (12000, 20250):
+        eng = S.SsdrEngine(channels, device=local_rank)
+        eng.set_kiwi_rate(rate)
+        configure(S, eng, "full", channels, 0)
+        eng.synth_iq(n_frames)
+        eng.run_chain()
+        eng.sync()
+        eng.set_profiling(True)
+        if rate == 12000:
+            stages["db2col"] = timed(eng, L.K_DB2COL, lambda: eng.run_db2col(db, sframes, fetch=False), "ssdr_db2col_kernel",
+                                     channels * sframes, channels * sframes * 6144.0)
+            stages["play"] = timed(eng, L.K_PLAY, lambda: eng.run_playbuffer(play, fetch=False), "ssdr_play_kernel",
+                                   channels * n_frames, channels * n_frames * (1024.0 + 8192.0))
+            wire_frames = 8
+            bodies = np.zeros((channels, wire_frames, 2065), np.uint8)
+            bodies[:, :, 17::7] = 3
+            stages["wire"] = timed(eng, L.K_WIRE, lambda: eng.push_iq_wire(bodies), "ssdr_iqwire_kernel",
+                                   channels * wire_frames, channels * wire_frames * (2065.0 + 2048.0))
+            del bodies
+        else:
+            stages["play_rs"] = timed(eng, L.K_PLAY, lambda: eng.run_playbuffer(play, fetch=False), "ssdr_play_rs_kernel",
+                                      channels * n_frames, channels * n_frames * (1024.0 + 1213 * 4.0))
+        eng.close()
+    return stages
+
+
+def measure_hub(S, L, torch, local_rank, channels, sframes, steps, in_place, batch_superframes=4):
+    """The pipelined feed driven through the product's own ingest API (supersdr_amd/workers.py:IQHub, the thing
+    KiwiSDRStream._process_iq_samples fills, kiwi/client.py:493-494): `channels` receivers, one block call per superframe.
+    in_place=False: IQHub.feed_block (one copy of the block into the hub's pinned slot -- the hub's whole host cost);
+    in_place=True: reserve / commit (the producer writes into the slot itself; here the slots keep the data they were
+    filled with once, so what is timed is bookkeeping + H2D + kernels + D2H).  Results come back as whole-batch arrays;
+    one channel has a listener attached.  PCIe-inclusive: never the headline value."""
+    from supersdr_amd.workers import IQHub
+    eng = S.SsdrEngine(channels, device=local_rank)
+    configure(S, eng, "full", channels, 0)
+    eng.synth_iq(2 * batch_superframes)
+    block = eng.read_input()                                     # [channels, K * 1024, 2]: K superframes of synthetic IQ, replayed
+    hub = IQHub(channels, engine=eng, gpu_post=False, pipeline=True, depth=3, lazy=True, batch_superframes=batch_superframes,
+                backlog_superframes=2 * batch_superframes, stall_superframes=batch_superframes)
+    hub.attach(channels // 2, wf=True, snd=True)
+    seen = [0]
+    hub.subscribe(lambda r: seen.__setitem__(0, seen[0] + r.pcm.shape[1] // 1024))
+    U = 1024 * batch_superframes
+
+    def one_batch():
+        if in_place:
+            v = hub.reserve(0, channels)
+            hub.commit(0, channels, v.shape[1])
+        else:
+            hub.feed_block(0, block)
+
+    for _ in range(len(hub._slots) + 2):                         # every slot filled once, the pipeline primed
+        hub.feed_block(0, block)
+    hub.flush()
+    n_batches = max(1, steps * sframes // batch_superframes)
+    seen[0] = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n_batches):
+        one_batch()
+    hub.flush()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    assert seen[0] == n_batches * batch_superframes, (seen, n_batches)
+    q = hub.snd_queue[channels // 2].qsize()
+    hub.close()
+    units = channels * n_batches * batch_superframes
+    return {"value": units / wall / RT_SUPERFRAMES_PER_S, "unit": "rt_channels", "ms_per_superframe": wall / (n_batches * batch_superframes) * 1e3,
+            "channels": channels, "superframes_per_gpu_run": batch_superframes, "superframes": n_batches * batch_superframes,
+            "ingest": "IQHub.reserve/commit (in place)" if in_place else "IQHub.feed_block (one host copy)",
+            "host_GBps": units * 4096.0 / wall / 1e9, "frames_queued_for_the_one_listener": q}
+
+
 def pmc_traffic(workload, channels, sframes, hop=1024):
     """HBM bytes per launch from the PMC passes committed under profiles/ (collected with rocprofv3 in separate
     runs, corrected as MI355X_MICROARCH.md prescribes; tools/profile_round.sh + tools/traffic_json.py).
@@ -411,9 +523,12 @@ def roofline(stage, traffic=None, src=None):
     fl = executed_flops(stage)
     if fl is not None:
         tf = fl / stage["avg_ms"] / 1e9
-        r["valu"] = {"flops_per_launch": fl, "flop_per_algorithmic_byte": fl / stage["bytes"], "ridge_flop_per_byte": RIDGE_FLOP_PER_BYTE,
-                     "achieved_tflops": tf, "peak_tflops": F32_PEAK_TFLOPS, "frac_f32": tf / F32_PEAK_TFLOPS,
-                     "source": "PMC SQ_INSTS_VALU per wave-unit x 64 lanes, FMA share from the opcode mix (profiles/README.md)"}
+        # ISSUE-SLOT work, not floating-point flops: every executed VALU lane-instruction counts once (moves, converts and integer
+        # ops included), an FMA twice -- the measure of how busy the vector ALU is against its f32 FMA peak
+        r["issue"] = {"lane_ops_per_launch": fl, "lane_ops_per_algorithmic_byte": fl / stage["bytes"], "ridge_per_byte": RIDGE_FLOP_PER_BYTE,
+                      "achieved_tera_ops": tf, "peak_tflops": F32_PEAK_TFLOPS, "frac_f32": tf / F32_PEAK_TFLOPS,
+                      "source": "constants from profiles/: PMC SQ_INSTS_VALU per wave-unit x 64 lanes, FMA share from the opcode mix "
+                                "(profiles/r04_isa_histograms.txt); not an observation of this run"}
         if fl / stage["bytes"] > RIDGE_FLOP_PER_BYTE:       # right of the ridge: the vector ALU's roof is the lower one
             r.update({"bound": "valu", "achieved": tf, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_PEAK_TFLOPS})
     if traffic is not None:
@@ -448,7 +563,8 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the short wf / mixed measurements after the main one")
     ap.add_argument("--host-feed", type=int, default=0,
                     help="1: inputs come from (pinned) host memory (2: as SND wire bodies, unpacked on the device) and results go back to it through the pipelined feed "
-                         "(ssdr_feed_*): the PCIe-inclusive rate of DESIGN.md, never the headline value")
+                         "(ssdr_feed_*): the PCIe-inclusive rate of DESIGN.md, never the headline value; 3: the same through the product's ingest API, "
+                         "IQHub.feed_block (one host copy per block); 4: IQHub.reserve / commit (in place)")
     ap.add_argument("--concurrent", type=int, default=0, help="bit 0: audio stage on a second stream beside the waterfall kernel; bit 1: the audio stage's per-path kernels one after the other")
     ap.add_argument("--fused", type=int, default=1,
                     help="1 (the library's default): ssdr_run_chain uses the fused superframe kernel where the configuration allows it "
@@ -458,6 +574,9 @@ def main():
     ap.add_argument("--exact", type=int, default=0, help="1: ssdr_set_exact_bins -- the waterfall stage in float64 (bins equal the float64 oracle bit for bit)")
     ap.add_argument("--no-parity-probe", action="store_true",
                     help="profiling runs only: skip the probe launches of the parity hash (they would enter the per-kernel PMC means)")
+    ap.add_argument("--record", default="", help="also write the long form of the result (every roofline object, notes, sources) to this file")
+    ap.add_argument("--verbose-line", action="store_true", help="print the long form as the JSON line (rounds 1-3's format)")
+    ap.add_argument("--host-feed-extra", type=int, default=1, help="0: skip extra.hub_feed (the pipelined feed through IQHub; takes 8 GiB of pinned host memory)")
     ap.add_argument("--dry-run", action="store_true",
                     help="control flow only (ranks, rendezvous over gloo, channel blocks, JSON line), no GPU work: the CPU test of --gpus")
     args = ap.parse_args()
@@ -510,6 +629,13 @@ def main():
     import supersdr_amd as S
     from supersdr_amd import _lib as L
 
+    if args.host_feed in (3, 4):         # the pipelined feed behind the product's own ingest API (IQHub); PCIe-inclusive, its own short line
+        h = measure_hub(S, L, torch, local_rank, channels, sframes, args.steps, in_place=(args.host_feed == 4))
+        if rank == 0:
+            print(json.dumps(dict(h, metric="real-time IQ channels sustained (WF+demod), inputs and results in host memory, through IQHub",
+                                  n_gpus=world, steps=args.steps, note="PCIe- and host-copy-inclusive: never the headline value")), flush=True)
+        rdv.close()
+        return
     m = measure(S, L, torch, rdv, rank, world, local_rank, args.workload, channels, sframes, args.steps, args.warmup,
                 args.spinup, args.concurrent, args.host_feed, args.hop, args.fused, args.exact, first_id)
     # SURVEY.md 8e parity hash (untimed): every rank hashes a probe of its own channel block and of the NEXT rank's block;
@@ -529,7 +655,7 @@ def main():
     dom = max(stages, key=lambda k: stages[k]["avg_ms"])
     traffic, src = pmc_traffic(args.workload, channels, sframes, args.hop)
 
-    out = {
+    full = {
         "metric": "real-time IQ channels sustained (WF+demod)", "value": m["value"], "unit": "rt_channels",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
         "higher_is_better": True, "scaling": "strong" if args.workload == "million" else "weak", "vs_baseline": None,
@@ -542,7 +668,8 @@ def main():
                              "kernels, which extra.full_two_kernels times)" if "fused" in m["stages"] else
                              "the per-stage kernels" + (" side by side on two streams" if args.concurrent & 1 else " one after the other")),
                    "clock_spinup_s": args.spinup,
-                   "input": "pinned host memory, pipelined H2D / kernels / D2H (PCIe-inclusive)" if args.host_feed else "resident in HBM",
+                   "input": {0: "resident in HBM", 1: "pinned host memory, pipelined H2D / kernels / D2H (PCIe-inclusive)",
+                             2: "SND wire bodies in pinned host memory, pipelined, unpacked on the device (PCIe-inclusive)"}[args.host_feed],
                    "sharding": "channel blocks per GPU, no collectives",
                    "rendezvous": ("none" if world == 1 else rdv.backend if not rdv.fallback_reason else
                                   "gloo (RCCL FAILED: %s)" % rdv.fallback_reason)},
@@ -551,66 +678,124 @@ def main():
                      "note": "each rank's own channel-superframes / its own wall time; `value` uses the max wall over ranks"},
         "roofline": roofline(stages[dom], stage_traffic(traffic, stages[dom]), src),
     }
+    # every measured kernel on every configuration, one short entry each: what the driver's record keeps of the line
+    summary = {}
+
+    def note(label, stage, tr=None, tsrc=None):
+        r = roofline(stage, stage_traffic(tr, stage) if tr else None, tsrc)
+        e = {"kernel": stage["kernel"], "ms": round(stage["avg_ms"], 4), "frac_hbm": round(r["frac_hbm"], 4)}
+        if "issue" in r:
+            e["frac_f32_issue"] = round(r["issue"]["frac_f32"], 3)
+        if r.get("traffic"):
+            e["traffic_over_algorithmic"] = round(r["traffic"] / stage["bytes"], 3)
+        if "reference_cpu" in stage:
+            e["gpu_over_one_reference_core"] = round(stage["reference_cpu"]["units_per_s_gpu"] / stage["reference_cpu"]["units_per_s_one_core"])
+        summary[label] = e
+        return r
+
     for k, label in (("wf", "roofline_fft"), ("audio", "roofline_audio"), ("fused", "roofline_fused")):
-        if k in stages and k != dom:
-            out[label] = roofline(stages[k], stage_traffic(traffic, stages[k]), src)
+        if k in stages:
+            r = note("%s.%s" % (args.workload, k), stages[k], traffic, src)
+            if k != dom:
+                full[label] = r
     if "wf" in stages and "audio" in stages:
         # the chain as one unit (fused budget): the input counted once, 4096 + 2048/N + 2048 B per channel-superframe
         b = channels * sframes * (4096.0 + (2 if args.hop == 512 else 1) * 2048.0 / n_avg + 2048.0)
         ms = stages["wf"]["avg_ms"] + stages["audio"]["avg_ms"]
-        out["roofline_chain"] = {"kernel": "waterfall + audio stage", "bound": "hbm", "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBPS,
-                                 "unit": "GB/s", "frac": b / ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "avg_kernel_ms": ms,
-                                 "algorithmic_bytes_per_launch": b}
+        full["roofline_chain"] = {"kernel": "waterfall + audio stage", "bound": "hbm", "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBPS,
+                                  "unit": "GB/s", "frac": b / ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "avg_kernel_ms": ms,
+                                  "algorithmic_bytes_per_launch": b}
 
     if rank == 0 and world == 1 and args.workload == "full" and not args.no_extra and not args.host_feed:
-        # configs[1] and configs[3] in the same driver-timed line: shorter runs, each with its own rooflines
         extra = {}
-        for wl in ("wf", "mixed"):
+
+        def chain_frac(e, ch, sf, navg, hop=1024):
+            """the chain as one unit against the HBM roof: SURVEY.md 8d's fused budget over the step time"""
+            b = ch * sf * (4096.0 + (2 if hop == 512 else 1) * 2048.0 / navg + 2048.0)
+            return {"chain_GBps": b / e["ms_per_step"] / 1e6, "chain_frac": b / e["ms_per_step"] / 1e6 / HBM_PEAK_GBPS}
+
+        def run_extra(key, wl, nsteps, text="", warm=2, spin=0.5, **kw):
             ch, sf = WORKLOADS[wl][0], WORKLOADS[wl][1]
-            e = measure(S, L, torch, rdv, rank, world, local_rank, wl, ch, sf, max(20, args.steps // 2), 2, 0.5, args.concurrent)
-            tr, tsrc = pmc_traffic(wl, ch, sf)
-            extra[wl] = {"workload": WORKLOAD_TEXT[wl], "value": e["value"], "unit": "rt_channels", "ms_per_step": e["ms_per_step"],
-                         "steps": max(20, args.steps // 2), "channels_per_gpu": ch, "superframes_per_step": sf, "averaging_n": e["n_avg"],
-                         "audio_paths": {PATH_TEXT[p]: e["paths"][p] for p in range(3) if e["paths"][p]} if WORKLOADS[wl][5] else {},
-                         "rooflines": [roofline(s, stage_traffic(tr, s), tsrc) for s in e["stages"].values()]}
-        # variants of the default workload that the design discusses, timed by the same run:
-        # both stages side by side on two streams; the fused superframe kernel; the waterfall at the reference's line rate
+            e = measure(S, L, torch, rdv, rank, world, local_rank, wl, ch, sf, nsteps, warm, spin, **kw)
+            tr, tsrc = pmc_traffic(wl, ch, sf, kw.get("hop", 1024)) if not kw.get("exact") else ({}, None)
+            extra[key] = {"workload": WORKLOAD_TEXT[wl] + text, "value": e["value"], "unit": "rt_channels", "ms_per_step": e["ms_per_step"],
+                          "steps": nsteps, "channels_per_gpu": ch, "superframes_per_step": sf, "averaging_n": e["n_avg"],
+                          "input_decimation": e["decim"],
+                          "audio_paths": {PATH_TEXT[p]: e["paths"][p] for p in range(3) if e["paths"][p]} if WORKLOADS[wl][5] else {},
+                          "rooflines": [note("%s.%s" % (key, sk), sv, tr, tsrc) for sk, sv in e["stages"].items()]}
+            if WORKLOADS[wl][4] and WORKLOADS[wl][5]:
+                extra[key].update(chain_frac(e, ch, sf, e["n_avg"], kw.get("hop", 1024)))
+            return e
+
         nst = max(20, args.steps // 3)
-        ch, sf = WORKLOADS["full"][0], WORKLOADS["full"][1]
-        for key, kw in (("full_two_kernels", dict(fused=0)), ("full_concurrent", dict(concurrent=1))):
-            e = measure(S, L, torch, rdv, rank, world, local_rank, "full", ch, sf, nst, 2, 0.5, **kw)
-            b = ch * sf * 8192.0
-            tr, tsrc = pmc_traffic("full", ch, sf)
-            extra[key] = {"workload": WORKLOAD_TEXT["full"] + (", waterfall and audio stage side by side on two streams (--concurrent 1)" if "concurrent" in kw
-                                                             else ", the two per-stage kernels one after the other (--fused 0)"),
-                          "value": e["value"], "unit": "rt_channels", "ms_per_step": e["ms_per_step"], "steps": nst,
-                          "chain_GBps": b / e["ms_per_step"] / 1e6, "chain_frac": b / e["ms_per_step"] / 1e6 / HBM_PEAK_GBPS}
-            if "fused" in kw:
-                extra[key]["rooflines"] = [roofline(s_, stage_traffic(tr, s_), tsrc) for s_ in e["stages"].values()]
-        ch, sf = WORKLOADS["wf"][0], WORKLOADS["wf"][1]
-        e = measure(S, L, torch, rdv, rank, world, local_rank, "wf", ch, sf, nst, 2, 0.5, hop=512)
-        tr, tsrc = pmc_traffic("wf", ch, sf, 512)
-        extra["wf_hop512"] = {"workload": WORKLOAD_TEXT["wf"] + ", hop 512 (23.4 lines/s)", "value": e["value"], "unit": "rt_channels",
-                              "ms_per_step": e["ms_per_step"], "steps": nst, "lines_per_s": e["stages"]["wf"]["lines_per_launch"] / e["ms_per_step"] * 1e3,
-                              "rooflines": [roofline(s, stage_traffic(tr, s), tsrc) for s in e["stages"].values()]}
-        # configs[4] at N = 1 (2^20 channels on this one GPU), the decimating front end, and the float64 exact-bins mode
-        for key, wl, kw, nsteps in (("million", "million", {}, 10), ("decim4", "decim4", {}, nst), ("wf_exact_bins", "wf", dict(exact=1), 3)):
-            ch, sf = WORKLOADS[wl][0], WORKLOADS[wl][1]
-            e = measure(S, L, torch, rdv, rank, world, local_rank, wl, ch, sf, nsteps, 1, 0.3, **kw)
-            extra[key] = {"workload": WORKLOAD_TEXT[wl] + (", float64 waterfall stage (--exact 1)" if kw else ""), "value": e["value"],
-                          "unit": "rt_channels", "ms_per_step": e["ms_per_step"], "steps": nsteps, "channels_per_gpu": ch,
-                          "superframes_per_step": sf, "input_decimation": e["decim"],
-                          "audio_paths": {PATH_TEXT[p]: e["paths"][p] for p in range(3) if e["paths"][p]},
-                          "rooflines": [roofline(s_) for s_ in e["stages"].values()]}
-        out["extra"] = extra
+        # configs[1] and configs[3] in the same driver-timed line: shorter runs, each with its own rooflines
+        run_extra("wf", "wf", max(20, args.steps // 2))
+        run_extra("mixed", "mixed", max(20, args.steps // 2))
+        # variants of the default workload that the design discusses (DESIGN.md section 6), timed by the same run
+        run_extra("full_two_kernels", "full", nst, ", the two per-stage kernels one after the other (--fused 0)", fused=0)
+        run_extra("full_exact", "full", nst, ", float64 waterfall stage (--exact 1: bins equal the NumPy float64 path bit for bit) + audio stage", exact=1)
+        run_extra("wf_exact_bins", "wf", nst, ", float64 waterfall stage (--exact 1)", exact=1)
+        e = run_extra("wf_hop512", "wf", nst, ", hop 512 (23.4 lines/s)", hop=512)
+        extra["wf_hop512"]["lines_per_s"] = e["stages"]["wf"]["lines_per_launch"] / e["ms_per_step"] * 1e3
+        run_extra("full_hop512", "full", nst, ", waterfall at hop 512 (23.4 lines/s, the reference's line rate)", hop=512)
+        # configs[4] at N = 1 (2^20 channels on this one GPU, 16 superframes per call) and the decimating front end
+        run_extra("million", "million", 5, warm=1, spin=0.3)
+        run_extra("decim4", "decim4", nst, warm=1, spin=0.3)
+        # SURVEY.md 8f: the reference's own post-processing on the GPU, next to the reference's own timings
+        post = measure_post(S, L, local_rank)
+        extra["post"] = {"workload": "spectrum_db2col / play_buffer (x4 and 64/27) / IQ wire unpack on the results of a 65536-channel x 16-superframe chain run",
+                         "rooflines": [note("post." + k, v) for k, v in post.items()],
+                         "reference_cpu": {v["kernel"]: v["reference_cpu"] for v in post.values() if "reference_cpu" in v}}
+        # the product's own ingest API in front of the pipelined feed (PCIe-inclusive, never `value`)
+        if args.host_feed_extra:
+            extra["hub_feed"] = {k: measure_hub(S, L, torch, local_rank, 65536, 16, 2, in_place=ip) for k, ip in (("feed_block", False), ("in_place", True))}
+        full["extra"] = extra
+    full["roofline"]["stages"] = summary
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload)
-        print(json.dumps(out), flush=True)
+            full["cpu_baseline"] = cpu_baseline(args.workload)
+        if args.record:
+            with open(args.record, "w") as f:
+                json.dump(full, f, indent=1)
+        print(json.dumps(full if args.verbose_line else compact_line(full)), flush=True)
     rdv.close()
     if not parity["ranks_agree"]:
         raise SystemExit("bench.py: PARITY HASH MISMATCH between ranks: %r" % (parity,))
+
+
+def compact_line(full):
+    """the ONE JSON line: the contract's fields, the dominant kernel's roofline with a one-entry-per-kernel summary of every
+    configuration measured (roofline.stages), the CPU baseline, and the value / step time of every extra workload.  The long
+    form (every roofline object, sources, notes) goes to --record FILE."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: full[k] for k in keep}
+    c = full["config"]
+    out["config"] = {k: c[k] for k in ("workload", "channels_per_gpu", "superframes_per_step", "averaging_n", "wf_hop", "wf_exact_bins",
+                                        "input", "sharding", "rendezvous")}
+    out["config"]["chain"] = "fused kernel (ssdr_run_chain)" if c["chain"].startswith("ssdr_run_chain") else c["chain"]
+    p = full["parity"]
+    out["parity"] = {k: p[k] for k in ("ranks_agree", "checksums", "skipped") if k in p}
+    out["per_rank"] = {k: full["per_rank"][k] for k in ("value_min", "value_max")}
+    r = full["roofline"]
+    out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_hbm", "traffic", "avg_kernel_ms",
+                                          "algorithmic_bytes_per_launch", "stages") if k in r}
+    if "cpu_baseline" in full:
+        cb = full["cpu_baseline"]
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
+        for k in ("c_twin", "one_process"):
+            if k in cb:
+                out["cpu_baseline"][k + "_value"] = cb[k]["value"]
+        if "post" in cb:
+            out["cpu_baseline"]["post"] = cb["post"]
+    if "extra" in full:
+        out["extra"] = {}
+        for k, v in full["extra"].items():
+            if "value" in v:
+                out["extra"][k] = {kk: (round(v[kk], 4) if isinstance(v[kk], float) else v[kk]) for kk in ("value", "ms_per_step", "chain_frac") if kk in v}
+            elif k == "hub_feed":
+                out["extra"][k] = {kk: {"value": vv["value"], "ms_per_superframe": round(vv["ms_per_superframe"], 3)} for kk, vv in v.items()}
+    return out
 
 
 if __name__ == "__main__":
