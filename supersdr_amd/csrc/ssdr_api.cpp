@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <utility>
 #include <vector>
 
 static thread_local char g_hip_err[256] = "";
@@ -138,6 +139,7 @@ struct ssdr_ctx {
     size_t color_lines = 0;
     ssdr_play_chan *d_play = nullptr;
     double *d_play_taps = nullptr, *d_play_hist = nullptr, *d_play_rs_taps = nullptr;
+    double *d_play_hist_alt = nullptr;      // the kernel reads d_play_hist and writes this one; swapped after every launch
     float *d_wfdata = nullptr;              // [wfdata_rows][n_ch][1024] newest rows of wf_data, row k at slot (head + k) % rows
     float *d_wfpend = nullptr;              // [3][n_ch][1024] wf_data_tmp: deque(maxlen = wf_buffer_len = 3) in front of it
     uint32_t wfdata_rows = 0, wfdata_head = 0, wfpend_n = 0;
@@ -234,7 +236,7 @@ void ssdr_destroy(ssdr_ctx *c)
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_wf_tail, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_flags, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
-                    c->d_play_taps, c->d_play_hist, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
+                    c->d_play_taps, c->d_play_hist, c->d_play_hist_alt, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
                     c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64, c->d_wire_gps, c->d_iq_out, c->d_zoom_taps, c->d_zoom_dphi, c->d_zoom_phase, c->d_zoom_hist, c->d_zoom_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -1037,6 +1039,7 @@ static int ensure_play(ssdr_ctx *c)
         HIP_TRY(hipMalloc(&c->d_play, (size_t)c->n_ch * sizeof(ssdr_play_chan)));
         HIP_TRY(hipMalloc(&c->d_play_taps, 33 * sizeof(double)));
         HIP_TRY(hipMalloc(&c->d_play_hist, (size_t)c->n_ch * 8 * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_play_hist_alt, (size_t)c->n_ch * 8 * sizeof(double)));
         HIP_TRY(hipMalloc(&c->d_play_rs_taps, sizeof(SSDR_RS_TAPS)));
         HIP_TRY(hipMemsetAsync(c->d_play_hist, 0, (size_t)c->n_ch * 8 * sizeof(double), c->stream));   // old_buffer = zeros (:1005)
         if (c->pending_play_hist.size() == (size_t)c->n_ch * 8) {
@@ -1209,11 +1212,13 @@ static int feed_submit_impl(ssdr_ctx *c, const void *host_in)
         HIP_TRY(hipMemcpyAsync(c->d_play, s.h_playchan, (size_t)c->n_ch * sizeof(ssdr_play_chan), hipMemcpyHostToDevice, c->stream));
         SsdrPlayArgs pa;
         pa.pcm = s.d_pcm; pa.n_ch = c->n_ch; pa.n_frames = nf; pa.chans = c->d_play; pa.taps = c->d_play_taps; pa.hist = c->d_play_hist;
+        pa.hist_out = c->d_play_hist_alt;
         pa.out = s.d_play; pa.rs_taps = c->d_play_rs_taps; pa.mono = c->recording ? s.d_mono : nullptr;
         s.has_mono = c->recording;
         int r3;
         if ((r3 = timed_begin(c)) != SSDR_OK) return r3;
         HIP_TRY(c->kiwi_rate != SSDR_RATE ? ssdr_launch_play_rs(pa, c->stream) : ssdr_launch_play(pa, c->stream));
+        if (c->kiwi_rate == SSDR_RATE) std::swap(c->d_play_hist, c->d_play_hist_alt);
         if ((r3 = timed_end(c, SSDR_K_PLAY)) != SSDR_OK) return r3;
         return SSDR_OK;
     }();
@@ -1780,6 +1785,7 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
     a.chans = c->d_play;
     a.taps = c->d_play_taps;
     a.hist = c->d_play_hist;
+    a.hist_out = c->d_play_hist_alt;
     a.out = c->d_play_out;
     a.rs_taps = c->d_play_rs_taps;
     a.mono = c->recording ? c->d_play_mono : nullptr;
@@ -1788,6 +1794,7 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
     int rc;
     if ((rc = timed_begin(c)) != SSDR_OK) return rc;
     HIP_TRY(wide ? ssdr_launch_play_rs(a, c->stream) : ssdr_launch_play(a, c->stream));
+    if (!wide) std::swap(c->d_play_hist, c->d_play_hist_alt);            // (the 64/27 branch carries no history)
     if ((rc = timed_end(c, SSDR_K_PLAY)) != SSDR_OK) return rc;
     if (out)
         HIP_TRY(hipMemcpyAsync(out, c->d_play_out, (size_t)c->n_ch * nf * per_frame * 2 * sizeof(int16_t),

@@ -50,7 +50,8 @@ SSDR_DEV int wave_max_i(int x)
 }
 SSDR_DEV int wave_min_i(int x) { return -wave_max_i(-x); }
 
-// One wave per channel, lines in order; lane l owns bins 16l .. 16l+15.
+// One wave per (channel, line) -- lines are independent of one another: with auto-scaling a line's clip levels come from the
+// line itself, without it they are the caller's and stay what they are.
 //
 // NumPy on a float32 line (restated, utils_supersdr.py:787-813):
 //   wf_db   = (-(255 - s) - 13) + 3 zoom               three float32 roundings
@@ -59,71 +60,117 @@ SSDR_DEV int wave_min_i(int x) { return -wave_max_i(-x); }
 //             on float32: q = 40/float32(100), virtual index 1024 q + (1 - q) - 1 in float32 -> gamma G)
 //   high    = max;  dyn = max(high - low, 40)
 //   color   = clip(clip((wf_db - (low + dlo)) / ((dyn + dhi) - dlo), 0, 1) * 254, 0, 255)
-// The order statistics are taken on the int16 sums (the map sum -> wf_db is monotone), by bisection on the
-// value with wave-wide counting: exact, no sort.
-__global__ __launch_bounds__(64) void ssdr_db2col_kernel(SsdrDb2colArgs a)
+// The order statistics are taken on the int16 sums (the map sum -> wf_db is monotone), by bisection on the value over
+// [0, 255 N] -- 8 steps at N = 1, 12 at N = 10 -- with the count taken by wave-wide compares (v_cmp writes a lane mask to
+// scalar registers, s_bcnt1 counts it: no cross-lane reduction, the decision is scalar): exact, no sort.
+// The 1024 divisions of a line share their divisor: where it is an ordinary number the quotients are formed with the
+// correctly rounded division's own refinement steps on ONE reciprocal (the sequence a float32 divide compiles to, minus
+// its per-quotient reciprocal and scaling); a zero, huge, tiny or non-finite divisor takes the plain divide.
+// num / den correctly rounded, given r = refined_rcp(den): the refinement steps of the float32 divide (what `/` compiles to on
+// gfx950: rcp, one Newton step, quotient, two residual corrections) with the reciprocal shared by all quotients of one divisor.
+// Valid where nothing leaves the normal range: |den| in [2^-40, 2^40], num = 0 or 2^-20 <= |num| < 2^24.
+SSDR_DEV float refined_rcp(float den)
 {
-    const int l = threadIdx.x;
-    const uint32_t ch = blockIdx.x;
-    if (ch >= a.n_ch) return;
+    const float r = __builtin_amdgcn_rcpf(den);
+    return fmaf(fmaf(-den, r, 1.0f), r, r);
+}
+SSDR_DEV float div_shared(float num, float den, float r)
+{
+    float c = num * r;
+    c = fmaf(fmaf(-den, c, num), r, c);
+    return fmaf(fmaf(-den, c, num), r, c);
+}
+
+SSDR_DEV int wave_count_le(const int (&s)[16], int mid)
+{
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) c += __builtin_popcountll(__ballot(s[i] <= mid));
+    return c;
+}
+
+__global__ __launch_bounds__(256) void ssdr_db2col_kernel(SsdrDb2colArgs a)
+{
+    const int l = threadIdx.x & 63;
+    const uint64_t item = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (uint64_t)a.n_ch * a.n_lines) return;
+    const uint32_t line = (uint32_t)(item / a.n_ch), ch = (uint32_t)(item - (uint64_t)line * a.n_ch);       // line-major, like the data
     ssdr_db2col_chan st = a.chans[ch];
     const float z3 = (float)(3 * st.zoom), dlo = (float)st.delta_low_db, dhi = (float)st.delta_high_db;
     const float fn = (float)a.n_avg;
     const float G = 0x1.99ap-3f;
 
-    for (uint32_t line = 0; line < a.n_lines; line++) {
-        const u32x4 *src = reinterpret_cast<const u32x4 *>(a.wf + ((uint64_t)line * a.n_ch + ch) * SSDR_NFFT) + 2 * l;
-        const u32x4 r0 = src[0], r1 = src[1];
-        const uint32_t rw[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-        int s[16];
+    // lane l owns bins 256 q + 4 l .. + 3, q = 0..3: every load instruction reads 512 contiguous bytes of the line, every store
+    // writes 1 KB of the colour line (the order statistics do not care who holds which bin)
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 *src = reinterpret_cast<const u32x2 *>(a.wf + ((uint64_t)line * a.n_ch + ch) * SSDR_NFFT) + l;
+    int s[16];
 #pragma unroll
-        for (int i = 0; i < 8; i++) { s[2 * i] = (int)(rw[i] & 0xFFFFu); s[2 * i + 1] = (int)(rw[i] >> 16); }
-        if (l == 0) s[0] = s[1];                                    // "first bin is broken" (:791)
+    for (int q = 0; q < 4; q++) {
+        const u32x2 r = __builtin_nontemporal_load(src + 64 * q);
+        s[4 * q] = (int)(r.x & 0xFFFFu); s[4 * q + 1] = (int)(r.x >> 16);
+        s[4 * q + 2] = (int)(r.y & 0xFFFFu); s[4 * q + 3] = (int)(r.y >> 16);
+    }
+    if (l == 0) s[0] = s[1];                                    // "first bin is broken" (:791)
 
-        float wf_db[16];
+    const float rn = refined_rcp(fn);                            // N in 1..100, sums in 0..25500: float32(sum) / float32(N) == np.mean
+    float wf_db[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const float sp = div_shared((float)s[i], fn, rn);
+        wf_db[i] = (-(255.0f - sp) - 13.0f) + z3;
+    }
+
+    if (st.auto_scale) {
+        // smallest v with #{s <= v} >= 410  ==  sorted[409]; the sums of N byte lines lie in [0, 255 N]
+        int lo = 0, hi = min(255 * (int)a.n_avg, 32767);
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (wave_count_le(s, mid) >= 410) hi = mid; else lo = mid + 1;
+        }
+        const int v409 = lo;
+        int above = 0x7FFF, mx = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const float sp = (float)s[i] / fn;                       // float32(sum) / float32(N) == np.mean
-            wf_db[i] = (-(255.0f - sp) - 13.0f) + z3;
+            above = min(above, (s[i] > v409) ? s[i] : 0x7FFF);
+            mx = max(mx, s[i]);
         }
+        const int v410 = (wave_count_le(s, v409) >= 411) ? v409 : wave_min_i(above);
+        const int vmax = wave_max_i(mx);
+        const float fa = (-(255.0f - div_shared((float)v409, fn, rn)) - 13.0f) + z3;
+        const float fb = (-(255.0f - div_shared((float)v410, fn, rn)) - 13.0f) + z3;
+        const float fh = (-(255.0f - div_shared((float)vmax, fn, rn)) - 13.0f) + z3;
+        const float d = fb - fa;
+        const float t = d * G;
+        st.low_clip_db = fa + t;
+        st.high_clip_db = fh;
+        const float span = fh - st.low_clip_db;
+        st.dynamic_range = (span > 40.0f) ? span : 40.0f;
+    }
+    const float lo2 = st.low_clip_db + dlo;
+    const float nf = st.dynamic_range + dhi;
+    const float den = nf - dlo;
+    st.wf_min_db = lo2 - z3;
+    st.wf_max_db = (st.low_clip_db + nf) - z3;
 
-        if (st.auto_scale) {
-            // smallest v with #{s <= v} >= 410  ==  sorted[409]
-            int lo = 0, hi = 32767;
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                int c = 0;
+    f32x4 *dst0 = reinterpret_cast<f32x4 *>(a.color + ((uint64_t)line * a.n_ch + ch) * SSDR_NFFT) + l;
+    const float aden = fabsf(den);
+    if (aden >= 0x1p-40f && aden <= 0x1p40f) {                  // wave-uniform
+        // num / den, correctly rounded: r = rcp refined once; q = num r refined twice against the exact residual.  |num| < 2^20 and is
+        // 0 or >= 2^-17, so no step leaves the normal range and the divide's scaling (v_div_scale / v_div_fixup) has nothing to do
+        const float r = refined_rcp(den);
 #pragma unroll
-                for (int i = 0; i < 16; i++) c += (s[i] <= mid) ? 1 : 0;
-                if (wave_sum_i(c) >= 410) hi = mid; else lo = mid + 1;
-            }
-            const int v409 = lo;
-            int c = 0, above = 0x7FFF, mx = 0;
+        for (int q = 0; q < 4; q++) {
+            f32x4 o;
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                c += (s[i] <= v409) ? 1 : 0;
-                above = min(above, (s[i] > v409) ? s[i] : 0x7FFF);
-                mx = max(mx, s[i]);
+            for (int i = 0; i < 4; i++) {
+                float c = div_shared(wf_db[4 * q + i] - lo2, den, r);
+                c = fminf(fmaxf(c, 0.0f), 1.0f) * 254.0f;
+                o[i] = fminf(fmaxf(c, 0.0f), 255.0f);
             }
-            const int v410 = (wave_sum_i(c) >= 411) ? v409 : wave_min_i(above);
-            const int vmax = wave_max_i(mx);
-            const float fa = (-(255.0f - (float)v409 / fn) - 13.0f) + z3;
-            const float fb = (-(255.0f - (float)v410 / fn) - 13.0f) + z3;
-            const float fh = (-(255.0f - (float)vmax / fn) - 13.0f) + z3;
-            const float d = fb - fa;
-            const float t = d * G;
-            st.low_clip_db = fa + t;
-            st.high_clip_db = fh;
-            const float span = fh - st.low_clip_db;
-            st.dynamic_range = (span > 40.0f) ? span : 40.0f;
+            __builtin_nontemporal_store(o, dst0 + 64 * q);
         }
-        const float lo2 = st.low_clip_db + dlo;
-        const float nf = st.dynamic_range + dhi;
-        const float den = nf - dlo;
-        st.wf_min_db = lo2 - z3;
-        st.wf_max_db = (st.low_clip_db + nf) - z3;
-
-        f32x4 *dst = reinterpret_cast<f32x4 *>(a.color + ((uint64_t)line * a.n_ch + ch) * SSDR_NFFT) + 4 * l;
+    } else {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             f32x4 o;
@@ -133,61 +180,80 @@ __global__ __launch_bounds__(64) void ssdr_db2col_kernel(SsdrDb2colArgs a)
                 c = fminf(fmaxf(c, 0.0f), 1.0f) * 254.0f;
                 o[i] = fminf(fmaxf(c, 0.0f), 255.0f);
             }
-            dst[q] = o;
+            __builtin_nontemporal_store(o, dst0 + 64 * q);
         }
     }
-    if (l == 0) a.chans[ch] = st;
+    // the display state as the LAST line leaves it (utils_supersdr.py:795-808); only the fields spectrum_db2col writes
+    if (l == 0 && line + 1 == a.n_lines) {
+        ssdr_db2col_chan *o = a.chans + ch;
+        o->low_clip_db = st.low_clip_db; o->high_clip_db = st.high_clip_db; o->dynamic_range = st.dynamic_range;
+        o->wf_min_db = st.wf_min_db; o->wf_max_db = st.wf_max_db;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// play_buffer: out[4n + r] for r = 0..3.  With zero stuffing only every 4th term of the 33-tap convolution
-// is non-zero:  y[i] = 4 * sum_j h[j] U[i + 32 - j],  U = [history(32) | stuffed frame],  U[m] != 0 only for
-// m = 0 mod 4.  One wave per channel; lane l produces outputs 32l .. 32l+31 of each 2048-sample block.
-__global__ __launch_bounds__(64) void ssdr_play_kernel(SsdrPlayArgs a)
+// play_buffer: out[4m + r] for r = 0..3.  With zero stuffing only every 4th term of the 33-tap convolution is non-zero:
+//   y[4m + r] = 4 * sum_t h[r + 4t] X[m + 8 - t],  X = [8 carried samples | frame], all scaled by the volume --
+// phase 0 has nine terms, phases 1..3 eight -- summed in ascending sample order like np.convolve, multiply then add in
+// float64.  One wave per (channel, frame): the carried samples of a frame are the previous frame's last eight (the ctx's
+// history for the first frame of a call; the last frame's tail goes to `hist_out`, a different buffer).  Lane l takes input
+// positions m = 64 k + l: the nine samples it needs are nine conflict-free LDS reads shared by its four outputs, which
+// leave as ONE 16-byte store -- every store instruction of the wave writes 1 KB of contiguous output.
+__global__ __launch_bounds__(256) void ssdr_play_kernel(SsdrPlayArgs a)
 {
-    __shared__ double s_x[8 + SSDR_FRAME];                          // 8 carried samples + the frame, volume applied
-    const int l = threadIdx.x;
-    const uint32_t ch = blockIdx.x;
-    if (ch >= a.n_ch) return;
+    __shared__ double s_xw[4][8 + SSDR_FRAME];                      // per wave: 8 carried samples + the frame, volume applied
+    const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t item = (uint64_t)blockIdx.x * 4 + wave;
+    if (item >= (uint64_t)a.n_ch * a.n_frames) return;
+    const uint32_t ch = (uint32_t)(item / a.n_frames), f = (uint32_t)(item - (uint64_t)ch * a.n_frames);
+    double *s_x = s_xw[wave];
     const ssdr_play_chan pc = a.chans[ch];
     const double vol = pc.volume / 100.0;
     const double lv = fmin(1.0 - pc.balance, 1.0), rv = fmin(1.0 + pc.balance, 1.0);
     const double l2 = lv * lv, r2 = rv * rv;
     double h[33];
 #pragma unroll
-    for (int j = 0; j < 33; j++) h[j] = a.taps[j];
-    if (l < 8) s_x[l] = a.hist[(size_t)ch * 8 + l];
-    __syncthreads();
+    for (int j = 0; j < 33; j++) h[j] = a.taps[j];                  // uniform address: scalar loads
 
-    for (uint32_t f = 0; f < a.n_frames; f++) {
-        const int16_t *src = a.pcm + ((uint64_t)ch * a.n_frames + f) * SSDR_FRAME;
+    const int16_t *src = a.pcm + ((uint64_t)ch * a.n_frames + f) * SSDR_FRAME;
 #pragma unroll
-        for (int i = 0; i < 8; i++) s_x[8 + 8 * l + i] = (double)src[8 * l + i] * vol;
-        __syncthreads();
-        // stuffed index m = 4 * (k) holds X[k], X = s_x (k = 0..519; k < 8 is history)
-        uint32_t *dst = reinterpret_cast<uint32_t *>(a.out + (((uint64_t)ch * a.n_frames + f) * 2048 + 32 * l) * 2);
-        for (int o4 = 0; o4 < 32; o4 += 4) {
+    for (int k = 0; k < 8; k++) s_x[8 + 64 * k + l] = (double)src[64 * k + l] * vol;
+    if (l < 8) s_x[l] = f ? (double)src[l - 8] * vol : a.hist[(size_t)ch * 8 + l];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    u32x4 *dst = reinterpret_cast<u32x4 *>(a.out + ((uint64_t)ch * a.n_frames + f) * 2048 * 2);
+    int16_t *mono = a.mono ? a.mono + ((uint64_t)ch * a.n_frames + f) * 2048 : nullptr;
+#pragma unroll 2
+    for (int k = 0; k < 8; k++) {
+        const int m = 64 * k + l;
+        double x[9];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {                           // i = 32 l + o4 + r, so i mod 4 == r (static)
-                const int i = 32 * l + o4 + r;
-                // terms j with (i + 32 - j) = 0 mod 4  ->  j = r + 4 t (j <= 32), summed in ascending sample order
-                double acc = 0.0;
+        for (int i = 0; i < 9; i++) x[i] = s_x[m + i];
+        uint32_t o[4];
+        int mo[4];
 #pragma unroll
-                for (int t = 8; t >= 0; t--) {
-                    const int j = r + 4 * t;
-                    if (j <= 32) acc += h[j] * s_x[(i + 32 - j) >> 2];
-                }
-                acc *= 4.0;
-                const int li = (int)(acc * l2), ri = (int)(acc * r2);    // trunc toward zero, then wrap to int16
-                dst[o4 + r] = ((uint32_t)li & 0xFFFFu) | ((uint32_t)ri << 16);
-                if (a.mono) a.mono[((uint64_t)ch * a.n_frames + f) * 2048 + i] = (int16_t)(int)acc;    // recording branch (:1139-1140)
+        for (int r = 0; r < 4; r++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int t = 8; t >= 0; t--) {
+                const int j = r + 4 * t;
+                if (j <= 32) acc += h[j] * x[8 - t];
             }
+            acc *= 4.0;
+            const int li = (int)(acc * l2), ri = (int)(acc * r2);        // trunc toward zero, then wrap to int16
+            o[r] = ((uint32_t)li & 0xFFFFu) | ((uint32_t)ri << 16);
+            mo[r] = (int)acc;
         }
-        __syncthreads();
-        if (l < 8) s_x[l] = s_x[SSDR_FRAME + l];
-        __syncthreads();
+        __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, dst + m);
+        if (mono) {                                                       // recording branch (:1139-1140)
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 v = {((uint32_t)mo[0] & 0xFFFFu) | ((uint32_t)mo[1] << 16), ((uint32_t)mo[2] & 0xFFFFu) | ((uint32_t)mo[3] << 16)};
+            *reinterpret_cast<u32x2 *>(mono + 4 * m) = v;
+        }
     }
-    if (l < 8) a.hist[(size_t)ch * 8 + l] = s_x[l];
+    if (f + 1 == a.n_frames && l < 8) a.hist_out[(size_t)ch * 8 + l] = s_x[SSDR_FRAME + l];
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -197,38 +263,65 @@ __global__ __launch_bounds__(64) void ssdr_play_kernel(SsdrPlayArgs a)
 // _apply_impl with MODE_LINE): output y of the full polyphase convolution uses phase t = 27 y mod 64 ending at
 // sample 27 y div 64; its 21 taps are applied oldest sample first, one multiply and one add each in float64;
 // samples outside the frame lie on the line through the frame's first and last sample; outputs
-// y = 24 .. 24 + 1212 are kept.  One workgroup per (channel, frame).
+// y = 24 .. 24 + 1212 are kept.
+// One wave per (channel, frame) at a time, persistent grid.  Output k = p + 64 j of lane p has phase 27 (p + 24) mod 64 for
+// every j: a lane's 21 taps are constants of the launch and live in registers; the frame, extended along the line on both
+// sides, lies in LDS as doubles, so the tap loop is 21 branch-free read / multiply / add steps; the lanes' outputs of one j
+// are 64 consecutive samples (a permutation of them): each store instruction fills 256 contiguous bytes.
+constexpr int RS_LEFT = SSDR_RS_HPP - 1;                                                     // 20 samples before the frame
+constexpr int RS_XMAX = ((SSDR_RS_OUT_PER_FRAME - 1 + SSDR_RS_PRE_REMOVE) * SSDR_RS_DOWN) / SSDR_RS_UP;   // last sample index touched: 521
+constexpr int RS_EXT = RS_LEFT + RS_XMAX + 1;                                                // 542 doubles
+
 __global__ __launch_bounds__(256) void ssdr_play_rs_kernel(SsdrPlayArgs a)
 {
-    __shared__ double s_x[SSDR_FRAME];
-    const uint32_t ch = blockIdx.x / a.n_frames, f = blockIdx.x - ch * a.n_frames;
-    const ssdr_play_chan pc = a.chans[ch];
-    const double vol = pc.volume / 100.0;
-    const double lv = fmin(1.0 - pc.balance, 1.0), rv = fmin(1.0 + pc.balance, 1.0);
-    const double l2 = lv * lv, r2 = rv * rv;
-    const int16_t *src = a.pcm + ((uint64_t)ch * a.n_frames + f) * SSDR_FRAME;
-    for (int i = threadIdx.x; i < SSDR_FRAME; i += blockDim.x) s_x[i] = (double)src[i] * vol;
-    __syncthreads();
-    const double x0 = s_x[0], xl = s_x[SSDR_FRAME - 1];
-    const double slope = (xl - x0) / (double)(SSDR_FRAME - 1);
-    uint32_t *dst = reinterpret_cast<uint32_t *>(a.out + ((uint64_t)ch * a.n_frames + f) * SSDR_RS_OUT_PER_FRAME * 2);
-    for (int k = threadIdx.x; k < SSDR_RS_OUT_PER_FRAME; k += blockDim.x) {
-        const int total = (k + SSDR_RS_PRE_REMOVE) * SSDR_RS_DOWN;
-        const int x_idx = total / SSDR_RS_UP, t = total % SSDR_RS_UP;
-        const double *h = a.rs_taps + t * SSDR_RS_HPP;
-        double acc = 0.0;
+    __shared__ double s_xw[4][RS_EXT];
+    const int p = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *s_x = s_xw[wave];
+    const int total0 = (p + SSDR_RS_PRE_REMOVE) * SSDR_RS_DOWN;
+    const int t = total0 % SSDR_RS_UP, x0_idx = total0 / SSDR_RS_UP;       // phase of all of this lane's outputs; end sample of its first
+    double h[SSDR_RS_HPP];
 #pragma unroll
-        for (int m = 0; m < SSDR_RS_HPP; m++) {
-            const int xi = x_idx - SSDR_RS_HPP + 1 + m;
-            double xv;
-            if (xi < 0) xv = x0 + (double)xi * slope;
-            else if (xi >= SSDR_FRAME) xv = xl + (double)(xi - SSDR_FRAME + 1) * slope;
-            else xv = s_x[xi];
-            acc = acc + xv * h[m];
+    for (int m = 0; m < SSDR_RS_HPP; m++) h[m] = a.rs_taps[t * SSDR_RS_HPP + m];
+    const uint64_t n_items = (uint64_t)a.n_ch * a.n_frames;
+    for (uint64_t item = (uint64_t)blockIdx.x * 4 + wave; item < n_items; item += (uint64_t)gridDim.x * 4) {
+        const uint32_t ch = (uint32_t)(item / a.n_frames), f = (uint32_t)(item - (uint64_t)ch * a.n_frames);
+        const ssdr_play_chan pc = a.chans[ch];
+        const double vol = pc.volume / 100.0;
+        const double lv = fmin(1.0 - pc.balance, 1.0), rv = fmin(1.0 + pc.balance, 1.0);
+        const double l2 = lv * lv, r2 = rv * rv;
+        const int16_t *src = a.pcm + ((uint64_t)ch * a.n_frames + f) * SSDR_FRAME;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s_x[RS_LEFT + 64 * k + p] = (double)src[64 * k + p] * vol;
+        const double x0 = (double)src[0] * vol, xl = (double)src[SSDR_FRAME - 1] * vol;
+        const double slope = (xl - x0) / (double)(SSDR_FRAME - 1);
+        if (p < RS_LEFT) s_x[p] = x0 + (double)(p - RS_LEFT) * slope;                              // xi = p - 20 < 0
+        else if (p < RS_LEFT + RS_XMAX + 1 - SSDR_FRAME) {                                         // xi = 512 .. 521
+            const int xi = SSDR_FRAME + (p - RS_LEFT);
+            s_x[RS_LEFT + xi] = xl + (double)(xi - SSDR_FRAME + 1) * slope;
         }
-        const int li = (int)(acc * l2), ri = (int)(acc * r2);            // trunc toward zero, then wrap to int16
-        dst[k] = ((uint32_t)li & 0xFFFFu) | ((uint32_t)ri << 16);
-        if (a.mono) a.mono[((uint64_t)ch * a.n_frames + f) * SSDR_RS_OUT_PER_FRAME + k] = (int16_t)(int)acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t *dst = reinterpret_cast<uint32_t *>(a.out + ((uint64_t)ch * a.n_frames + f) * SSDR_RS_OUT_PER_FRAME * 2);
+        int16_t *mono = a.mono ? a.mono + ((uint64_t)ch * a.n_frames + f) * SSDR_RS_OUT_PER_FRAME : nullptr;
+        constexpr int NJ = (SSDR_RS_OUT_PER_FRAME + 63) / 64;                                        // 19
+#pragma unroll 1
+        for (int j = 0; j < NJ; j++) {
+            const int k = p + 64 * j;
+            // window of output k: samples x_idx - 20 .. x_idx, x_idx = x0_idx + 27 j  ->  s_x[x0_idx + 27 j + m], m = 0..20
+            const double *xw = s_x + min(x0_idx + SSDR_RS_DOWN * j, RS_XMAX);
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < SSDR_RS_HPP; m++) acc = acc + xw[m] * h[m];
+            if (k < SSDR_RS_OUT_PER_FRAME) {
+                const int li = (int)(acc * l2), ri = (int)(acc * r2);                                // trunc toward zero, then wrap to int16
+                dst[k] = ((uint32_t)li & 0xFFFFu) | ((uint32_t)ri << 16);
+                if (mono) mono[k] = (int16_t)(int)acc;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                                                            // the next frame overwrites s_x
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -391,19 +484,35 @@ hipError_t ssdr_launch_adpcm(const uint8_t *data, uint32_t n_streams, uint32_t n
 
 hipError_t ssdr_launch_db2col(const SsdrDb2colArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(ssdr_db2col_kernel, dim3(a.n_ch), dim3(64), 0, stream, a);
+    const uint64_t items = (uint64_t)a.n_ch * a.n_lines;
+    if (!items) return hipSuccess;
+    hipLaunchKernelGGL(ssdr_db2col_kernel, dim3((uint32_t)((items + 3) / 4)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t ssdr_launch_play_rs(const SsdrPlayArgs &a, hipStream_t stream)
 {
-    if (a.n_ch == 0 || a.n_frames == 0) return hipSuccess;
-    hipLaunchKernelGGL(ssdr_play_rs_kernel, dim3(a.n_ch * a.n_frames), dim3(256), 0, stream, a);
+    const uint64_t items = (uint64_t)a.n_ch * a.n_frames;
+    if (!items) return hipSuccess;
+    static uint32_t resident = 0;                    // persistent grid: the lanes' taps are loaded once per wave
+    if (!resident) {
+        int dev = 0, per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ssdr_play_rs_kernel, 256, 0) == hipSuccess && per_cu > 0)
+            resident = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+        else
+            resident = 1024;
+    }
+    const uint64_t need = (items + 3) / 4;
+    hipLaunchKernelGGL(ssdr_play_rs_kernel, dim3((uint32_t)(need < resident ? need : resident)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t ssdr_launch_play(const SsdrPlayArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(ssdr_play_kernel, dim3(a.n_ch), dim3(64), 0, stream, a);
+    const uint64_t items = (uint64_t)a.n_ch * a.n_frames;
+    if (!items) return hipSuccess;
+    hipLaunchKernelGGL(ssdr_play_kernel, dim3((uint32_t)((items + 3) / 4)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t ssdr_launch_trace(const SsdrTraceArgs &a, hipStream_t stream)
