@@ -1118,7 +1118,7 @@ int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth, uint32_t flag
         ok = ok && hipHostMalloc(&s.h_in, wire ? wire_b : in_b, hipHostMallocDefault) == hipSuccess;
         if (wire) {
             ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_wire_rssi), rssi_b, hipHostMallocDefault) == hipSuccess;
-            ok = ok && hipMalloc(&s.d_wire, wire_b) == hipSuccess && hipMalloc(&s.d_wire_rssi, rssi_b) == hipSuccess;
+            ok = ok && hipMalloc(&s.d_wire, wire_b + 16) == hipSuccess /* the unpack kernel reads whole dwords */ && hipMalloc(&s.d_wire_rssi, rssi_b) == hipSuccess;
         }
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_wf), wf_b, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_pcm), pcm_b, hipHostMallocDefault) == hipSuccess;
@@ -1835,7 +1835,7 @@ int ssdr_push_iq_wire(ssdr_ctx *c, const uint8_t *bodies, uint32_t n_frames, flo
         if (c->d_wire_rssi) { HIP_TRY(hipFree(c->d_wire_rssi)); c->d_wire_rssi = nullptr; }
         if (c->d_wire_gps) { HIP_TRY(hipFree(c->d_wire_gps)); c->d_wire_gps = nullptr; }
         c->wire_frames = 0;
-        HIP_TRY(hipMalloc(&c->d_wire, (size_t)c->n_ch * n_frames * SSDR_WIRE_BODY));
+        HIP_TRY(hipMalloc(&c->d_wire, (size_t)c->n_ch * n_frames * SSDR_WIRE_BODY + 16));   // (the unpack kernel reads whole dwords)
         HIP_TRY(hipMalloc(&c->d_wire_rssi, (size_t)c->n_ch * n_frames * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_wire_gps, (size_t)c->n_ch * n_frames * 4 * sizeof(uint32_t)));
         c->wire_frames = n_frames;

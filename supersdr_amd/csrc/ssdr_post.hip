@@ -272,32 +272,57 @@ constexpr int RS_LEFT = SSDR_RS_HPP - 1;                                        
 constexpr int RS_XMAX = ((SSDR_RS_OUT_PER_FRAME - 1 + SSDR_RS_PRE_REMOVE) * SSDR_RS_DOWN) / SSDR_RS_UP;   // last sample index touched: 521
 constexpr int RS_EXT = RS_LEFT + RS_XMAX + 1;                                                // 542 doubles
 
+// The frame lies in LDS twice, the second copy shifted by one sample: whatever the parity of a window's first sample, one of
+// the two copies holds it 16-byte aligned, and the 21 samples arrive as eleven ds_read_b128 (left to itself the compiler pairs
+// 8-byte reads into ds_read2_b64, which moves half as many bytes per LDS cycle -- the kernel was bound by exactly that).
+constexpr int RS_PITCH = 560;                                                               // doubles per copy: even, >= RS_EXT + 1, and 2 * 560 dwords = 32 (mod 64 banks):
+                                                                                            // the two copies of a sample sit half the banks apart
+static_assert(RS_PITCH >= RS_EXT + 1 && RS_PITCH % 2 == 0, "copy pitch");
+
 __global__ __launch_bounds__(256) void ssdr_play_rs_kernel(SsdrPlayArgs a)
 {
-    __shared__ double s_xw[4][RS_EXT];
+    __shared__ __attribute__((aligned(16))) double s_xw[4][2 * RS_PITCH];
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
     const int p = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *s_x = s_xw[wave];
+    double *s_a = s_xw[wave], *s_b = s_a + RS_PITCH;               // s_a[i] = X[i], s_b[i] = X[i + 1]
     const int total0 = (p + SSDR_RS_PRE_REMOVE) * SSDR_RS_DOWN;
     const int t = total0 % SSDR_RS_UP, x0_idx = total0 / SSDR_RS_UP;       // phase of all of this lane's outputs; end sample of its first
     double h[SSDR_RS_HPP];
 #pragma unroll
     for (int m = 0; m < SSDR_RS_HPP; m++) h[m] = a.rs_taps[t * SSDR_RS_HPP + m];
     const uint64_t n_items = (uint64_t)a.n_ch * a.n_frames;
-    for (uint64_t item = (uint64_t)blockIdx.x * 4 + wave; item < n_items; item += (uint64_t)gridDim.x * 4) {
+    auto put = [&](int i, double v) { s_a[i] = v; if (i) s_b[i - 1] = v; };
+    const uint64_t stride = (uint64_t)gridDim.x * 4;
+    uint64_t item = (uint64_t)blockIdx.x * 4 + wave;
+    // the next frame's samples are fetched while this one is computed (a frame is 1 KB: one memory round trip per frame
+    // would otherwise stand in front of every 1.7 us of arithmetic)
+    int16_t cur[8], nxt[8];
+    if (item < n_items) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) cur[k] = a.pcm[item * SSDR_FRAME + 64 * k + p];
+    }
+    for (; item < n_items; item += stride) {
         const uint32_t ch = (uint32_t)(item / a.n_frames), f = (uint32_t)(item - (uint64_t)ch * a.n_frames);
+        const uint64_t nitem = item + stride < n_items ? item + stride : item;
+#pragma unroll
+        for (int k = 0; k < 8; k++) nxt[k] = a.pcm[nitem * SSDR_FRAME + 64 * k + p];
         const ssdr_play_chan pc = a.chans[ch];
         const double vol = pc.volume / 100.0;
         const double lv = fmin(1.0 - pc.balance, 1.0), rv = fmin(1.0 + pc.balance, 1.0);
         const double l2 = lv * lv, r2 = rv * rv;
-        const int16_t *src = a.pcm + ((uint64_t)ch * a.n_frames + f) * SSDR_FRAME;
 #pragma unroll
-        for (int k = 0; k < 8; k++) s_x[RS_LEFT + 64 * k + p] = (double)src[64 * k + p] * vol;
-        const double x0 = (double)src[0] * vol, xl = (double)src[SSDR_FRAME - 1] * vol;
+        for (int k = 0; k < 8; k++) put(RS_LEFT + 64 * k + p, (double)cur[k] * vol);
+#pragma unroll
+        for (int k = 0; k < 8; k++) cur[k] = nxt[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const double x0 = s_a[RS_LEFT], xl = s_a[RS_LEFT + SSDR_FRAME - 1];
         const double slope = (xl - x0) / (double)(SSDR_FRAME - 1);
-        if (p < RS_LEFT) s_x[p] = x0 + (double)(p - RS_LEFT) * slope;                              // xi = p - 20 < 0
+        if (p < RS_LEFT) put(p, x0 + (double)(p - RS_LEFT) * slope);                              // xi = p - 20 < 0
         else if (p < RS_LEFT + RS_XMAX + 1 - SSDR_FRAME) {                                         // xi = 512 .. 521
             const int xi = SSDR_FRAME + (p - RS_LEFT);
-            s_x[RS_LEFT + xi] = xl + (double)(xi - SSDR_FRAME + 1) * slope;
+            put(RS_LEFT + xi, xl + (double)(xi - SSDR_FRAME + 1) * slope);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -305,14 +330,22 @@ __global__ __launch_bounds__(256) void ssdr_play_rs_kernel(SsdrPlayArgs a)
         uint32_t *dst = reinterpret_cast<uint32_t *>(a.out + ((uint64_t)ch * a.n_frames + f) * SSDR_RS_OUT_PER_FRAME * 2);
         int16_t *mono = a.mono ? a.mono + ((uint64_t)ch * a.n_frames + f) * SSDR_RS_OUT_PER_FRAME : nullptr;
         constexpr int NJ = (SSDR_RS_OUT_PER_FRAME + 63) / 64;                                        // 19
+        // per output: all eleven reads are issued, then the 21-term chain runs (left to the scheduler every read is followed by
+        // its own wait, and the wave sits out the LDS latency eleven times per output)
 #pragma unroll 1
         for (int j = 0; j < NJ; j++) {
             const int k = p + 64 * j;
-            // window of output k: samples x_idx - 20 .. x_idx, x_idx = x0_idx + 27 j  ->  s_x[x0_idx + 27 j + m], m = 0..20
-            const double *xw = s_x + min(x0_idx + SSDR_RS_DOWN * j, RS_XMAX);
+            // window of output k: samples x_idx - 20 .. x_idx, x_idx = x0_idx + 27 j  ->  X[s + m], m = 0..20, s = x0_idx + 27 j
+            const int s = min(x0_idx + SSDR_RS_DOWN * j, RS_XMAX);
+            const f64x2 *xw = reinterpret_cast<const f64x2 *>((s & 1) ? s_b + (s - 1) : s_a + s);
+            double x[22];
+#pragma unroll
+            for (int m = 0; m < 11; m++) { const f64x2 v = xw[m]; x[2 * m] = v.x; x[2 * m + 1] = v.y; }
+            __builtin_amdgcn_sched_barrier(0);
             double acc = 0.0;
 #pragma unroll
-            for (int m = 0; m < SSDR_RS_HPP; m++) acc = acc + xw[m] * h[m];
+            for (int m = 0; m < SSDR_RS_HPP; m++) acc = acc + x[m] * h[m];
+            __builtin_amdgcn_sched_barrier(0);
             if (k < SSDR_RS_OUT_PER_FRAME) {
                 const int li = (int)(acc * l2), ri = (int)(acc * r2);                                // trunc toward zero, then wrap to int16
                 dst[k] = ((uint32_t)li & 0xFFFFu) | ((uint32_t)ri << 16);
@@ -320,7 +353,7 @@ __global__ __launch_bounds__(256) void ssdr_play_rs_kernel(SsdrPlayArgs a)
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                                                            // the next frame overwrites s_x
+        __builtin_amdgcn_wave_barrier();                                                            // the next frame overwrites the copies
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
@@ -376,20 +409,33 @@ __global__ __launch_bounds__(256) void ssdr_smeter_kernel(SsdrSmeterArgs a)
 }
 
 // SND body in IQ mode: 7 bytes (flags, seq, smeter) + 10 bytes GPS + 512 x (I,Q) big-endian int16.
-// One wave per (channel, frame): lane l converts samples 8l .. 8l+7 (32 payload bytes at byte offset 17 + 32 l).
-__global__ __launch_bounds__(64) void ssdr_iqwire_kernel(SsdrWireArgs a)
+// One wave per (channel, frame): lane l converts samples 8l .. 8l+7 (32 payload bytes at byte offset 17 + 32 l).  A body is
+// 2065 bytes long, so the payload sits at any byte alignment -- the same one for all lanes of a frame: each lane fetches the
+// nine aligned dwords that cover its 32 bytes (two 16-byte loads + one), v_alignbyte_b32 shifts neighbours together by the
+// frame's misalignment and one v_perm_b32 per sample swaps the bytes of I and of Q.
+__global__ __launch_bounds__(256) void ssdr_iqwire_kernel(SsdrWireArgs a)
 {
-    const int l = threadIdx.x;
-    const uint32_t f = blockIdx.x % a.n_frames, ch = blockIdx.x / a.n_frames;
-    if (ch >= a.n_ch) return;
+    const int l = threadIdx.x & 63;
+    const uint64_t item = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= (uint64_t)a.n_ch * a.n_frames) return;
+    const uint32_t ch = (uint32_t)(item / a.n_frames), f = (uint32_t)(item - (uint64_t)ch * a.n_frames);
     const uint8_t *body = a.bodies + ((uint64_t)ch * a.n_frames + f) * SSDR_WIRE_BODY;
     const uint8_t *p = body + 17 + 32 * l;
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u);                     // wave-uniform
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(p - sh);
+    uint32_t d[9];
+    {
+        typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));
+        const u32x4u v0 = *reinterpret_cast<const u32x4u *>(q), v1 = *reinterpret_cast<const u32x4u *>(q + 4);
+        d[0] = v0.x; d[1] = v0.y; d[2] = v0.z; d[3] = v0.w; d[4] = v1.x; d[5] = v1.y; d[6] = v1.z; d[7] = v1.w;
+        // the ninth dword is only needed (and, at the very end of the buffer, only there) when the payload is not dword-aligned
+        d[8] = sh ? q[8] : 0u;
+    }
     uint32_t w[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        // I = p[0..1] big-endian, Q = p[2..3] big-endian -> dword I | Q << 16 (little-endian halves)
-        const uint32_t b0 = p[4 * i], b1 = p[4 * i + 1], b2 = p[4 * i + 2], b3 = p[4 * i + 3];
-        w[i] = ((b0 << 8) | b1) | (((b2 << 8) | b3) << 16);
+        const uint32_t be = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);                  // bytes I_hi I_lo Q_hi Q_lo, lowest address first
+        w[i] = __builtin_amdgcn_perm(0u, be, 0x02030001u);                                   // -> I | Q << 16, little-endian halves
     }
     u32x4 *dst = reinterpret_cast<u32x4 *>(a.iq + (uint64_t)ch * a.ch_stride + (uint64_t)f * SSDR_FRAME) + 2 * l;
     dst[0] = u32x4{w[0], w[1], w[2], w[3]};
@@ -528,6 +574,8 @@ hipError_t ssdr_launch_smeter(const SsdrSmeterArgs &a, hipStream_t stream)
 }
 hipError_t ssdr_launch_iqwire(const SsdrWireArgs &a, hipStream_t stream)
 {
-    hipLaunchKernelGGL(ssdr_iqwire_kernel, dim3(a.n_ch * a.n_frames), dim3(64), 0, stream, a);
+    const uint64_t items = (uint64_t)a.n_ch * a.n_frames;
+    if (!items) return hipSuccess;
+    hipLaunchKernelGGL(ssdr_iqwire_kernel, dim3((uint32_t)((items + 3) / 4)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
