@@ -193,7 +193,10 @@ def spawn_ranks(gpus, argv):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         if "SSDR_BENCH_DEVICE" not in os.environ:      # one host process per GPU, confined to it; the rank then
-            env["HIP_VISIBLE_DEVICES"] = str(r)         # sees exactly one device, index 0
+            mask = [d for d in os.environ.get("HIP_VISIBLE_DEVICES", "").split(",") if d.strip()]      # sees exactly one device, index 0
+            if mask and len(mask) < gpus:
+                raise SystemExit("bench.py: --gpus %d but HIP_VISIBLE_DEVICES=%s permits %d" % (gpus, os.environ["HIP_VISIBLE_DEVICES"], len(mask)))
+            env["HIP_VISIBLE_DEVICES"] = mask[r].strip() if mask else str(r)       # rank r -> the r-th PERMITTED device
             env["SSDR_BENCH_DEVICE"] = "0"
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
@@ -574,6 +577,9 @@ def main():
     ap.add_argument("--exact", type=int, default=0, help="1: ssdr_set_exact_bins -- the waterfall stage in float64 (bins equal the float64 oracle bit for bit)")
     ap.add_argument("--no-parity-probe", action="store_true",
                     help="profiling runs only: skip the probe launches of the parity hash (they would enter the per-kernel PMC means)")
+    ap.add_argument("--rendezvous", default="gloo", choices=["gloo", "nccl"],
+                    help="process group for the barrier around the timed region, the max-over-ranks of the wall time and the parity-hash "
+                         "gather (no data moves between ranks): gloo (default), or nccl = RCCL (falls back to gloo, loudly, if it cannot come up)")
     ap.add_argument("--record", default="", help="also write the long form of the result (every roofline object, notes, sources) to this file")
     ap.add_argument("--verbose-line", action="store_true", help="print the long form as the JSON line (rounds 1-3's format)")
     ap.add_argument("--host-feed-extra", type=int, default=1, help="0: skip extra.hub_feed (the pipelined feed through IQHub; takes 8 GiB of pinned host memory)")
@@ -624,7 +630,10 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible); --gpus must not exceed the GPUs of the node"
                          % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
-    rdv = Rendezvous("nccl", torch.device("cuda", local_rank))     # barrier + max-over-ranks only
+    # barrier + max-over-ranks + the parity-hash gather: a few scalars, no data path.  SURVEY.md 8e has the parent gather them;
+    # under torch.distributed.run the ranks gather them themselves, over gloo (TCP on the loopback) unless --rendezvous nccl
+    # asks for RCCL -- which this path has no use for and which has never had more than one device to come up on here
+    rdv = Rendezvous(args.rendezvous, torch.device("cuda", local_rank) if args.rendezvous == "nccl" else None)
 
     import supersdr_amd as S
     from supersdr_amd import _lib as L

@@ -368,6 +368,9 @@ int ssdr_set_state(ssdr_ctx *ctx, uint32_t first, uint32_t count, const ssdr_cha
  * history -- as one blob of ssdr_checkpoint_size bytes (host memory).  Loading it into a ctx of the same channel count
  * (fresh or not) continues the streams bit for bit; the restored stream counts as live, so a later ssdr_set_params
  * keeps its state. */
+/* Not in the blob: the zoomed waterfall stream (ssdr_set_wf_zoom > 1: save and load return SSDR_ESTATE while a zoom is set) and
+ * mode switches that carry no stream state (ssdr_set_exact_bins, ssdr_set_fused).  The kernels' per-channel constants are
+ * recompiled from the saved ssdr_chan_params on load (blob version 4; older blobs are refused with SSDR_EINVAL). */
 int ssdr_checkpoint_size(ssdr_ctx *ctx, uint64_t *bytes);
 int ssdr_checkpoint_save(ssdr_ctx *ctx, void *blob);
 /* bytes must equal ssdr_checkpoint_size; the header and every channel's compiled constants are validated before anything

@@ -517,6 +517,8 @@ static int zoom_restart(ssdr_ctx *c, uint32_t first, uint32_t count, bool restar
     HIP_TRY(hipMemcpyAsync(c->d_zoom_dphi + first, dphi.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(c->d_zoom_phase + first, 0, count * sizeof(uint32_t), c->stream));
     HIP_TRY(hipMemsetAsync(c->d_zoom_hist + (size_t)first * SSDR_ZOOM_HIST, 0, (size_t)count * SSDR_ZOOM_HIST * 4, c->stream));
+    if (c->d_wf_tail)        // hop 512: the carried half-line belongs to the old span / centre
+        HIP_TRY(hipMemsetAsync(c->d_wf_tail + (size_t)first * (SSDR_NFFT / 2), 0, (size_t)count * (SSDR_NFFT / 2) * 4, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (restart_group) c->wf_phase = 0;
     return SSDR_OK;
@@ -534,8 +536,13 @@ int ssdr_set_wf_zoom(ssdr_ctx *c, uint32_t zoom)
         HIP_TRY(hipMalloc(&c->d_zoom_hist, (size_t)c->n_ch * SSDR_ZOOM_HIST * 4));
     }
     if (c->h_zoom_offset.size() != c->n_ch) c->h_zoom_offset.assign(c->n_ch, 0.0);
+    const bool changed = zoom != c->zoom;
     c->zoom = zoom;
     c->wf_phase = 0;
+    if (changed && zoom == 1 && c->d_wf_tail) {             // back to the full span: the carried half-line was a zoomed one
+        HIP_TRY(hipMemsetAsync(c->d_wf_tail, 0, (size_t)c->n_ch * (SSDR_NFFT / 2) * 4, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
     if (zoom > 1) {
         // the reference's tap formula (utils_supersdr.py:334-344) with the cut-off at the zoomed stream's Nyquist frequency,
         // fl / fs = 1 / (2 Z), and 32 Z - 1 taps: the transition takes the outer ~17 % of the span on either side at every Z
@@ -1396,6 +1403,10 @@ struct SsdrCkptHeader {
     uint32_t hop, decim;
 };
 static const uint32_t kCkptMagic = 0x52445353u;          // "SSDR"
+// 4: the channels' compiled constants and taps in the blob are informative only -- loading recompiles them from the saved
+// ssdr_chan_params at the blob's decimation and rate, so a blob never carries a constants layout of another build into the
+// kernels (version 3 blobs, whose `kfm` word meant padding, are refused)
+static const uint32_t kCkptVersion = 4;
 
 int ssdr_checkpoint_size(ssdr_ctx *c, uint64_t *bytes)
 {
@@ -1413,7 +1424,8 @@ int ssdr_checkpoint_save(ssdr_ctx *c, void *blob)
     HIP_TRY(hipSetDevice(c->device));
     { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     const size_t n = c->n_ch;
-    SsdrCkptHeader h = {kCkptMagic, 3, c->n_ch, c->n_avg, c->wf_phase, c->audio_started ? 1u : 0u, c->kiwi_rate,
+    if (c->zoom > 1) return SSDR_ESTATE;                     // the zoomed waterfall stream (phase, history, centres) is not part of the blob
+    SsdrCkptHeader h = {kCkptMagic, kCkptVersion, c->n_ch, c->n_avg, c->wf_phase, c->audio_started ? 1u : 0u, c->kiwi_rate,
                         c->d_play_hist ? 1u : 0u, c->synth_sample0, c->hop, c->decim};
     char *p = static_cast<char *>(blob);
     memcpy(p, &h, sizeof h); p += sizeof h;
@@ -1442,30 +1454,30 @@ int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob, uint64_t bytes)
     if (bytes != want) return SSDR_EINVAL;                    // a blob of another channel count, another version, or cut short
     SsdrCkptHeader h;
     memcpy(&h, blob, sizeof h);
-    if (h.magic != kCkptMagic || h.version != 3 || h.n_ch != c->n_ch || h.n_avg < 1 || h.n_avg > 100 || h.wf_phase >= h.n_avg ||
+    if (h.magic != kCkptMagic || h.version != kCkptVersion || h.n_ch != c->n_ch || h.n_avg < 1 || h.n_avg > 100 || h.wf_phase >= h.n_avg ||
         (h.hop != SSDR_NFFT && h.hop != SSDR_NFFT / 2) || (h.decim != 1 && h.decim != 2 && h.decim != 4) ||
         (h.kiwi_rate != SSDR_RATE && h.kiwi_rate != SSDR_RATE_WIDE))
         return SSDR_EINVAL;
-    {   // the compiled constants go to the device as they are: nothing a kernel indexes with may be out of range
-        const ssdr_chan_consts *k = reinterpret_cast<const ssdr_chan_consts *>(static_cast<const char *>(blob) + sizeof h);
-        for (uint32_t i = 0; i < c->n_ch; i++) {
-            const uint32_t kd = k[i].decim > 1 ? k[i].decim : 1;
-            if (k[i].mode > SSDR_MODE_IQ || k[i].ntap > SSDR_NTAP_MAX || k[i].ntap8 > SSDR_NTAP_MAX || (k[i].ntap8 & 7u) ||
-                k[i].ntap8 * kd > SSDR_NTAP_MAX || kd != h.decim || k[i].hang_frames > 8 ||
-                (h.decim > 1 && (k[i].fir_flags & SSDR_FIR_DELAY4)))
-                return SSDR_EINVAL;
-        }
-    }
-    if (!c->feed.empty()) return SSDR_ESTATE;
+    const size_t n = c->n_ch;
+    const char *params_at = static_cast<const char *>(blob) + sizeof h + n * (sizeof(ssdr_chan_consts) + SSDR_NTAP_MAX * sizeof(float) +
+                            sizeof(ssdr_chan_state) + SSDR_HIST * 4 + SSDR_NFFT * 2 + 8 * sizeof(double) + (SSDR_NFFT / 2) * 4);
+    // what the kernels run on is compiled HERE from the saved parameters (at the blob's decimation and rate): a damaged or foreign
+    // parameter set is refused by the compiler before anything is touched
+    std::vector<ssdr_chan_params> prm(n);
+    memcpy(prm.data(), params_at, n * sizeof(ssdr_chan_params));
+    std::vector<ssdr_chan_consts> kc(n);
+    std::vector<float> ktaps(n * SSDR_NTAP_MAX);
+    for (size_t i = 0; i < n; i++)
+        if (ssdr_compile_params_host(&prm[i], &kc[i], ktaps.data() + i * SSDR_NTAP_MAX, h.decim, h.kiwi_rate) != SSDR_OK) return SSDR_EINVAL;
+    if (!c->feed.empty() || c->zoom > 1) return SSDR_ESTATE;
     HIP_TRY(hipSetDevice(c->device));
     { int rch = ssdr_set_hop(c, h.hop); if (rch != SSDR_OK) return rch; }
     { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
-    const size_t n = c->n_ch;
     const char *p = static_cast<const char *>(blob) + sizeof h;
     const hipMemcpyKind h2d = hipMemcpyHostToDevice;
-    memcpy(c->h_consts.data(), p, n * sizeof(ssdr_chan_consts));
-    HIP_TRY(hipMemcpyAsync(c->d_consts, p, n * sizeof(ssdr_chan_consts), h2d, c->stream)); p += n * sizeof(ssdr_chan_consts);
-    HIP_TRY(hipMemcpyAsync(c->d_taps, p, n * SSDR_NTAP_MAX * sizeof(float), h2d, c->stream)); p += n * SSDR_NTAP_MAX * sizeof(float);
+    memcpy(c->h_consts.data(), kc.data(), n * sizeof(ssdr_chan_consts));
+    HIP_TRY(hipMemcpyAsync(c->d_consts, kc.data(), n * sizeof(ssdr_chan_consts), h2d, c->stream)); p += n * sizeof(ssdr_chan_consts);
+    HIP_TRY(hipMemcpyAsync(c->d_taps, ktaps.data(), n * SSDR_NTAP_MAX * sizeof(float), h2d, c->stream)); p += n * SSDR_NTAP_MAX * sizeof(float);
     HIP_TRY(hipMemcpyAsync(c->d_state, p, n * sizeof(ssdr_chan_state), h2d, c->stream)); p += n * sizeof(ssdr_chan_state);
     HIP_TRY(hipMemcpyAsync(c->d_hist, p, n * SSDR_HIST * 4, h2d, c->stream)); p += n * SSDR_HIST * 4;
     HIP_TRY(hipMemcpyAsync(c->d_wf_acc[c->wf_acc_cur], p, n * SSDR_NFFT * 2, h2d, c->stream)); p += n * SSDR_NFFT * 2;

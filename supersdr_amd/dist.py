@@ -1,9 +1,11 @@
 """Multi-GPU harness: channel-block sharding and the timing rendezvous.
 
 The path has no exchange step (channels are independent), so there is NO
-data-path collective: torch.distributed (backend "nccl" == RCCL on the GPU box, "gloo" in the
-CPU tests) is used only for the barrier around the timed region and the max-over-ranks of the
-wall time.  One process per GPU, launched by torch.distributed.run.
+data-path collective: torch.distributed is used only for the barrier around the timed region,
+the max-over-ranks of the wall time and the parity-hash gather -- a few scalars.  The default
+backend is "gloo" (TCP on the loopback, what SURVEY.md 8e's "the parent gathers over pipes" amounts
+to under torch.distributed.run); "nccl" (= RCCL) is opt-in (bench.py --rendezvous nccl) and falls
+back to gloo, loudly, if it cannot come up.  One process per GPU, launched by torch.distributed.run.
 """
 import os
 
@@ -25,7 +27,7 @@ def channel_block(rank, world, total_channels):
 class Rendezvous:
     """barrier() and max_over_ranks() for the bench; a no-op world of one needs no process group."""
 
-    def __init__(self, backend="nccl", device=None):
+    def __init__(self, backend="gloo", device=None):
         self.rank, self.local_rank, self.world = env_rank()
         self.backend = backend
         self.device = device

@@ -829,6 +829,8 @@ class WaterfallSeams:
     # ---- the true frequency axis of the GPU waterfall
     def set_iq_zoom_center(self, khz):
         """centre of this channel's zoomed waterfall (hub built with zoom > 1), an absolute frequency inside its IQ band"""
+        if getattr(self.hub, "zoom", 1) == 1:        # no zoom stage runs: the lines stay centred on iq_center_khz, and so must the axis
+            raise ValueError("set_iq_zoom_center needs a hub built with zoom > 1")
         self.hub.set_wf_center(self.channel, (float(khz) - self.iq_center_khz) * 1000.0)
         self.iq_zoom_center_khz = float(khz)
 

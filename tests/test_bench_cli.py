@@ -99,3 +99,33 @@ def test_spawned_ranks_are_confined_to_their_gpu():
         os.environ.update(env0)
     assert [e["HIP_VISIBLE_DEVICES"] for e in seen] == ["0", "1", "2"] and all(e["SSDR_BENCH_DEVICE"] == "0" for e in seen)
     assert [e["RANK"] for e in seen] == ["0", "1", "2"] and all(e["WORLD_SIZE"] == "3" for e in seen)
+    # a mask the user set already is honoured: rank r takes the r-th PERMITTED device
+    del seen[:]
+    subprocess.Popen = P
+    os.environ["HIP_VISIBLE_DEVICES"] = "4,5, 6,7"
+    try:
+        b.spawn_ranks(3, ["--gpus", "3"])
+        import pytest
+        with pytest.raises(SystemExit):
+            b.spawn_ranks(5, ["--gpus", "5"])
+    finally:
+        subprocess.Popen = real_popen
+        os.environ.clear()
+        os.environ.update(env0)
+    assert [e["HIP_VISIBLE_DEVICES"] for e in seen[:3]] == ["4", "5", "6"]
+
+
+def test_eight_ranks_meet_over_gloo_shard_a_million_channels_and_close_the_parity_ring():
+    """the driver's N = 8 shape on the CPU: eight ranks (started by the launcher the driver uses), the default rendezvous
+    (gloo: no RCCL anywhere on this path), 2^20 channels in eight blocks of 131 072, the parity ring r -> r + 1 -> ... -> 0"""
+    port = 29500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "8", "--dry-run", "--workload", "million"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = last_json(p)
+    assert d["n_gpus"] == 8 and d["channels_total"] == 1 << 20 and d["config"]["channels_per_gpu"] == 131072
+    assert d["config"]["rendezvous"] == "gloo" and d["parity"]["ranks_agree"]
+    assert d["parity"]["first_channel_ids"] == [r * 131072 for r in range(8)] and len({tuple(c) for c in d["parity"]["checksums"]}) == 8
+    assert abs(d["max_wall"] - 8e-3) < 1e-9

@@ -6,14 +6,22 @@ channel filter takes 40+ dB down (out-of-band carrier, narrow passband) is only 
 discriminator turns that straight into phase.  Rule:
   * a channel is WELL CONDITIONED when its filtered power (the oracle's RSSI) stays within 40 dB of its input power in
     every frame;
-  * every well-conditioned channel -- all of them, no best-of selection -- must meet 1e-5 RMS of full scale after its
-    0.5 % largest sample deviations are set aside (the instants where a filtered transient crosses zero);
+  * every well-conditioned channel -- all of them, no best-of selection -- must meet 1e-5 RMS of full scale UNTRIMMED
+    (every sample counted); the one exception is stated: an NBFM channel may reach 5e-5 untrimmed, and must then meet
+    1e-5 once its 0.5 % largest sample deviations are set aside -- the discriminator takes the phase of samples whose
+    filtered magnitude passes through zero (a burst at the rails, a deep AM trough), where 1e-7 relative in I and Q is
+    radians in the output; measured: one such channel in five sweeps, 1.8e-5 with a largest deviation of 25 LSB;
+  * at least three quarters of a sweep's channels must be well conditioned (the draw of tests/random_params.py gives 75-96 %);
   * every channel, conditioned or not, must stay within 1e-3 RMS.
+The untrimmed figures are reported (REPORT, printed with pytest -s) next to the trimmed ones.
 """
 import numpy as np
 
 PCM_RMS_TOL = 1e-5
+NBFM_UNTRIMMED_TOL = 5e-5
 LOOSE_TOL = 1e-3
+MIN_WELL_FRACTION = 0.75
+REPORT = []                     # one dict per sweep: what was measured, trimmed and untrimmed
 
 
 def well_conditioned(iq, rssi_o, smeter_cal_db):
@@ -23,14 +31,25 @@ def well_conditioned(iq, rssi_o, smeter_cal_db):
     return (rssi_o > in_db[:, None] - 40).all(axis=1)
 
 
-def assert_pcm_within_tolerance(pcm, pcm_o, iq, rssi_o, smeter_cal_db, min_well=None):
+def assert_pcm_within_tolerance(pcm, pcm_o, iq, rssi_o, smeter_cal_db, modes=None, min_well=None, what=""):
+    """modes: the channels' mode names (the NBFM exception applies to "nbfm" only; None: to nobody).  min_well: channels that
+    must be well conditioned (default: MIN_WELL_FRACTION of them)."""
     pcm = np.asarray(pcm, np.float64)
+    n_ch = pcm.shape[0]
     well = well_conditioned(iq, rssi_o, smeter_cal_db)
-    if min_well is not None:
-        assert well.sum() >= min_well, (int(well.sum()), min_well)
+    need = int(np.ceil(MIN_WELL_FRACTION * n_ch)) if min_well is None else int(min_well)
+    assert well.sum() >= need, (int(well.sum()), need, n_ch)
     rms = np.sqrt(((pcm - pcm_o) ** 2).mean(axis=1)) / 32768.0
     dev = np.sort(np.abs(pcm - pcm_o), axis=1)[:, : int(pcm_o.shape[1] * 0.995)]
     rms_trim = np.sqrt((dev ** 2).mean(axis=1)) / 32768.0
+    fm = np.array([m == "nbfm" for m in modes], bool) if modes is not None else np.zeros(n_ch, bool)
+    REPORT.append({"what": what, "channels": n_ch, "well_conditioned": int(well.sum()),
+                   "untrimmed_max_well": float(rms[well].max(initial=0.0)), "untrimmed_max_well_not_nbfm": float(rms[well & ~fm].max(initial=0.0)),
+                   "trimmed_max_well": float(rms_trim[well].max(initial=0.0)), "untrimmed_max_all": float(rms.max())})
+    print("pcm vs float64 oracle %s: %d/%d well conditioned; untrimmed RMS max %.2e (NBFM excluded %.2e), trimmed %.2e; all channels %.2e"
+          % (what, well.sum(), n_ch, rms[well].max(initial=0.0), rms[well & ~fm].max(initial=0.0), rms_trim[well].max(initial=0.0), rms.max()))
+    assert rms[well & ~fm].max(initial=0.0) < PCM_RMS_TOL, (int(np.argmax(rms * (well & ~fm))), float((rms * (well & ~fm)).max()))
+    assert rms[well & fm].max(initial=0.0) < NBFM_UNTRIMMED_TOL, (int(np.argmax(rms * (well & fm))), float((rms * (well & fm)).max()))
     assert rms_trim[well].max(initial=0.0) < PCM_RMS_TOL, (int(np.argmax(rms_trim * well)), float((rms_trim * well).max()))
     assert rms.max() < LOOSE_TOL, (int(np.argmax(rms)), float(rms.max()))
     return well, rms_trim
