@@ -835,7 +835,7 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
         else HIP_TRY(ssdr_launch_wf(a, grid ? grid : 1, c->stream));
         if ((rc = timed_end(c, SSDR_K_WF)) != SSDR_OK) return rc;
     }
-    if (hop512)                  // the batch's last half-line is the next batch's first: [n_ch] rows of 2 KB out of the input
+    if (hop512 && !c->fuse_next) // the batch's last half-line is the next batch's first: [n_ch] rows of 2 KB out of the input
         HIP_TRY(hipMemcpy2DAsync(c->d_wf_tail, (SSDR_NFFT / 2) * 4, wf_src + (size_t)(halves - 1) * SSDR_FRAME,
                                  wf_stride * 4, (SSDR_NFFT / 2) * 4, c->n_ch, hipMemcpyDeviceToDevice, c->stream));
     c->wf_phase = total % c->n_avg;
@@ -935,6 +935,9 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         if ((rc = timed_begin(c, s)) != SSDR_OK) return rc;
         HIP_TRY(ssdr_launch_fused_am(fa, grid ? grid : 1, s));
         if ((rc = timed_end(c, SSDR_K_FUSED, s)) != SSDR_OK) return rc;
+        if (fa.wf.tail)          // hop 512: only now may the carried half-line (the kernel's line 0 read it) become this batch's last one
+            HIP_TRY(hipMemcpy2DAsync(c->d_wf_tail, (SSDR_NFFT / 2) * 4, fa.wf.iq + (size_t)(fa.wf.n_lines - 1) * SSDR_FRAME,
+                                     fa.wf.ch_stride * 4, (SSDR_NFFT / 2) * 4, c->n_ch, hipMemcpyDeviceToDevice, s));
         return SSDR_OK;
     }
     // one kernel per non-empty path: the first on the stream itself, the others beside it on their own streams
@@ -987,9 +990,11 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
     if (!c->have_input) return SSDR_ESTATE;
     chan_summary(c);
     const uint32_t n_am = c->sum_paths[SSDR_PATH_AM_RAW];
-    // the fused kernel covers the metric's configuration: every channel on the full-band AM path, N = 1, hop 1024, 12 kHz IQ;
-    // from four lines per call on (a wave sets a channel pair's carried state up once per call: measured ahead from there)
-    const bool eligible = n_am == c->n_ch && c->n_avg == 1 && c->hop == SSDR_NFFT && c->decim == 1 && !(c->in_frames & 1u) &&
+    // the fused kernel covers the metric's configuration: every channel on the full-band AM path, N = 1, 12 kHz IQ, either line
+    // rate (hop 1024, or hop 512 = the reference's 23 lines/s); from eight frames per call on (a wave sets a channel pair's
+    // carried state up once per call: measured ahead from there)
+    const bool hop512 = c->hop == SSDR_NFFT / 2;            // (one line per frame: any frame count; hop 1024 needs whole lines)
+    const bool eligible = n_am == c->n_ch && c->n_avg == 1 && c->decim == 1 && (hop512 || !(c->in_frames & 1u)) &&
                           c->in_frames >= 8 &&
                           !c->concurrent && c->fused_grid != 0 && c->fused_enabled && !c->exact_bins && c->zoom == 1;
     if (fused) *fused = eligible ? 1 : 0;

@@ -547,6 +547,10 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
 // x 8 consecutive samples per frame read back from LDS, i.e. exactly the stand-alone kernel's layout and code (bit-identical
 // results, the same scan orders); then the FFT proceeds on the raw samples it still holds.  The vector ALU work is the
 // sum of the two kernels'; what is saved is the second read of the input.
+// HOP (round 4): the waterfall at the reference's line rate (hop 512, utils_supersdr.py:597, 742).  A step is then one half-line:
+// the 512 new samples of each channel are its next audio frame, and the line is the previous half (re-read -- the wave fetched
+// it one step earlier, and only that read is left to the L2: plain load, everything else streams) followed by the new one.
+template <bool HOP>
 __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fused_am_kernel(SsdrFusedArgs fa)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];
@@ -593,7 +597,9 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
 
         const uint32_t *src = a.iq + (uint64_t)ch * a.ch_stride + l;
         uint32_t last_raw31 = 0;
-        for (uint32_t line = 0; line < a.n_lines; line++, src += SSDR_NFFT) {
+        constexpr uint32_t LINE_STEP = HOP ? SSDR_NFFT / 2 : SSDR_NFFT;
+        constexpr int FRAMES_PER_LINE = HOP ? 1 : 2;
+        for (uint32_t line = 0; line < a.n_lines; line++, src += LINE_STEP) {
             // ---- the carried state out of its resting place (the powers below overwrite it)
             float dc[2], agc_d[2], agc_m[2][8];
             uint32_t tail_q[2][4];
@@ -613,7 +619,8 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
             {
                 uint32_t *q = qbuf + opaque(h) * XCH_FLOATS + opaque(l);
                 uint32_t t[32];                     // all 32 loads in flight, then the stores: left alone the compiler issues
-                load_line(src, t);                  // load, wait, store one sample at a time -- 32 round trips to memory per line
+                if (HOP) load_line_halves(line ? src - SSDR_NFFT / 2 : a.tail + (uint64_t)ch * (SSDR_NFFT / 2) + l, src, t);
+                else load_line(src, t);             // load, wait, store one sample at a time -- 32 round trips to memory per line
                 SCHED_FENCE();
 #pragma unroll
                 for (int r = 0; r < 32; r++) q[32 * r] = t[r];
@@ -631,9 +638,9 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                 const AgcK agc_c = {kc.agc_c0, kc.agc_c1, kc.agc_knee, kc.agc_delta8, kc.hang_frames};
                 const float cal_c = kc.smeter_cal_db;
 #pragma unroll
-                for (int f = 0; f < 2; f++) {
-                    const uint32_t frame = 2 * line + f;
-                    const u32x4 *qp = reinterpret_cast<const u32x4 *>(qbuf + c * XCH_FLOATS + SSDR_FRAME * f) + 2 * opaque(lane);
+                for (int f = 0; f < FRAMES_PER_LINE; f++) {
+                    const uint32_t frame = HOP ? line : 2 * line + f;               // hop 512: the new half of the line is the step's frame
+                    const u32x4 *qp = reinterpret_cast<const u32x4 *>(qbuf + c * XCH_FLOATS + SSDR_FRAME * (HOP ? 1 : f)) + 2 * opaque(lane);
                     const u32x4 q0 = qp[0], q1 = qp[1];
                     const uint32_t rw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
                     uint32_t qv[8], d[8];
@@ -792,13 +799,18 @@ hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream
 
 hipError_t ssdr_launch_fused_am(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream)
 {
-    hipLaunchKernelGGL(ssdr_fused_am_kernel, dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
+    if (a.wf.tail) hipLaunchKernelGGL(ssdr_fused_am_kernel<true>, dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
+    else hipLaunchKernelGGL(ssdr_fused_am_kernel<false>, dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
     return hipGetLastError();
 }
 
 hipError_t ssdr_fused_blocks_per_cu(int *blocks)
 {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks, ssdr_fused_am_kernel, SSDR_WF_BLOCK, 0);
+    int b0 = 0, b1 = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, ssdr_fused_am_kernel<false>, SSDR_WF_BLOCK, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, ssdr_fused_am_kernel<true>, SSDR_WF_BLOCK, 0);
+    *blocks = b0 < b1 ? b0 : b1;
+    return e;
 }
 
 // workgroups of the waterfall kernel that are resident per CU (min over both instances)

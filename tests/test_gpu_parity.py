@@ -1149,6 +1149,49 @@ def test_fused_superframe_kernel_equals_the_two_kernels(S, twin, n_ch):
         assert eng.run_chain() == (0, False)
 
 
+@pytest.mark.parametrize("n_ch", [1, 7, 300])
+def test_fused_kernel_at_hop_512_equals_the_two_kernels(S, twin, n_ch):
+    """Round 4: ssdr_run_chain's one-read kernel at the reference's waterfall line rate (hop 512: a line per audio frame, the
+    previous half-line re-read).  Waterfall lines, PCM, RSSI, flags, carried state, FIR history and the carried half-line are
+    bit-identical to the two kernels and to the twin over several calls -- odd frame counts, the half-line crossing calls
+    and crossing between the two ways, a clipping sample."""
+    rng = np.random.default_rng(40 + n_ch)
+    calls = [3, 9, 131] if n_ch <= 7 else [5, 8, 11]
+    n_frames = sum(calls)
+    iq = O.synth_iq(n_ch, n_frames * 512, seed=900 + n_ch)
+    iq[0, 4 * 512 + 17, 0] = 32767
+    ps = [S.default_params("am", f_shift_hz=float(rng.integers(-5900, 5900)), agc_hang=int(c % 2),
+                           agc_decay=float(rng.choice([400.0, 4000.0])), wf_cal_db=float(rng.integers(-6, 7))) for c in range(n_ch)]
+    outs = {}
+    for fused in (False, True):
+        with S.SsdrEngine(n_ch) as eng:
+            eng.set_hop(512)
+            eng.set_params(0, ps)
+            eng.set_fused(fused)
+            wfs, pcms, rssis, flags, pos = [], [], [], [], 0
+            for nf in calls:
+                eng.push_iq(iq[:, pos * 512:(pos + nf) * 512])
+                lines, was_fused = eng.run_chain()
+                assert was_fused == (fused and nf >= 8) and lines == nf
+                wfs.append(eng.fetch_wf(lines))
+                p, r = eng.fetch_audio()
+                pcms.append(p)
+                rssis.append(r)
+                flags.append(eng.audio_flags())
+                pos += nf
+            consts, taps = eng.get_consts()
+            st, hist = eng.get_state()
+        outs[fused] = (np.concatenate(wfs), np.concatenate(pcms, axis=1), np.concatenate(rssis, axis=1),
+                       np.concatenate(flags, axis=1), st.tobytes(), hist)
+    for a, b in zip(outs[False], outs[True]):
+        assert (a == b) if isinstance(a, bytes) else np.array_equal(a, b)
+    st, hist = twinlib.fresh_state(consts)
+    pcm_t, rssi_t, flags_t = twin.audio(iq, consts, taps, st, hist, want_flags=True)
+    assert np.array_equal(outs[True][1], pcm_t) and np.array_equal(outs[True][2], rssi_t) and np.array_equal(outs[True][3], flags_t)
+    stream = np.concatenate([np.zeros((n_ch, 512, 2), np.int16), iq], axis=1)
+    assert np.array_equal(outs[True][0], twin.wf_hop(stream, 512, 1, consts["wf_cal_lin"])) and outs[True][3].sum() == 1
+
+
 # ------------------------------------------------------------------ round 3
 def test_set_concurrent_bits_are_bit_identical_to_the_default(S):
     """ssdr_set_concurrent: bit 0 (audio stage on a second stream beside the waterfall kernel, which then takes
