@@ -41,9 +41,9 @@ typedef double f64x2 __attribute__((ext_vector_type(2)));
 constexpr int WAVES = SSDR_WFX_BLOCK / 64;
 constexpr int XROW = 65;                                     // row stride of the transpose buffer, doubles
 constexpr int XCH_BYTES = 16 * XROW * 8;                     // 8320 per wave
-// LDS map: window (513 floats), quantiser words, twiddle tables (double2), per-wave transpose buffers
-constexpr int LDS_WIN = 0;
-constexpr int LDS_LUT0 = 2064;
+// LDS map: window (513 doubles), quantiser words, twiddle tables (double2), per-wave transpose buffers
+constexpr int LDS_WIN = 0;                                   // 513 doubles: float32 window table x 2^-16 (exact)
+constexpr int LDS_LUT0 = 4112;
 constexpr int LDS_LUT_END = LDS_LUT0 + SSDR_LUT_N * 4;
 constexpr int LDS_TW = (LDS_LUT_END + 15) & ~15;
 constexpr int LDS_XCH = LDS_TW + SSDR_TW64_N * 16;
@@ -161,29 +161,30 @@ XDEV uint32_t quant_addr(float pc) { return (__float_as_uint(pc) >> (SSDR_LUT_SH
 XDEV uint32_t quant_pair(uint32_t w0, uint32_t w1) { return __builtin_amdgcn_perm(w1, w0, 0x0C070C03u); }
 
 // |X|^2 cal in double -> the largest float32 not above it, scaled by 2^-48 and clamped to [0, 1]
-XDEV float scaled_power_trunc(cd x, double cal)
+// (cal arrives times 2^-48, an exact scaling: the product is the table's argument already; the clamp to [0, 1] rides on the conversion)
+XDEV float scaled_power_trunc(cd x, double cal_scaled)
 {
-    const double p = fma(x.r, x.r, x.i * x.i) * cal;
+    const double p = fma(x.r, x.r, x.i * x.i) * cal_scaled;
     const long long bits = __double_as_longlong(p) & ~0x1FFFFFFFll;       // 23 mantissa bits stay: the conversion below is exact
-    const float pf = (float)__longlong_as_double(bits);
+    const double pt = __longlong_as_double(bits);
     float pc;
-    asm("v_mul_f32_e64 %0, %1, %2 clamp" : "=v"(pc) : "v"(pf), "v"(SSDR_LUT_SCALE));
+    asm("v_cvt_f32_f64_e64 %0, %1 clamp" : "=v"(pc) : "v"(pt));
     return pc;
 }
 
-XDEV double dbl_i16lo(uint32_t raw) { return (double)(int)(int16_t)(raw & 0xFFFFu); }
-XDEV double dbl_i16hi(uint32_t raw) { return (double)((int32_t)raw >> 16); }
+XDEV double dbl_i16lo(uint32_t raw) { return (double)(int32_t)(raw << 16); }            // I * 2^16
+XDEV double dbl_i16hi(uint32_t raw) { return (double)(int32_t)(raw & 0xFFFF0000u); }    // Q * 2^16
 
 // AVG: averaging N > 1 (accumulators); HOP: lines overlap by half (hop 512)
-template <bool AVG, bool HOP>
+template <bool AVG, bool HOP, bool PF = false>
 __global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_wf_exact_kernel(SsdrWfArgs a, const double2 *tw_g)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];
     {
-        float *s_win = reinterpret_cast<float *>(smem + LDS_WIN);
+        double *s_win = reinterpret_cast<double *>(smem + LDS_WIN);
         uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + LDS_LUT0);
         f64x2 *s_tw = reinterpret_cast<f64x2 *>(smem + LDS_TW);
-        for (int i = threadIdx.x; i < 513; i += blockDim.x) s_win[i] = a.win[i];
+        for (int i = threadIdx.x; i < 513; i += blockDim.x) s_win[i] = (double)a.win[i] * 0x1p-16;       // (the samples arrive times 2^16)
         for (int i = threadIdx.x; i < SSDR_LUT_N; i += blockDim.x) s_lut[i] = a.lut[i];
         for (int i = threadIdx.x; i < SSDR_TW64_N; i += blockDim.x) s_tw[i] = f64x2{tw_g[i].x, tw_g[i].y};
         __syncthreads();
@@ -196,17 +197,53 @@ __global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_wf
     const uint32_t n_items = a.n_ch * n_runs;
     const uint32_t wave_stride = gridDim.x * WAVES;
 
+    constexpr uint32_t LINE_STEP = HOP ? SSDR_NFFT / 2 : SSDR_NFFT;
+    // work items: hop 1024 -- one (group, channel) each, group-major; hop 512 -- a run of consecutive groups of one channel
+    auto decode = [&](uint32_t it, uint32_t &ch_, uint32_t &gb, uint32_t &ge) {
+        if (HOP) {
+            ch_ = it / n_runs;
+            gb = (it - ch_ * n_runs) * run;
+            ge = min(gb + run, a.n_groups);
+        } else {
+            gb = it / a.n_ch;
+            ch_ = it - gb * a.n_ch;
+            ge = gb + 1;
+        }
+    };
+    auto first_line = [&](uint32_t grp_) -> uint32_t {
+        const int64_t g0_ = (int64_t)grp_ * a.n_avg - a.phase;
+        return g0_ < 0 ? 0u : (uint32_t)g0_;
+    };
+    // lane L fetches samples 64 q + L of line `ln` of channel `ch_` (hop 512: the older half, then the new one)
+    auto load_raw = [&](uint32_t ch_, uint32_t ln, uint32_t (&raw_)[16]) {
+        const uint32_t *src_ = a.iq + (uint64_t)ch_ * a.ch_stride + (uint64_t)ln * LINE_STEP + lane;
+        if (HOP) {
+            const uint32_t *older = ln ? src_ - SSDR_NFFT / 2 : a.tail + (uint64_t)ch_ * (SSDR_NFFT / 2) + lane;
+#pragma unroll
+            for (int q = 0; q < 8; q++) raw_[q] = __builtin_nontemporal_load(older + 64 * q);
+#pragma unroll
+            for (int q = 0; q < 8; q++) raw_[8 + q] = src_[64 * q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; q++) raw_[q] = __builtin_nontemporal_load(src_ + 64 * q);
+        }
+    };
+    // PF (A/B only, off): the samples of the NEXT line requested as soon as the window stage has consumed this line's.  Measured
+    // no gain (2.36 ms either way, profiles/r04_ab_wf_exact.txt): the kernel is bound by its ~940 VALU instructions per line
+    // (87 % of the issue slots busy), not by the memory round trip in front of each FFT -- and the second register set costs 32 moves
+    uint32_t raw[16];
+    if (PF) {
+        const uint32_t it0 = blockIdx.x * WAVES + wave;
+        if (it0 < n_items) {
+            uint32_t c0, gb0, ge0;
+            decode(it0, c0, gb0, ge0);
+            load_raw(c0, first_line(gb0), raw);
+        }
+    }
+
     for (uint32_t item = blockIdx.x * WAVES + wave; item < n_items; item += wave_stride) {
         uint32_t ch, g_begin, g_end;
-        if (HOP) {                                   // a run of consecutive groups of one channel: the wave walks its lines in order
-            ch = item / n_runs;
-            g_begin = (item - ch * n_runs) * run;
-            g_end = min(g_begin + run, a.n_groups);
-        } else {                                     // group-major
-            g_begin = item / a.n_ch;
-            ch = item - g_begin * a.n_ch;
-            g_end = g_begin + 1;
-        }
+        decode(item, ch, g_begin, g_end);
         for (uint32_t grp = g_begin; grp < g_end; grp++) {
             uint32_t ch_now = __builtin_amdgcn_readfirstlane(ch);
             asm volatile("" : "+s"(ch_now));
@@ -215,40 +252,29 @@ __global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_wf
             const uint32_t l1 = min((uint32_t)(g0 + a.n_avg), a.n_lines);
             const bool carry_in = (grp == 0) && (a.phase != 0);
             const bool complete = (g0 + (int64_t)a.n_avg) <= (int64_t)a.n_lines;
-            const double cal = (double)a.consts[ch_now].wf_cal_lin;
+            const double cal = (double)a.consts[ch_now].wf_cal_lin * (double)SSDR_LUT_SCALE;
             uint32_t acc[AVG ? 8 : 1];
 #pragma unroll
             for (int j = 0; j < (AVG ? 8 : 1); j++) acc[j] = 0;
-            constexpr uint32_t LINE_STEP = HOP ? SSDR_NFFT / 2 : SSDR_NFFT;
-            const uint32_t *src = a.iq + (uint64_t)ch_now * a.ch_stride + (uint64_t)l0 * LINE_STEP + lane;
-
-            for (uint32_t line = l0; line < l1; line++, src += LINE_STEP) {
+            for (uint32_t line = l0; line < l1; line++) {
                 // ---- the line: lane L holds samples 64 q + L
-                uint32_t raw[16];
-                if (HOP) {
-                    const uint32_t *older = line ? src - SSDR_NFFT / 2 : a.tail + (uint64_t)ch_now * (SSDR_NFFT / 2) + lane;
-#pragma unroll
-                    for (int q = 0; q < 8; q++) raw[q] = __builtin_nontemporal_load(older + 64 * q);
-#pragma unroll
-                    for (int q = 0; q < 8; q++) raw[8 + q] = src[64 * q];
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 16; q++) raw[q] = __builtin_nontemporal_load(src + 64 * q);
-                }
+                if (!PF) load_raw(ch_now, line, raw);
                 // ---- window (float32 table, products exact in double) with stage 1 folded in: sample n = 64 q + L pairs with
                 //      n + 512; w[n + 512] = w[512 - n] (symmetric table of 513)
                 cd z[16];
                 {
                     const int ll = opaque(lane);
-                    const float *win_up = reinterpret_cast<const float *>(smem + LDS_WIN) + ll;
-                    const float *win_dn = reinterpret_cast<const float *>(smem + LDS_WIN) + 512 - ll;
-                    float wu[8], wd[8];
+                    const double *win_up = reinterpret_cast<const double *>(smem + LDS_WIN) + ll;
+                    const double *win_dn = reinterpret_cast<const double *>(smem + LDS_WIN) + 512 - ll;
+                    double wu[8], wd[8];
 #pragma unroll
                     for (int q = 0; q < 8; q++) { wu[q] = win_up[64 * q]; wd[q] = win_dn[-64 * q]; }
                     XFENCE();
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
-                        const double w0 = (double)wu[q], w1 = (double)wd[q];
+                        // I and Q converted where they sit in the dword, i.e. times 2^16 (one shift / one mask instead of a sign
+                        // extension each); the window table carries the 2^-16: the products are the same doubles
+                        const double w0 = wu[q], w1 = wd[q];
                         const double xr = dbl_i16lo(raw[q]), xi = dbl_i16hi(raw[q]);
                         const double yr = dbl_i16lo(raw[q + 8]), yi = dbl_i16hi(raw[q + 8]);
                         const double tr = xr * w0, ti = xi * w0;
@@ -257,6 +283,20 @@ __global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_wf
                     }
                 }
                 XFENCE();
+                if (PF) {                            // where the wave goes next (all of it scalar): the next line of this group, the first
+                    uint32_t n_ch_ = ch_now, n_ln = line + 1;       // line of the next group of the run, or of the next work item
+                    bool more = true;
+                    if (n_ln >= l1) {
+                        if (grp + 1 < g_end) n_ln = first_line(grp + 1);
+                        else if (item + wave_stride < n_items) {
+                            uint32_t gb, ge;
+                            decode(item + wave_stride, n_ch_, gb, ge);
+                            n_ln = first_line(gb);
+                        } else more = false;
+                    }
+                    if (more) load_raw(n_ch_, n_ln, raw);
+                    XFENCE();
+                }
                 stage_const<2>(z);
                 stage_const<3>(z);
                 stage_const<4>(z);
