@@ -193,6 +193,17 @@ typedef struct ssdr_db2col_chan {
     float wf_min_db, wf_max_db;                         /* out (:807-808)                            */
     uint32_t pad[3];
 } ssdr_db2col_chan;
+/* The reference's post-processing is per viewer (one kiwi_waterfall / kiwi_sound per receiver somebody looks at or listens to); a ctx
+ * of 10^5 channels has a handful.  ssdr_set_post_channels names the channels the post-processing entry points work on from
+ * now on -- `channels` ascending and unique, `count` of them; (NULL, 0): every channel again, the default.  With a selection
+ * set, every per-channel array of ssdr_run_db2col, ssdr_run_playbuffer, ssdr_playbuffer_mono, ssdr_feed_post,
+ * ssdr_feed_collect_post, ssdr_run_trace, ssdr_push_color_lines and ssdr_wfdata_white_flag has `count` entries in the
+ * order of the list (display state in, colours / 48 kHz blocks / traces out); cost and transfers scale with the listeners,
+ * not with the ctx.  play_buffer's carried history stays per channel (a channel that leaves and re-enters the selection
+ * continues where it was).  The device copy of wf_data (ssdr_set_wfdata_rows) starts over.  count = 0 with a non-NULL list:
+ * nobody is looking -- the post-processing calls return at once.  Batches already submitted to the pipelined feed keep the
+ * selection they were submitted with (the caller remembers it for ssdr_feed_collect_post). */
+int ssdr_set_post_channels(ssdr_ctx *ctx, const uint32_t *channels, uint32_t count);
 /* spectrum_db2col for every channel and every line produced by the last ssdr_run_wf:
  * color_out float32 [lines][n_ch][1024] in 0..254 (wf_color), chans[] updated in place (host memory). */
 int ssdr_run_db2col(ssdr_ctx *ctx, ssdr_db2col_chan *chans, float *color_out, int out_is_device);

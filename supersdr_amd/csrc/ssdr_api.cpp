@@ -3,6 +3,7 @@
 // Never throws, never aborts: every failure is a negative return code.
 #include "ssdr_kernels.h"
 #include "ssdr_resample_taps.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -109,6 +110,7 @@ struct ssdr_ctx {
         ssdr_play_chan *h_playchan = nullptr;
         int16_t *d_play = nullptr, *h_play = nullptr, *d_mono = nullptr, *h_mono = nullptr;
         bool has_mono = false;
+        uint32_t n_post = 0;                             // channels the batch was post-processed for (ssdr_set_post_channels at submit)
     };
     std::vector<FeedSlot> feed;
     uint32_t feed_frames = 0, feed_head = 0, feed_tail = 0, feed_inflight = 0;
@@ -134,6 +136,8 @@ struct ssdr_ctx {
     uint32_t wf_grid = 0, wf_grid_1 = 0;
     unsigned long long *d_scratch = nullptr;
     // post-processing
+    uint32_t *d_post_sel = nullptr;         // ssdr_set_post_channels: the channels the post kernels work on (null: all)
+    uint32_t n_post = 0;                    // their number (n_ch when no selection is set)
     ssdr_db2col_chan *d_db2col = nullptr;
     float *d_color = nullptr;
     size_t color_lines = 0;
@@ -237,7 +241,7 @@ void ssdr_destroy(ssdr_ctx *c)
     void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_wf_tail, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_flags, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
                     c->d_play_taps, c->d_play_hist, c->d_play_hist_alt, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
-                    c->d_smeter_in, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64, c->d_wire_gps, c->d_iq_out, c->d_zoom_taps, c->d_zoom_dphi, c->d_zoom_phase, c->d_zoom_hist, c->d_zoom_out};
+                    c->d_smeter_in, c->d_post_sel, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64, c->d_wire_gps, c->d_iq_out, c->d_zoom_taps, c->d_zoom_dphi, c->d_zoom_phase, c->d_zoom_hist, c->d_zoom_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -381,6 +385,7 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
     if (!c) return SSDR_ENOMEM;
     c->device = device_id;
     c->n_ch = n_channels;
+    c->n_post = n_channels;
     int rc = [&]() -> int {
         HIP_TRY(hipSetDevice(device_id));
         HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -1209,22 +1214,29 @@ static int feed_submit_impl(ssdr_ctx *c, const void *host_in)
     int rc = ssdr_run_chain(c, &lines, nullptr);           // the fused superframe kernel where the batch allows it
     if (rc == SSDR_OK && c->feed_post) rc = [&]() -> int {
         // spectrum_db2col of this batch's lines and play_buffer of its frames, on the slot's buffers, in batch order
+        s.n_post = c->n_post;
+        s.has_mono = false;
+        if (c->n_post == 0) return SSDR_OK;                  // ssdr_set_post_channels with an empty list: nobody is looking
         if (lines) {
-            memcpy(s.h_dbchan, c->feed_dbchan.data(), (size_t)c->n_ch * sizeof(ssdr_db2col_chan));
-            HIP_TRY(hipMemcpyAsync(s.d_dbchan, s.h_dbchan, (size_t)c->n_ch * sizeof(ssdr_db2col_chan), hipMemcpyHostToDevice, c->stream));
+            memcpy(s.h_dbchan, c->feed_dbchan.data(), (size_t)c->n_post * sizeof(ssdr_db2col_chan));
+            HIP_TRY(hipMemcpyAsync(s.d_dbchan, s.h_dbchan, (size_t)c->n_post * sizeof(ssdr_db2col_chan), hipMemcpyHostToDevice, c->stream));
             SsdrDb2colArgs d;
             d.wf = s.d_wf; d.n_ch = c->n_ch; d.n_lines = lines; d.n_avg = c->n_avg; d.chans = s.d_dbchan; d.color = s.d_color;
+            d.sel = c->d_post_sel; d.n_sel = c->n_post;
             int r2;
             if ((r2 = timed_begin(c)) != SSDR_OK) return r2;
             HIP_TRY(ssdr_launch_db2col(d, c->stream));
             if ((r2 = timed_end(c, SSDR_K_DB2COL)) != SSDR_OK) return r2;
             if (c->d_wfdata) { r2 = wfdata_feed(c, s.d_color, lines); if (r2 != SSDR_OK) return r2; }
         }
-        memcpy(s.h_playchan, c->feed_playchan.data(), (size_t)c->n_ch * sizeof(ssdr_play_chan));
-        HIP_TRY(hipMemcpyAsync(c->d_play, s.h_playchan, (size_t)c->n_ch * sizeof(ssdr_play_chan), hipMemcpyHostToDevice, c->stream));
+        memcpy(s.h_playchan, c->feed_playchan.data(), (size_t)c->n_post * sizeof(ssdr_play_chan));
+        HIP_TRY(hipMemcpyAsync(c->d_play, s.h_playchan, (size_t)c->n_post * sizeof(ssdr_play_chan), hipMemcpyHostToDevice, c->stream));
         SsdrPlayArgs pa;
         pa.pcm = s.d_pcm; pa.n_ch = c->n_ch; pa.n_frames = nf; pa.chans = c->d_play; pa.taps = c->d_play_taps; pa.hist = c->d_play_hist;
-        pa.hist_out = c->d_play_hist_alt;
+        pa.hist_out = c->d_play_hist_alt; pa.sel = c->d_post_sel; pa.n_sel = c->n_post;
+        s.n_post = c->n_post;
+        if (c->d_post_sel && c->kiwi_rate == SSDR_RATE)      // the channels outside the selection keep their history
+            HIP_TRY(hipMemcpyAsync(c->d_play_hist_alt, c->d_play_hist, (size_t)c->n_ch * 8 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         pa.out = s.d_play; pa.rs_taps = c->d_play_rs_taps; pa.mono = c->recording ? s.d_mono : nullptr;
         s.has_mono = c->recording;
         int r3;
@@ -1251,13 +1263,15 @@ static int feed_submit_impl(ssdr_ctx *c, const void *host_in)
     HIP_TRY(hipMemcpyAsync(s.h_flags, s.d_flags, (size_t)c->n_ch * nf, hipMemcpyDeviceToHost, c->feed_s_out));
     if (c->feed_post) {
         const size_t per_frame = c->kiwi_rate != SSDR_RATE ? (size_t)SSDR_RS_OUT_PER_FRAME : 2048;
-        if (lines) {
-            HIP_TRY(hipMemcpyAsync(s.h_color, s.d_color, (size_t)lines * c->n_ch * SSDR_NFFT * sizeof(float), hipMemcpyDeviceToHost, c->feed_s_out));
-            HIP_TRY(hipMemcpyAsync(s.h_dbchan, s.d_dbchan, (size_t)c->n_ch * sizeof(ssdr_db2col_chan), hipMemcpyDeviceToHost, c->feed_s_out));
+        if (lines && c->n_post) {
+            HIP_TRY(hipMemcpyAsync(s.h_color, s.d_color, (size_t)lines * c->n_post * SSDR_NFFT * sizeof(float), hipMemcpyDeviceToHost, c->feed_s_out));
+            HIP_TRY(hipMemcpyAsync(s.h_dbchan, s.d_dbchan, (size_t)c->n_post * sizeof(ssdr_db2col_chan), hipMemcpyDeviceToHost, c->feed_s_out));
         }
-        HIP_TRY(hipMemcpyAsync(s.h_play, s.d_play, (size_t)c->n_ch * nf * per_frame * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, c->feed_s_out));
-        if (s.has_mono)
-            HIP_TRY(hipMemcpyAsync(s.h_mono, s.d_mono, (size_t)c->n_ch * nf * per_frame * sizeof(int16_t), hipMemcpyDeviceToHost, c->feed_s_out));
+        if (c->n_post) {
+            HIP_TRY(hipMemcpyAsync(s.h_play, s.d_play, (size_t)c->n_post * nf * per_frame * 2 * sizeof(int16_t), hipMemcpyDeviceToHost, c->feed_s_out));
+            if (s.has_mono)
+                HIP_TRY(hipMemcpyAsync(s.h_mono, s.d_mono, (size_t)c->n_post * nf * per_frame * sizeof(int16_t), hipMemcpyDeviceToHost, c->feed_s_out));
+        }
     }
     HIP_TRY(hipEventRecord(s.ev_out, c->feed_s_out));
     c->feed_head = (c->feed_head + 1) % (uint32_t)c->feed.size();
@@ -1303,8 +1317,8 @@ int ssdr_feed_post(ssdr_ctx *c, const ssdr_db2col_chan *chans, const ssdr_play_c
 {
     if (!c) return SSDR_EINVAL;
     if (c->feed.empty() || !c->feed_post) return SSDR_ESTATE;
-    if (chans) c->feed_dbchan.assign(chans, chans + c->n_ch);
-    if (play) c->feed_playchan.assign(play, play + c->n_ch);
+    if (chans) std::copy(chans, chans + c->n_post, c->feed_dbchan.begin());        // (n_post entries, in the order of the selection)
+    if (play) std::copy(play, play + c->n_post, c->feed_playchan.begin());
     return SSDR_OK;
 }
 
@@ -1526,7 +1540,7 @@ int ssdr_selftest_quantiser(ssdr_ctx *c, uint64_t *mismatches)
 // oldest queued line becomes row 0 and the rows scroll down by one.
 static int wfdata_feed(ssdr_ctx *c, const float *color, uint32_t lines)
 {
-    const size_t line = (size_t)c->n_ch * SSDR_NFFT;
+    const size_t line = (size_t)c->n_post * SSDR_NFFT;       // the rows hold the selected channels' lines, in selection order
     for (uint32_t i = 0; i < lines; i++) {
         c->wfdata_seen++;                                                        // run_index += 1 (:889)
         if (c->wfpend_n == 3) { c->wfpend_first++; c->wfpend_n--; }              // deque(maxlen=3).appendleft on a full deque
@@ -1545,6 +1559,33 @@ static int wfdata_feed(ssdr_ctx *c, const float *color, uint32_t lines)
     return SSDR_OK;
 }
 
+int ssdr_set_post_channels(ssdr_ctx *c, const uint32_t *channels, uint32_t count)
+{
+    if (!c || (count && !channels && count != c->n_ch) || count > c->n_ch) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool all = channels == nullptr;                    // (NULL, 0) or (NULL, n_ch): every channel, the default
+    if (!all)
+        for (uint32_t i = 0; i < count; i++)
+            if (channels[i] >= c->n_ch || (i && channels[i] <= channels[i - 1])) return SSDR_EINVAL;     // ascending, unique
+    if (!all) {
+        if (!c->d_post_sel) HIP_TRY(hipMalloc(&c->d_post_sel, (size_t)c->n_ch * sizeof(uint32_t)));
+        // in stream order behind the batches already queued with the previous selection
+        if (count) HIP_TRY(hipMemcpyAsync(c->d_post_sel, channels, (size_t)count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));             // `channels` is the caller's
+        c->n_post = count;
+    } else {
+        if (c->d_post_sel) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(c->d_post_sel)); c->d_post_sel = nullptr; }
+        c->n_post = c->n_ch;
+    }
+    // the device copy of wf_data holds other channels' rows now: it starts over (kiwi_waterfall.__init__'s np.zeros, utils_supersdr.py:692)
+    if (c->d_wfdata) {
+        HIP_TRY(hipMemsetAsync(c->d_wfdata, 0, (size_t)c->wfdata_rows * c->n_ch * SSDR_NFFT * sizeof(float), c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->wfdata_head = 0; c->wfdata_seen = c->wfpend_first = 0; c->wfpend_n = 0;
+    }
+    return SSDR_OK;
+}
+
 int ssdr_run_db2col(ssdr_ctx *c, ssdr_db2col_chan *chans, float *color_out, int out_is_device)
 {
     if (!c || !chans) return SSDR_EINVAL;
@@ -1558,7 +1599,8 @@ int ssdr_run_db2col(ssdr_ctx *c, ssdr_db2col_chan *chans, float *color_out, int 
         HIP_TRY(hipMalloc(&c->d_color, (size_t)lines * c->n_ch * SSDR_NFFT * sizeof(float)));
         c->color_lines = lines;
     }
-    HIP_TRY(hipMemcpyAsync(c->d_db2col, chans, (size_t)c->n_ch * sizeof(ssdr_db2col_chan), hipMemcpyHostToDevice, c->stream));
+    if (c->n_post == 0) return SSDR_OK;                       // an empty selection: nobody is looking
+    HIP_TRY(hipMemcpyAsync(c->d_db2col, chans, (size_t)c->n_post * sizeof(ssdr_db2col_chan), hipMemcpyHostToDevice, c->stream));
     SsdrDb2colArgs a;
     a.wf = c->d_wf_out;
     a.n_ch = c->n_ch;
@@ -1566,14 +1608,16 @@ int ssdr_run_db2col(ssdr_ctx *c, ssdr_db2col_chan *chans, float *color_out, int 
     a.n_avg = c->n_avg;
     a.chans = c->d_db2col;
     a.color = c->d_color;
+    a.sel = c->d_post_sel;
+    a.n_sel = c->n_post;
     int rc;
     if ((rc = timed_begin(c)) != SSDR_OK) return rc;
     HIP_TRY(ssdr_launch_db2col(a, c->stream));
     if ((rc = timed_end(c, SSDR_K_DB2COL)) != SSDR_OK) return rc;
     if (c->d_wfdata) { int rcw = wfdata_feed(c, c->d_color, lines); if (rcw != SSDR_OK) return rcw; }
-    HIP_TRY(hipMemcpyAsync(chans, c->d_db2col, (size_t)c->n_ch * sizeof(ssdr_db2col_chan), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(chans, c->d_db2col, (size_t)c->n_post * sizeof(ssdr_db2col_chan), hipMemcpyDeviceToHost, c->stream));
     if (color_out)
-        HIP_TRY(hipMemcpyAsync(color_out, c->d_color, (size_t)lines * c->n_ch * SSDR_NFFT * sizeof(float),
+        HIP_TRY(hipMemcpyAsync(color_out, c->d_color, (size_t)lines * c->n_post * SSDR_NFFT * sizeof(float),
                                out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
@@ -1597,6 +1641,8 @@ int ssdr_db2col_line(ssdr_ctx *c, const int16_t *wf_sum, uint32_t n_avg, ssdr_db
     a.n_avg = n_avg;
     a.chans = c->d_dbchan1;
     a.color = c->d_color1;
+    a.sel = nullptr;
+    a.n_sel = 1;
     int rc;
     if ((rc = timed_begin(c)) != SSDR_OK) return rc;
     HIP_TRY(ssdr_launch_db2col(a, c->stream));
@@ -1657,7 +1703,7 @@ int ssdr_push_color_lines(ssdr_ctx *c, const float *color, uint32_t lines, int c
     if (!c->d_wfdata) return SSDR_ESTATE;
     if (lines == 0) return SSDR_OK;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t n = (size_t)lines * c->n_ch * SSDR_NFFT;
+    const size_t n = (size_t)lines * c->n_post * SSDR_NFFT;
     const float *src = color;
     if (!color_is_device) {
         if (c->color_lines < lines) {
@@ -1676,14 +1722,14 @@ int ssdr_push_color_lines(ssdr_ctx *c, const float *color, uint32_t lines, int c
 
 int ssdr_wfdata_white_flag(ssdr_ctx *c, uint32_t first, uint32_t count)
 {
-    if (!c || first + count > c->n_ch || first + count < first) return SSDR_EINVAL;
+    if (!c || first + count > c->n_post || first + count < first) return SSDR_EINVAL;      // (positions in the selection)
     if (!c->d_wfdata) return SSDR_ESTATE;
     if (count == 0) return SSDR_OK;
     HIP_TRY(hipSetDevice(c->device));
     const float white = 255.0f;                                                  // np.ones_like(wf_color) * 255 (:876)
     uint32_t bits;
     memcpy(&bits, &white, 4);
-    float *row0 = c->d_wfdata + ((size_t)c->wfdata_head * c->n_ch + first) * SSDR_NFFT;
+    float *row0 = c->d_wfdata + ((size_t)c->wfdata_head * c->n_post + first) * SSDR_NFFT;
     HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(row0), (int)bits, (size_t)count * SSDR_NFFT, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
@@ -1695,14 +1741,15 @@ int ssdr_run_trace(ssdr_ctx *c, uint32_t t_avg, uint32_t spectrum_height, double
     if (!c->d_wfdata) return SSDR_ESTATE;
     if (t_avg > c->wfdata_rows) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t n = (size_t)c->n_ch * SSDR_NFFT;
+    const size_t n = (size_t)c->n_post * SSDR_NFFT;
+    if (!n) return SSDR_OK;
     if (!c->d_trace) {
-        HIP_TRY(hipMalloc(&c->d_trace, n * sizeof(double)));
-        HIP_TRY(hipMalloc(&c->d_trace_y, n * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&c->d_trace, (size_t)c->n_ch * SSDR_NFFT * sizeof(double)));
+        HIP_TRY(hipMalloc(&c->d_trace_y, (size_t)c->n_ch * SSDR_NFFT * sizeof(int32_t)));
     }
     SsdrTraceArgs a;
     a.ring = c->d_wfdata;
-    a.n_ch = c->n_ch;
+    a.n_ch = c->n_post;
     a.rows = c->wfdata_rows;
     a.head = c->wfdata_head;
     a.t_avg = t_avg;
@@ -1794,7 +1841,10 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
         HIP_TRY(hipMalloc(&c->d_play_mono, (size_t)c->n_ch * nf * 2048 * sizeof(int16_t)));
         c->play_mono_frames = nf;
     }
-    HIP_TRY(hipMemcpyAsync(c->d_play, chans, (size_t)c->n_ch * sizeof(ssdr_play_chan), hipMemcpyHostToDevice, c->stream));
+    if (c->n_post == 0) { c->play_run_frames = 0; return SSDR_OK; }
+    HIP_TRY(hipMemcpyAsync(c->d_play, chans, (size_t)c->n_post * sizeof(ssdr_play_chan), hipMemcpyHostToDevice, c->stream));
+    if (c->d_post_sel && !wide)          // the channels outside the selection keep their history
+        HIP_TRY(hipMemcpyAsync(c->d_play_hist_alt, c->d_play_hist, (size_t)c->n_ch * 8 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     SsdrPlayArgs a;
     a.pcm = c->d_pcm;
     a.n_ch = c->n_ch;
@@ -1803,6 +1853,8 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
     a.taps = c->d_play_taps;
     a.hist = c->d_play_hist;
     a.hist_out = c->d_play_hist_alt;
+    a.sel = c->d_post_sel;
+    a.n_sel = c->n_post;
     a.out = c->d_play_out;
     a.rs_taps = c->d_play_rs_taps;
     a.mono = c->recording ? c->d_play_mono : nullptr;
@@ -1814,7 +1866,7 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
     if (!wide) std::swap(c->d_play_hist, c->d_play_hist_alt);            // (the 64/27 branch carries no history)
     if ((rc = timed_end(c, SSDR_K_PLAY)) != SSDR_OK) return rc;
     if (out)
-        HIP_TRY(hipMemcpyAsync(out, c->d_play_out, (size_t)c->n_ch * nf * per_frame * 2 * sizeof(int16_t),
+        HIP_TRY(hipMemcpyAsync(out, c->d_play_out, (size_t)c->n_post * nf * per_frame * 2 * sizeof(int16_t),
                                out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
@@ -1833,7 +1885,7 @@ int ssdr_playbuffer_mono(ssdr_ctx *c, int16_t *mono_out, int out_is_device)
     if (!c || !mono_out) return SSDR_EINVAL;
     if (!c->d_play_mono || c->play_run_frames == 0) return SSDR_ESTATE;       // the last ssdr_run_playbuffer did not record
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemcpyAsync(mono_out, c->d_play_mono, (size_t)c->n_ch * c->play_run_frames * c->play_run_len * sizeof(int16_t),
+    HIP_TRY(hipMemcpyAsync(mono_out, c->d_play_mono, (size_t)c->n_post * c->play_run_frames * c->play_run_len * sizeof(int16_t),
                            out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;

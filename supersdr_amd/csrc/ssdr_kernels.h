@@ -76,11 +76,15 @@ struct SsdrSynthArgs {
 
 #define SSDR_WIRE_BODY (17 + SSDR_FRAME * 4)  // SND body in IQ mode: 7 B header + 10 B GPS + 512 x (I,Q) int16 BE
 
+// Post-processing works on `n_sel` channels: all of the ctx (sel == null, n_sel == n_ch) or the ones ssdr_set_post_channels named.
+// Inputs (waterfall sums, PCM, play_buffer history) are indexed by the channel, display state and outputs by the position in the list.
 struct SsdrDb2colArgs {
     const int16_t *wf;                       // [n_lines][n_ch][1024] sums of n_avg byte lines
     uint32_t n_ch, n_lines, n_avg;
-    ssdr_db2col_chan *chans;                 // [n_ch] in/out
-    float *color;                            // [n_lines][n_ch][1024]
+    ssdr_db2col_chan *chans;                 // [n_sel] in/out
+    float *color;                            // [n_lines][n_sel][1024]
+    const uint32_t *sel;                     // [n_sel] channel of every position, or null
+    uint32_t n_sel;
 };
 
 struct SsdrPlayArgs {
@@ -94,6 +98,8 @@ struct SsdrPlayArgs {
     const double *rs_taps;                   // resampled path: [64*21] polyphase taps (ssdr_resample_taps.h)
     int16_t *mono;                           // [n_ch][n_frames*L] the block before the pan, truncated (the recording branch,
                                              // utils_supersdr.py:1139-1140), or null
+    const uint32_t *sel;                     // as in SsdrDb2colArgs: chans / out / mono are [n_sel]..., pcm and hist per channel
+    uint32_t n_sel;
 };
 
 struct SsdrTraceArgs {

@@ -93,9 +93,10 @@ __global__ __launch_bounds__(256) void ssdr_db2col_kernel(SsdrDb2colArgs a)
 {
     const int l = threadIdx.x & 63;
     const uint64_t item = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (item >= (uint64_t)a.n_ch * a.n_lines) return;
-    const uint32_t line = (uint32_t)(item / a.n_ch), ch = (uint32_t)(item - (uint64_t)line * a.n_ch);       // line-major, like the data
-    ssdr_db2col_chan st = a.chans[ch];
+    if (item >= (uint64_t)a.n_sel * a.n_lines) return;
+    const uint32_t line = (uint32_t)(item / a.n_sel), pos = (uint32_t)(item - (uint64_t)line * a.n_sel);      // line-major, like the data
+    const uint32_t ch = a.sel ? a.sel[pos] : pos;
+    ssdr_db2col_chan st = a.chans[pos];
     const float z3 = (float)(3 * st.zoom), dlo = (float)st.delta_low_db, dhi = (float)st.delta_high_db;
     const float fn = (float)a.n_avg;
     const float G = 0x1.99ap-3f;
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void ssdr_db2col_kernel(SsdrDb2colArgs a)
     st.wf_min_db = lo2 - z3;
     st.wf_max_db = (st.low_clip_db + nf) - z3;
 
-    f32x4 *dst0 = reinterpret_cast<f32x4 *>(a.color + ((uint64_t)line * a.n_ch + ch) * SSDR_NFFT) + l;
+    f32x4 *dst0 = reinterpret_cast<f32x4 *>(a.color + ((uint64_t)line * a.n_sel + pos) * SSDR_NFFT) + l;
     const float aden = fabsf(den);
     if (aden >= 0x1p-40f && aden <= 0x1p40f) {                  // wave-uniform
         // num / den, correctly rounded: r = rcp refined once; q = num r refined twice against the exact residual.  |num| < 2^20 and is
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void ssdr_db2col_kernel(SsdrDb2colArgs a)
     }
     // the display state as the LAST line leaves it (utils_supersdr.py:795-808); only the fields spectrum_db2col writes
     if (l == 0 && line + 1 == a.n_lines) {
-        ssdr_db2col_chan *o = a.chans + ch;
+        ssdr_db2col_chan *o = a.chans + pos;
         o->low_clip_db = st.low_clip_db; o->high_clip_db = st.high_clip_db; o->dynamic_range = st.dynamic_range;
         o->wf_min_db = st.wf_min_db; o->wf_max_db = st.wf_max_db;
     }
@@ -204,10 +205,11 @@ __global__ __launch_bounds__(256) void ssdr_play_kernel(SsdrPlayArgs a)
     __shared__ double s_xw[4][8 + SSDR_FRAME];                      // per wave: 8 carried samples + the frame, volume applied
     const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t item = (uint64_t)blockIdx.x * 4 + wave;
-    if (item >= (uint64_t)a.n_ch * a.n_frames) return;
-    const uint32_t ch = (uint32_t)(item / a.n_frames), f = (uint32_t)(item - (uint64_t)ch * a.n_frames);
+    if (item >= (uint64_t)a.n_sel * a.n_frames) return;
+    const uint32_t pos = (uint32_t)(item / a.n_frames), f = (uint32_t)(item - (uint64_t)pos * a.n_frames);
+    const uint32_t ch = a.sel ? a.sel[pos] : pos;
     double *s_x = s_xw[wave];
-    const ssdr_play_chan pc = a.chans[ch];
+    const ssdr_play_chan pc = a.chans[pos];
     const double vol = pc.volume / 100.0;
     const double lv = fmin(1.0 - pc.balance, 1.0), rv = fmin(1.0 + pc.balance, 1.0);
     const double l2 = lv * lv, r2 = rv * rv;
@@ -223,8 +225,8 @@ __global__ __launch_bounds__(256) void ssdr_play_kernel(SsdrPlayArgs a)
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    u32x4 *dst = reinterpret_cast<u32x4 *>(a.out + ((uint64_t)ch * a.n_frames + f) * 2048 * 2);
-    int16_t *mono = a.mono ? a.mono + ((uint64_t)ch * a.n_frames + f) * 2048 : nullptr;
+    u32x4 *dst = reinterpret_cast<u32x4 *>(a.out + ((uint64_t)pos * a.n_frames + f) * 2048 * 2);
+    int16_t *mono = a.mono ? a.mono + ((uint64_t)pos * a.n_frames + f) * 2048 : nullptr;
 #pragma unroll 2
     for (int k = 0; k < 8; k++) {
         const int m = 64 * k + l;
@@ -290,8 +292,12 @@ __global__ __launch_bounds__(256) void ssdr_play_rs_kernel(SsdrPlayArgs a)
     double h[SSDR_RS_HPP];
 #pragma unroll
     for (int m = 0; m < SSDR_RS_HPP; m++) h[m] = a.rs_taps[t * SSDR_RS_HPP + m];
-    const uint64_t n_items = (uint64_t)a.n_ch * a.n_frames;
+    const uint64_t n_items = (uint64_t)a.n_sel * a.n_frames;
     auto put = [&](int i, double v) { s_a[i] = v; if (i) s_b[i - 1] = v; };
+    auto frame_of = [&](uint64_t it) -> uint64_t {                  // item (position, frame) -> its PCM frame (channel, frame)
+        const uint32_t ps = (uint32_t)(it / a.n_frames), fr = (uint32_t)(it - (uint64_t)ps * a.n_frames);
+        return (uint64_t)(a.sel ? a.sel[ps] : ps) * a.n_frames + fr;
+    };
     const uint64_t stride = (uint64_t)gridDim.x * 4;
     uint64_t item = (uint64_t)blockIdx.x * 4 + wave;
     // the next frame's samples are fetched while this one is computed (a frame is 1 KB: one memory round trip per frame
@@ -299,14 +305,14 @@ __global__ __launch_bounds__(256) void ssdr_play_rs_kernel(SsdrPlayArgs a)
     int16_t cur[8], nxt[8];
     if (item < n_items) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) cur[k] = a.pcm[item * SSDR_FRAME + 64 * k + p];
+        for (int k = 0; k < 8; k++) cur[k] = a.pcm[frame_of(item) * SSDR_FRAME + 64 * k + p];
     }
     for (; item < n_items; item += stride) {
-        const uint32_t ch = (uint32_t)(item / a.n_frames), f = (uint32_t)(item - (uint64_t)ch * a.n_frames);
-        const uint64_t nitem = item + stride < n_items ? item + stride : item;
+        const uint32_t pos = (uint32_t)(item / a.n_frames), f = (uint32_t)(item - (uint64_t)pos * a.n_frames);
+        const uint64_t nframe = frame_of(item + stride < n_items ? item + stride : item);
 #pragma unroll
-        for (int k = 0; k < 8; k++) nxt[k] = a.pcm[nitem * SSDR_FRAME + 64 * k + p];
-        const ssdr_play_chan pc = a.chans[ch];
+        for (int k = 0; k < 8; k++) nxt[k] = a.pcm[nframe * SSDR_FRAME + 64 * k + p];
+        const ssdr_play_chan pc = a.chans[pos];
         const double vol = pc.volume / 100.0;
         const double lv = fmin(1.0 - pc.balance, 1.0), rv = fmin(1.0 + pc.balance, 1.0);
         const double l2 = lv * lv, r2 = rv * rv;
@@ -327,8 +333,8 @@ __global__ __launch_bounds__(256) void ssdr_play_rs_kernel(SsdrPlayArgs a)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        uint32_t *dst = reinterpret_cast<uint32_t *>(a.out + ((uint64_t)ch * a.n_frames + f) * SSDR_RS_OUT_PER_FRAME * 2);
-        int16_t *mono = a.mono ? a.mono + ((uint64_t)ch * a.n_frames + f) * SSDR_RS_OUT_PER_FRAME : nullptr;
+        uint32_t *dst = reinterpret_cast<uint32_t *>(a.out + ((uint64_t)pos * a.n_frames + f) * SSDR_RS_OUT_PER_FRAME * 2);
+        int16_t *mono = a.mono ? a.mono + ((uint64_t)pos * a.n_frames + f) * SSDR_RS_OUT_PER_FRAME : nullptr;
         constexpr int NJ = (SSDR_RS_OUT_PER_FRAME + 63) / 64;                                        // 19
         // per output: all eleven reads are issued, then the 21-term chain runs (left to the scheduler every read is followed by
         // its own wait, and the wave sits out the LDS latency eleven times per output)
@@ -530,14 +536,14 @@ hipError_t ssdr_launch_adpcm(const uint8_t *data, uint32_t n_streams, uint32_t n
 
 hipError_t ssdr_launch_db2col(const SsdrDb2colArgs &a, hipStream_t stream)
 {
-    const uint64_t items = (uint64_t)a.n_ch * a.n_lines;
+    const uint64_t items = (uint64_t)a.n_sel * a.n_lines;
     if (!items) return hipSuccess;
     hipLaunchKernelGGL(ssdr_db2col_kernel, dim3((uint32_t)((items + 3) / 4)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 hipError_t ssdr_launch_play_rs(const SsdrPlayArgs &a, hipStream_t stream)
 {
-    const uint64_t items = (uint64_t)a.n_ch * a.n_frames;
+    const uint64_t items = (uint64_t)a.n_sel * a.n_frames;
     if (!items) return hipSuccess;
     static uint32_t resident = 0;                    // persistent grid: the lanes' taps are loaded once per wave
     if (!resident) {
@@ -556,7 +562,7 @@ hipError_t ssdr_launch_play_rs(const SsdrPlayArgs &a, hipStream_t stream)
 
 hipError_t ssdr_launch_play(const SsdrPlayArgs &a, hipStream_t stream)
 {
-    const uint64_t items = (uint64_t)a.n_ch * a.n_frames;
+    const uint64_t items = (uint64_t)a.n_sel * a.n_frames;
     if (!items) return hipSuccess;
     hipLaunchKernelGGL(ssdr_play_kernel, dim3((uint32_t)((items + 3) / 4)), dim3(256), 0, stream, a);
     return hipGetLastError();

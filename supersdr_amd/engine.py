@@ -61,6 +61,8 @@ class SsdrEngine:
         self.kiwi_rate = L.RATE
         self.audio_frames = 0          # frames of the last run_audio / set_pcm (extent of the device PCM / RSSI / flags)
         self._pinned = []              # host_alloc()
+        self.n_post = self.n_ch        # channels the post-processing works on (set_post_channels)
+        self._feed_n_post = []         # ... of the batches in flight in the pipelined feed, oldest first
 
     def close(self):
         if self._ctx:
@@ -220,15 +222,28 @@ class SsdrEngine:
         check(lib.ssdr_sync(self._ctx), "ssdr_sync")
 
     # ---- the reference's post-processing on the GPU
+    def set_post_channels(self, channels=None):
+        """the channels the post-processing works on from now on (ascending, unique; None: all of them).  Every per-channel
+        array of run_db2col / run_playbuffer / playbuffer_mono / feed_post / feed_collect_post / run_trace then has
+        len(channels) entries, in this order."""
+        if channels is None:
+            check(lib.ssdr_set_post_channels(self._ctx, None, 0), "ssdr_set_post_channels")
+            self.n_post = self.n_ch
+            return
+        sel = np.ascontiguousarray(channels, np.uint32)
+        check(lib.ssdr_set_post_channels(self._ctx, sel.ctypes.data if len(sel) else (C.c_uint32 * 1)(), len(sel)), "ssdr_set_post_channels")
+        self.n_post = len(sel)
+
     def run_db2col(self, chans, lines, fetch=True):
         """spectrum_db2col for the lines of the last run_wf.  chans: list of Db2colChan, or a ctypes array
-        (Db2colChan * n_ch) that goes to the library as it is (no per-channel Python work); updated in place.
-        -> float32 [lines, n_ch, 1024] wf_color."""
-        arr = chans if isinstance(chans, C.Array) else (Db2colChan * self.n_ch)(*chans)
-        out = np.empty((lines, self.n_ch, L.NFFT), np.float32) if fetch else None
-        check(lib.ssdr_run_db2col(self._ctx, arr, out.ctypes.data if fetch else None, 0), "ssdr_run_db2col")
+        (Db2colChan * n_post) that goes to the library as it is (no per-channel Python work); updated in place.
+        -> float32 [lines, n_post, 1024] wf_color (n_post = n_ch unless set_post_channels named a subset)."""
+        n = self.n_post
+        arr = chans if isinstance(chans, C.Array) else (Db2colChan * max(n, 1))(*chans)
+        out = np.empty((lines, n, L.NFFT), np.float32) if fetch else None
+        check(lib.ssdr_run_db2col(self._ctx, arr, out.ctypes.data if fetch and n else None, 0), "ssdr_run_db2col")
         if arr is not chans:
-            for i in range(self.n_ch):
+            for i in range(n):
                 chans[i] = arr[i]
         return out
 
@@ -239,11 +254,12 @@ class SsdrEngine:
         check(lib.ssdr_feed_open(self._ctx, int(n_frames), int(depth), (1 if wire else 0) | (2 if post else 0)), "ssdr_feed_open")
         self._feed_frames, self._feed_wire, self._feed_post = int(n_frames), bool(wire), bool(post)
         self._feed_lines = 0
+        self._feed_n_post, self._feed_last_n_post = [], self.n_post
 
     def feed_post(self, chans=None, play=None):
         """display state for the batches submitted from now on: lists of Db2colChan / PlayChan (None keeps the previous)"""
-        a = chans if chans is None or isinstance(chans, C.Array) else (Db2colChan * self.n_ch)(*chans)
-        b = play if play is None or isinstance(play, C.Array) else (PlayChan * self.n_ch)(*play)
+        a = chans if chans is None or isinstance(chans, C.Array) else (Db2colChan * max(self.n_post, 1))(*chans)
+        b = play if play is None or isinstance(play, C.Array) else (PlayChan * max(self.n_post, 1))(*play)
         check(lib.ssdr_feed_post(self._ctx, a, b), "ssdr_feed_post")
 
     def feed_collect_post(self):
@@ -252,13 +268,16 @@ class SsdrEngine:
         col, ch, pl, mo = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         check(lib.ssdr_feed_collect_post(self._ctx, C.byref(col), C.byref(ch), C.byref(pl), C.byref(mo)), "ssdr_feed_collect_post")
         nf, nl, P = self._feed_frames, self._feed_lines, self.playbuffer_frame_len()
-        color = chans = mono = None
+        n = self._feed_last_n_post                  # what the batch was post-processed for: the selection at ITS submit
+        color = chans = mono = play = None
+        if n == 0:
+            return None, None, None, None
         if nl and col.value:
-            color = np.ctypeslib.as_array(C.cast(col, C.POINTER(C.c_float)), shape=(nl * self.n_ch * L.NFFT,)).reshape(nl, self.n_ch, L.NFFT)
-            chans = (Db2colChan * self.n_ch).from_address(ch.value)        # indexable view of the slot's pinned copy
-        play = np.ctypeslib.as_array(C.cast(pl, C.POINTER(C.c_int16)), shape=(self.n_ch * nf * P * 2,)).reshape(self.n_ch, nf * P, 2)
+            color = np.ctypeslib.as_array(C.cast(col, C.POINTER(C.c_float)), shape=(nl * n * L.NFFT,)).reshape(nl, n, L.NFFT)
+            chans = (Db2colChan * n).from_address(ch.value)                # indexable view of the slot's pinned copy
+        play = np.ctypeslib.as_array(C.cast(pl, C.POINTER(C.c_int16)), shape=(n * nf * P * 2,)).reshape(n, nf * P, 2)
         if mo.value:
-            mono = np.ctypeslib.as_array(C.cast(mo, C.POINTER(C.c_int16)), shape=(self.n_ch * nf * P,)).reshape(self.n_ch, nf * P)
+            mono = np.ctypeslib.as_array(C.cast(mo, C.POINTER(C.c_int16)), shape=(n * nf * P,)).reshape(n, nf * P)
         return color, chans, play, mono
 
     def feed_slot(self):
@@ -274,6 +293,7 @@ class SsdrEngine:
 
     def feed_submit(self):
         check(lib.ssdr_feed_submit(self._ctx), "ssdr_feed_submit")
+        self._feed_n_post.append(self.n_post)
 
     def feed_submit_from(self, batch):
         """queue a batch that lies in the caller's own host array (layout of feed_slot(); ideally from host_alloc): no copy
@@ -281,6 +301,7 @@ class SsdrEngine:
         if not (batch.flags.c_contiguous and batch.nbytes == self._feed_bytes()):
             raise ValueError("feed_submit_from: the batch must be C-contiguous and exactly one slot in size")
         check(lib.ssdr_feed_submit_from(self._ctx, batch.ctypes.data), "ssdr_feed_submit_from")
+        self._feed_n_post.append(self.n_post)
 
     def _feed_bytes(self):
         return self.n_ch * self._feed_frames * (L.WIRE_BODY if self._feed_wire else L.FRAME * 4)
@@ -311,6 +332,7 @@ class SsdrEngine:
                                     C.byref(fl), C.byref(navg)), "ssdr_feed_collect")
         nf, nl = self._feed_frames, int(lines.value)
         self._feed_lines = nl
+        self._feed_last_n_post = self._feed_n_post.pop(0) if self._feed_n_post else self.n_post
         self.feed_flags = np.ctypeslib.as_array(C.cast(fl, C.POINTER(C.c_uint8)), shape=(self.n_ch * nf,)).reshape(self.n_ch, nf)
         self.feed_n_avg = int(navg.value)          # the N in force when this batch was submitted
         w = (np.ctypeslib.as_array(C.cast(wf, C.POINTER(C.c_int16)), shape=(nl * self.n_ch * L.NFFT,)).reshape(nl, self.n_ch, L.NFFT)
@@ -331,19 +353,19 @@ class SsdrEngine:
     def push_color_line(self, color):
         """float32 [lines, n_ch, 1024] colour lines from elsewhere than run_db2col into the device copy of wf_data."""
         color = np.ascontiguousarray(color, np.float32)
-        assert color.ndim == 3 and color.shape[1:] == (self.n_ch, L.NFFT)
+        assert color.ndim == 3 and color.shape[1:] == (self.n_post, L.NFFT)
         check(lib.ssdr_push_color_lines(self._ctx, color.ctypes.data, color.shape[0], 0), "ssdr_push_color_lines")
 
     def white_flag(self, first=0, count=None):
         """kiwi_waterfall.set_white_flag (utils_supersdr.py:875-877) on the device copy of wf_data."""
-        check(lib.ssdr_wfdata_white_flag(self._ctx, int(first), self.n_ch - first if count is None else int(count)),
+        check(lib.ssdr_wfdata_white_flag(self._ctx, int(first), self.n_post - first if count is None else int(count)),
               "ssdr_wfdata_white_flag")
 
     def run_trace(self, t_avg=15, spectrum_height=0, want_y=True):
         """plot_spectrum's reduction (utils_supersdr.py:1678-1679) -> (float64 [n_ch, 1024] nanmean over the t_avg newest
         wf_data rows, int32 [n_ch, 1024] pixel rows or None)."""
-        trace = np.empty((self.n_ch, L.NFFT), np.float64)
-        y = np.empty((self.n_ch, L.NFFT), np.int32) if want_y else None
+        trace = np.empty((self.n_post, L.NFFT), np.float64)
+        y = np.empty((self.n_post, L.NFFT), np.int32) if want_y else None
         check(lib.ssdr_run_trace(self._ctx, int(t_avg), int(spectrum_height), trace.ctypes.data,
                                  y.ctypes.data if want_y else None, 0), "ssdr_run_trace")
         return trace, y
@@ -372,9 +394,9 @@ class SsdrEngine:
     def run_playbuffer(self, chans, fetch=True):
         """play_buffer for the frames of the last run_audio -> int16 [n_ch, n_frames*L, 2], L = playbuffer_frame_len()
         (2048 at 12 kHz, 1213 at 20.25 kHz).  chans: list of PlayChan or a ctypes array (PlayChan * n_ch)."""
-        arr = chans if isinstance(chans, C.Array) else (PlayChan * self.n_ch)(*chans)
-        out = np.empty((self.n_ch, self.audio_frames * self.playbuffer_frame_len(), 2), np.int16) if fetch else None
-        check(lib.ssdr_run_playbuffer(self._ctx, arr, out.ctypes.data if fetch else None, 0), "ssdr_run_playbuffer")
+        arr = chans if isinstance(chans, C.Array) else (PlayChan * max(self.n_post, 1))(*chans)
+        out = np.empty((self.n_post, self.audio_frames * self.playbuffer_frame_len(), 2), np.int16) if fetch else None
+        check(lib.ssdr_run_playbuffer(self._ctx, arr, out.ctypes.data if fetch and self.n_post else None, 0), "ssdr_run_playbuffer")
         return out
 
     def set_recording(self, on):
@@ -383,7 +405,7 @@ class SsdrEngine:
 
     def playbuffer_mono(self):
         """-> int16 [n_ch, n_frames*L]: pyaudio_buffer.astype(np.int16) of the last run_playbuffer (utils_supersdr.py:1139-1140)"""
-        out = np.empty((self.n_ch, self.audio_frames * self.playbuffer_frame_len()), np.int16)
+        out = np.empty((self.n_post, self.audio_frames * self.playbuffer_frame_len()), np.int16)
         check(lib.ssdr_playbuffer_mono(self._ctx, out.ctypes.data, 0), "ssdr_playbuffer_mono")
         return out
 

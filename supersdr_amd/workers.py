@@ -71,9 +71,11 @@ class SuperframeResult:
     wf int16 [lines, n_ch, 1024] sums of n_avg byte lines, pcm int16 [n_ch, frames*512], rssi float32 [n_ch, frames],
     flags uint8 [n_ch, frames]; with gpu_post also color float32 [lines, n_ch, 1024], chans (Db2colChan per channel, as
     spectrum_db2col left them), play int16 [n_ch, frames*L, 2], mono (recording) -- or None where that stage did not run.
+    On a lazy hub the post-processing runs for the channels with a worker only: post_channels lists them, and color / chans /
+    play / mono have one entry per listed channel, in that order (post_channels None: one per channel).
     In pipeline mode the arrays are views of the feed's pinned slots: valid until `depth - 1` further superframes have
     been collected (copy what must live longer)."""
-    __slots__ = ("seq", "wf", "n_avg", "color", "chans", "pcm", "rssi", "flags", "play", "mono", "iq", "wire_rssi")
+    __slots__ = ("seq", "wf", "n_avg", "color", "chans", "pcm", "rssi", "flags", "play", "mono", "iq", "wire_rssi", "post_channels")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -219,11 +221,12 @@ class IQHub:
         self._n_wf_clients = self._n_snd_clients = 0
         self.wf_clients = _ClientSlots(self.n_ch, self._wf_client_changed)      # kiwi_waterfall objects: display state for db2col
         self.snd_clients = _ClientSlots(self.n_ch, self._snd_client_changed)    # kiwi_sound objects: volume / balance for play_buffer
-        self._db_arr = (Db2colChan * self.n_ch)()
-        self._play_arr = (PlayChan * self.n_ch)()
-        d0 = self._db2col_chan(None)
-        _fill_struct_array(self._db_arr, d0)
-        _fill_struct_array(self._play_arr, PlayChan(100.0, 0.0))
+        # spectrum_db2col / play_buffer are per viewer: a lazy hub runs them for the channels with a worker only
+        # (ssdr_set_post_channels); a hub that attaches everybody keeps them on every channel
+        self._post_select = self._lazy and hasattr(self.engine, "set_post_channels")
+        self._post_sel, self._post_pos, self._post_dirty = None, None, self._post_select
+        self._inflight_sel = deque()                 # pipelined: the selection each batch in flight was submitted with
+        self._alloc_post_arrays(self.n_ch)
         self._params = {}                            # channel -> ChanParams, for the channels that were given any
         self._default_params = default_params("am")
         self._n_iq_mode = 0
@@ -269,8 +272,30 @@ class IQHub:
         hook (a recorder, a detector over all channels); per-channel consumers use the queues"""
         self._subscribers.append(fn)
 
+    def _alloc_post_arrays(self, n):
+        self._db_arr = (Db2colChan * max(n, 1))()
+        self._play_arr = (PlayChan * max(n, 1))()
+        _fill_struct_array(self._db_arr, self._db2col_chan(None))
+        _fill_struct_array(self._play_arr, PlayChan(100.0, 0.0))
+
+    @property
+    def post_channels(self):
+        """the channels spectrum_db2col / play_buffer run for (None: all of them)"""
+        return self._post_sel
+
+    def _apply_post_selection(self):
+        """lazy hub: the post kernels' channel list follows the workers that are attached"""
+        self._post_dirty = False
+        sel = sorted({c for c in self._wf_att if self.wf_clients[c] is not None} | {c for c in self._snd_att if self.snd_clients[c] is not None})
+        if sel == self._post_sel:
+            return
+        self.engine.set_post_channels(sel)
+        self._post_sel, self._post_pos = sel, {c: i for i, c in enumerate(sel)}
+        self._alloc_post_arrays(len(sel))
+
     def _wf_client_changed(self, c, old, new):
         with self._lock:
+            self._post_dirty = self._post_select
             self._n_wf_clients += (new is not None) - (old is not None)
             n = int(self._want_n[c])
             if (new is not None) != (old is not None):
@@ -279,16 +304,16 @@ class IQHub:
                     del self._want_cli[n]
             if new is not None:
                 self.attach(c, wf=True)
-                self._db_arr[c] = self._db2col_chan(new)
-            else:
+            elif not self._post_select:
                 self._db_arr[c] = self._db2col_chan(None)
 
     def _snd_client_changed(self, c, old, new):
         with self._lock:
+            self._post_dirty = self._post_select
             self._n_snd_clients += (new is not None) - (old is not None)
             if new is not None:
                 self.attach(c, snd=True)
-            else:
+            elif not self._post_select:
                 self._play_arr[c] = PlayChan(100.0, 0.0)
 
     # ---- control plane (forwarded SET commands)
@@ -467,15 +492,19 @@ class IQHub:
 
     # ---- data plane: the GPU run and what becomes of its results
     def _sync_display_state(self):
-        """the attached workers' display state into the two per-channel arrays the post kernels read"""
+        """the attached workers' display state into the two arrays the post kernels read (one entry per channel, or per
+        selected channel on a lazy hub)"""
+        if self._post_dirty:
+            self._apply_post_selection()
+        pos = self._post_pos
         for c in self._wf_att:
             w = self.wf_clients[c]
             if w is not None:
-                self._db_arr[c] = self._db2col_chan(w)
+                self._db_arr[c if pos is None else pos[c]] = self._db2col_chan(w)
         for c in self._snd_att:
             s = self.snd_clients[c]
             if s is not None:
-                self._play_arr[c] = PlayChan(float(s.volume), float(s.audio_balance))
+                self._play_arr[c if pos is None else pos[c]] = PlayChan(float(s.volume), float(s.audio_balance))
 
     def _sync_recording(self):
         rec = any(self.snd_clients[c] is not None and self.snd_clients[c].audio_rec.recording_flag for c in self._snd_att)
@@ -506,30 +535,34 @@ class IQHub:
                 mono = eng.playbuffer_mono()
         self.superframes += 1
         self._hand_out(SuperframeResult(seq=self.superframes, wf=wf, n_avg=n_avg, color=color, chans=chans, pcm=pcm, rssi=rssi,
-                                        flags=flags, play=play, mono=mono, iq=iqo, wire_rssi=wire_rssi))
+                                        flags=flags, play=play, mono=mono, iq=iqo, wire_rssi=wire_rssi, post_channels=self._post_sel))
 
     def _hand_out(self, r):
         self.last = r
         for fn in self._subscribers:
             fn(r)
         P, wf, pcm = self.play_len, r.wf, r.pcm
+        pos = None if r.post_channels is None else {c: i for i, c in enumerate(r.post_channels)}      # row of a channel in the post results
         for c in self._wf_att:
             q = self.wf_queue._q[c]
-            has_post = r.color is not None and self.wf_clients[c] is not None
+            pc = c if pos is None else pos.get(c)
+            has_post = r.color is not None and self.wf_clients[c] is not None and pc is not None
             for i in range(len(wf)):
                 post = None
                 if has_post:
-                    k = r.chans[c]
-                    post = (r.color[i, c].copy(), k.low_clip_db, k.high_clip_db, k.dynamic_range, k.wf_min_db, k.wf_max_db)
+                    k = r.chans[pc]
+                    post = (r.color[i, pc].copy(), k.low_clip_db, k.high_clip_db, k.dynamic_range, k.wf_min_db, k.wf_max_db)
                 _put_drop_oldest(q, (wf[i, c].copy(), r.n_avg, post))
         for c in self._snd_att:
             q = self.snd_queue._q[c]
             iq_mode = r.iq is not None and self.params(c).mode == L.MODE_IQ
+            pc = c if pos is None else pos.get(c)
+            has_play = r.play is not None and pc is not None
             for f in range(pcm.shape[1] // L.FRAME):
                 _put_drop_oldest(q, Frame.make(
                     pcm[c, f * L.FRAME:(f + 1) * L.FRAME], r.rssi[c, f],
-                    r.play[c, f * P:(f + 1) * P].copy() if r.play is not None else None,
-                    r.mono[c, f * P:(f + 1) * P].copy() if r.mono is not None else None, r.flags[c, f],
+                    r.play[pc, f * P:(f + 1) * P].copy() if has_play else None,
+                    r.mono[pc, f * P:(f + 1) * P].copy() if has_play and r.mono is not None else None, r.flags[c, f],
                     r.iq[c, f * L.FRAME:(f + 1) * L.FRAME].copy() if iq_mode else None))
 
     def _run_pipelined(self, batch):
@@ -538,6 +571,7 @@ class IQHub:
             self._sync_recording()
             self._sync_display_state()
             eng.feed_post(self._db_arr, self._play_arr)
+        self._inflight_sel.append(self._post_sel)
         if hasattr(eng, "feed_submit_from"):
             eng.feed_submit_from(batch)               # the H2D copy reads the hub's slot itself
         else:
@@ -555,6 +589,7 @@ class IQHub:
         self._inflight -= 1
         n_avg, flags = eng.feed_n_avg, eng.feed_flags          # per slot: the N in force at submit, this batch's flags
         color = chans = play = mono = None
+        sel = self._inflight_sel.popleft() if self._inflight_sel else self._post_sel
         if self.gpu_post:
             color, chans, play, mono = eng.feed_collect_post()
             if not self._n_wf_clients:
@@ -562,7 +597,8 @@ class IQHub:
             if not self._n_snd_clients:
                 play = mono = None
         self._hand_out(SuperframeResult(seq=self.superframes - self._inflight, wf=wf, n_avg=n_avg, color=color, chans=chans, pcm=pcm,
-                                        rssi=rssi, flags=flags, play=play, mono=mono, wire_rssi=got[3] if len(got) > 3 else None))
+                                        rssi=rssi, flags=flags, play=play, mono=mono, wire_rssi=got[3] if len(got) > 3 else None,
+                                        post_channels=sel))
 
     def flush(self):
         """pipeline mode: wait for the superframes still in flight and hand their results out"""

@@ -564,3 +564,96 @@ def test_hub_with_zoomed_waterfall(S, twin):
     hub.close()
     with pytest.raises(ValueError):
         IQHub(1, zoom=2, pipeline=True)
+
+
+def test_post_processing_for_the_listeners_only(S):
+    """Round 4: ssdr_set_post_channels -- spectrum_db2col / play_buffer run for the channels somebody looks at, not for the ctx.
+    (1) the engine: a subset's colours, display state, 48 kHz blocks and mono blocks equal the rows of an all-channel run; a
+    channel that leaves the selection and comes back continues its play_buffer history; an empty selection does nothing.
+    (2) the hub: on a lazy hub of 600 receivers with workers on two of them, synchronous and pipelined, the two workers see bit
+    for bit what they see on a hub that post-processes everybody; the post results carry two rows."""
+    from supersdr_amd._lib import Db2colChan, PlayChan
+    from supersdr_amd.workers import IQHub, bind_headless
+    n_ch, sel = 40, [3, 17, 18, 39]
+    iq = O.synth_iq(n_ch, 6 * 1024, seed=52)
+    rng = np.random.default_rng(5)
+    db = [Db2colChan(zoom=int(rng.integers(0, 12)), auto_scale=int(c % 3 != 0), delta_low_db=int(rng.integers(-20, 20)),
+                     delta_high_db=int(rng.integers(-20, 20)), low_clip_db=-110.0, high_clip_db=-50.0, dynamic_range=60.0) for c in range(n_ch)]
+    pl = [PlayChan(float(rng.choice([50, 100, 150])), float(rng.choice([-1, -0.5, 0, 0.5, 1]))) for c in range(n_ch)]
+
+    def run(eng, k, chans, play):
+        eng.push_iq(iq[:, 2 * k * 1024: 2 * (k + 1) * 1024])
+        wf = eng.run_wf()
+        eng.run_audio()
+        d = [Db2colChan.from_buffer_copy(bytes(x)) for x in chans]
+        col = eng.run_db2col(d, len(wf))
+        out = eng.run_playbuffer(play)
+        return col, d, out, eng.playbuffer_mono()
+
+    with S.SsdrEngine(n_ch) as full, S.SsdrEngine(n_ch) as part:
+        for e in (full, part):
+            e.set_recording(True)
+        ref = [run(full, k, db, pl) for k in range(3)]
+        part.set_post_channels(sel)
+        for k in range(3):
+            if k == 1:
+                part.set_post_channels([3, 18])                # channels 17 and 39 sit this batch out ...
+                col, d, out, mono = run(part, k, [db[3], db[18]], [pl[3], pl[18]])
+                now = [3, 18]
+            else:
+                part.set_post_channels(sel)                    # ... and come back: their history is the one they left with
+                col, d, out, mono = run(part, k, [db[c] for c in sel], [pl[c] for c in sel])
+                now = sel
+            assert col.shape == (2, len(now), 1024) and out.shape == (len(now), 4 * 2048, 2) and mono.shape == (len(now), 4 * 2048)
+            for i, c in enumerate(now):
+                assert np.array_equal(col[:, i], ref[k][0][:, c]) and bytes(d[i]) == bytes(ref[k][1][c]), (k, c)
+                if not (k == 2 and c in (17, 39)):             # (those two skipped a batch: their history is one batch older)
+                    assert np.array_equal(out[i], ref[k][2][c]) and np.array_equal(mono[i], ref[k][3][c]), (k, c)
+        part.set_post_channels([])
+        part.push_iq(iq[:, :2048])
+        wf = part.run_wf()
+        part.run_audio()
+        assert part.run_db2col([], len(wf)).shape == (2, 0, 1024) and part.run_playbuffer([]).shape == (0, 4 * 2048, 2)
+        part.set_post_channels(None)
+        assert part.run_db2col([Db2colChan.from_buffer_copy(bytes(x)) for x in db], len(wf)).shape == (2, n_ch, 1024)
+        with pytest.raises(S.SsdrError):
+            part.set_post_channels([5, 5])
+        with pytest.raises(S.SsdrError):
+            part.set_post_channels([7, n_ch])
+
+    # (2) through the hub
+    kiwi_waterfall, kiwi_sound = bind_headless().kiwi_waterfall, bind_headless().kiwi_sound
+
+    class Disp:
+        DISPLAY_WIDTH, WF_HEIGHT = 1024, 8
+
+    N, who = 600, (41, 500)
+    big = O.synth_iq(N, 5 * 1024, seed=53)
+    seen = {}
+    for name, kw in (("everybody", dict(lazy=False)), ("listeners", dict(lazy=True)), ("listeners, pipelined", dict(lazy=True, pipeline=True, depth=3))):
+        hub = IQHub(N, **kw)
+        wfs = [kiwi_waterfall("gpu", 0, "", 4 + i, 7100.0, None, Disp(), hub=hub, channel=c, timeout=1.0) for i, c in enumerate(who)]
+        snds = [kiwi_sound(7100.0 + i, "AM", -6000, 6000, "", w, 8) for i, w in enumerate(wfs)]
+        snds[1].volume, snds[1].audio_balance = 130, 0.5
+        rows = []
+        hub.subscribe(lambda r: rows.append((r.post_channels, None if r.color is None else r.color.shape, None if r.play is None else r.play.shape)))
+        for k in range(5):
+            hub.feed_block(0, big[:, k * 1024:(k + 1) * 1024])
+        hub.flush()
+        got = []
+        for w, s_ in zip(wfs, snds):
+            for k in range(5):
+                w.step()
+                got.append((w.wf_color.copy(), w.wf_min_db, w.wf_max_db))
+            for f in range(10):
+                fr = s_.process_audio_stream()
+                got.append((np.asarray(fr).copy(), fr.play_block.copy()))
+        seen[name] = got
+        if kw["lazy"]:
+            assert hub.post_channels == list(who) and all(r == (list(who), (1, 2, 1024), (2, 2 * 2048, 2)) for r in rows)
+        else:
+            assert hub.post_channels is None and rows[0][1] == (1, N, 1024)
+        hub.close()
+    for name in ("listeners", "listeners, pipelined"):
+        for a, b in zip(seen["everybody"], seen[name]):
+            assert all(np.array_equal(x, y) for x, y in zip(a, b)), name
