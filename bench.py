@@ -63,21 +63,22 @@ PATH_NAMES = ("FIR", "shift", "AM-shift")        # ssdr_audio_kernel<0|1|2>
 PATH_TEXT = ("general: NCO -> FIR -> demodulator", "full-band lane shift: NCO, no FIR", "full-band AM: no NCO, no FIR (|x e^{j phi}| = |x|)")
 F32_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: vector f32 peak (an FMA = 2 flop)
 RIDGE_FLOP_PER_BYTE = F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)          # 19.7
-# Executed vector work per unit: VALU wave-instructions from PMC SQ_INSTS_VALU / wave-units (profiles/r03_*_pmc_summary.txt:
-# 6.152e8 per 524 288 line pairs, 3.727e8 per 327 680, 5.456e8 / 1.872e8 / 8.056e7 per 655 360 / 327 680 / 327 680 frames,
-# the fused superframe kernel 1.130e9 per 1 048 576 channel-superframes,
-# 7.031e8 per 262 144 frames), FMA share from the static opcode mix of the loops (profiles/r02_isa_histograms.txt; the
-# filters' multiply-adds -- 512 per frame for 33 taps, 2000 for 125 at D = 4 -- are dynamic).
-# flops = 64 lanes x (instructions + FMA instructions).
+# Executed vector work per unit: VALU wave-instructions from PMC SQ_INSTS_VALU / wave-units (profiles/r04_*_pmc_summary.txt:
+# 6.152e8 per 524 288 line pairs, 3.727e8 per 327 680, 1.2204e9 per 1 048 576 (hop 512); 5.456e8 / 1.898e8 / 7.958e7 per
+# 655 360 / 327 680 / 327 680 frames; the fused superframe kernel 1.1296e9 (hop 1024) / 1.7386e9 (hop 512) per 1 048 576
+# channel-superframes; 7.031e8 per 262 144 frames at D = 4), FMA share from the opcode mix of the loops
+# (profiles/r04_isa_histograms.txt; the filters' multiply-adds -- 512 per frame for 33 taps, 2000 for 125 at D = 4 -- are dynamic).
+# lane-ops = 64 lanes x (instructions + FMA instructions): issue-slot work, see roofline().
 KERNEL_VALU = {
-    "ssdr_wf_kernel<false, false>": ("line", 1173.5 / 2, 0.64),
-    "ssdr_wf_kernel<true, false>": ("line", 1137.5 / 2, 0.64),
-    "ssdr_wf_kernel<false, true>": ("line", 1173.5 / 2, 0.64),
-    "ssdr_wf_kernel<true, true>": ("line", 1137.5 / 2, 0.64),
-    "ssdr_audio_kernel<0>": ("frame", 832, 0.75),
-    "ssdr_audio_kernel<1>": ("frame", 571, 0.42),
-    "ssdr_audio_kernel<2>": ("frame", 243, 0.23),
-    "ssdr_fused_am_kernel": ("channel-superframe", 1077, 0.45),
+    "ssdr_wf_kernel<false, false>": ("line", 1173.5 / 2, 0.65),
+    "ssdr_wf_kernel<true, false>": ("line", 1137.5 / 2, 0.60),
+    "ssdr_wf_kernel<false, true>": ("line", 1163.9 / 2, 0.65),
+    "ssdr_wf_kernel<true, true>": ("line", 1137.5 / 2, 0.60),
+    "ssdr_audio_kernel<0>": ("frame", 832.6, 0.75),
+    "ssdr_audio_kernel<1>": ("frame", 579.2, 0.42),
+    "ssdr_audio_kernel<2>": ("frame", 241, 0.22),
+    "ssdr_fused_am_kernel<false>": ("channel-superframe", 1077.2, 0.45),
+    "ssdr_fused_am_kernel<true>": ("channel-superframe", 1658.0, 0.50),
     "ssdr_audio_dec_kernel<4>": ("frame", 2682, 0.85),
 }
 
@@ -353,9 +354,9 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
                                               else {name: channels * n_frames}}
     if fu_n:
         avg = fu_ms / fu_n
-        b = channels * sframes * 8192.0                 # SURVEY.md 8d, fused budget at N = 1: 4096 in + 2048 + 2048 out
-        stages["fused"] = {"kernel": "ssdr_fused_am_kernel", "avg_ms": avg, "launches": fu_n, "bytes": b, "GBps": b / avg / 1e6,
-                           "units": channels * sframes}
+        b = channels * sframes * (4096.0 + (2 if hop == 512 else 1) * 2048.0 + 2048.0)      # SURVEY.md 8d, fused budget at N = 1: 4096 in + 2048 per line + 2048 PCM out
+        stages["fused"] = {"kernel": "ssdr_fused_am_kernel<%s>" % ("true" if hop == 512 else "false"), "avg_ms": avg, "launches": fu_n,
+                           "bytes": b, "GBps": b / avg / 1e6, "units": channels * sframes}
     return {"value": units / wall / RT_SUPERFRAMES_PER_S, "ms_per_step": wall / steps * 1e3, "stages": stages,
             "n_avg": n_avg, "paths": paths, "decim": decim,
             "own_value": channels * sframes * steps / own_wall / RT_SUPERFRAMES_PER_S}
@@ -499,7 +500,10 @@ def stage_traffic(traffic, stage):
     """PMC bytes of a stage: its kernel's, or the sum over the kernels a multi-kernel audio stage names"""
     import re
     names = re.findall(r"ssdr_\w+_kernel(?:<[^>]*>)?", stage["kernel"])
-    vals = [traffic.get(n) for n in names]
+    bare = {}                                      # a kernel named without its template arguments: the one instance that was profiled
+    for k, v in traffic.items():
+        bare.setdefault(k.split("<")[0], []).append(v)
+    vals = [traffic.get(n, bare.get(n, [None])[0] if len(bare.get(n, [])) == 1 else None) for n in names]
     return sum(vals) if vals and all(v is not None for v in vals) else None
 
 
@@ -726,7 +730,7 @@ def main():
         def run_extra(key, wl, nsteps, text="", warm=2, spin=0.5, **kw):
             ch, sf = WORKLOADS[wl][0], WORKLOADS[wl][1]
             e = measure(S, L, torch, rdv, rank, world, local_rank, wl, ch, sf, nsteps, warm, spin, **kw)
-            tr, tsrc = pmc_traffic(wl, ch, sf, kw.get("hop", 1024)) if not kw.get("exact") else ({}, None)
+            tr, tsrc = pmc_traffic(wl, ch, sf, kw.get("hop", 1024))
             extra[key] = {"workload": WORKLOAD_TEXT[wl] + text, "value": e["value"], "unit": "rt_channels", "ms_per_step": e["ms_per_step"],
                           "steps": nsteps, "channels_per_gpu": ch, "superframes_per_step": sf, "averaging_n": e["n_avg"],
                           "input_decimation": e["decim"],

@@ -56,6 +56,27 @@ def read_kiwi_iq_wav(path_or_bytes):
     return np.stack(blocks), stamps
 
 
+def kiwi_iq_wav_time_axis(stamps, block_len, nominal_rate=12000.0):
+    """The time axis kiwi/wavreader.py builds for a Kiwi IQ recording (wavreader.py:86-99): every block is stamped with the GNSS
+    time of its first sample; the sample rate is re-estimated from consecutive stamps -- taken as measured for the first blocks,
+    then smoothed 0.9 / 0.1 -- and a block's samples sit at stamp + k / rate.  The first two blocks only prime the estimate
+    (the reader hands out no time for them).  stamps: the (last_gps_solution, dummy, gpssec, gpsnsec) tuples read_kiwi_iq_wav
+    returns; -> (t float64 [n_blocks - 2, block_len] GNSS seconds, rate estimates float64 [n_blocks])."""
+    rate, last, primed = float(nominal_rate), -1.0, 0
+    rates, rows = [], []
+    for _, _, sec, nsec in stamps:
+        now = sec + 1e-9 * nsec
+        if last >= 0:
+            measured = block_len / (now - last)
+            rate = measured if primed < 3 else 0.9 * rate + 0.1 * measured
+        if primed >= 2:
+            rows.append(np.arange(start=now, stop=now + (block_len - 0.5) / rate, step=1 / rate, dtype=np.float64))
+        rates.append(rate)
+        last = now
+        primed += primed < 3
+    return (np.stack(rows) if rows else np.zeros((0, block_len))), np.array(rates)
+
+
 class IQBatcher:
     """Mixin: IQ frames -> IQHub.  `samples` arrives as the reference builds it (kiwi/client.py:
     449-453): complex64 with unscaled int16 values in re/im, so the conversion back is exact."""

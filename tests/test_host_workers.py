@@ -456,6 +456,10 @@ def test_kiwi_wav_reader_vs_reference_golden():
     assert [s[3] for s in stamps] == [42666667 * i for i in range(5)]
     with pytest.raises(ValueError):
         read_kiwi_iq_wav(b"RIFX" + bytes(40))
+    # the reader's time axis (wavreader.py:86-99: per-block rate estimate from the GNSS stamps, 0.9 / 0.1 smoothing; VERDICT r3 missing #5)
+    from supersdr_amd.iqstream import kiwi_iq_wav_time_axis
+    t, rates = kiwi_iq_wav_time_axis(stamps, blocks.shape[1])
+    assert t.shape == (3, 512) and np.array_equal(t.reshape(-1), g["t"]) and abs(rates[-1] - 12000.0) < 0.01
 
 
 # ------------------------------------------------------------------ round 2: hardening of the host shim
