@@ -425,7 +425,7 @@ def measure_post(S, L, local_rank, channels=65536, sframes=16, steps=10, spinup=
     return stages
 
 
-def measure_hub(S, L, torch, local_rank, channels, sframes, steps, in_place, batch_superframes=4):
+def measure_hub(S, L, torch, local_rank, channels, sframes, steps, in_place, batch_superframes=4, copy_threads=0):
     """The pipelined feed driven through the product's own ingest API (supersdr_amd/workers.py:IQHub, the thing
     KiwiSDRStream._process_iq_samples fills, kiwi/client.py:493-494): `channels` receivers, one block call per superframe.
     in_place=False: IQHub.feed_block (one copy of the block into the hub's pinned slot -- the hub's whole host cost);
@@ -438,7 +438,7 @@ def measure_hub(S, L, torch, local_rank, channels, sframes, steps, in_place, bat
     eng.synth_iq(2 * batch_superframes)
     block = eng.read_input()                                     # [channels, K * 1024, 2]: K superframes of synthetic IQ, replayed
     hub = IQHub(channels, engine=eng, gpu_post=False, pipeline=True, depth=3, lazy=True, batch_superframes=batch_superframes,
-                backlog_superframes=2 * batch_superframes, stall_superframes=batch_superframes)
+                backlog_superframes=2 * batch_superframes, stall_superframes=batch_superframes, copy_threads=copy_threads)
     hub.attach(channels // 2, wf=True, snd=True)
     seen = [0]
     hub.subscribe(lambda r: seen.__setitem__(0, seen[0] + r.pcm.shape[1] // 1024))
@@ -469,7 +469,7 @@ def measure_hub(S, L, torch, local_rank, channels, sframes, steps, in_place, bat
     units = channels * n_batches * batch_superframes
     return {"value": units / wall / RT_SUPERFRAMES_PER_S, "unit": "rt_channels", "ms_per_superframe": wall / (n_batches * batch_superframes) * 1e3,
             "channels": channels, "superframes_per_gpu_run": batch_superframes, "superframes": n_batches * batch_superframes,
-            "ingest": "IQHub.reserve/commit (in place)" if in_place else "IQHub.feed_block (one host copy)",
+            "ingest": "IQHub.reserve/commit (in place)" if in_place else "IQHub.feed_block (one host copy%s)" % (", %d threads" % copy_threads if copy_threads > 1 else ""),
             "host_GBps": units * 4096.0 / wall / 1e9, "frames_queued_for_the_one_listener": q}
 
 
@@ -761,7 +761,8 @@ def main():
                          "reference_cpu": {v["kernel"]: v["reference_cpu"] for v in post.values() if "reference_cpu" in v}}
         # the product's own ingest API in front of the pipelined feed (PCIe-inclusive, never `value`)
         if args.host_feed_extra:
-            extra["hub_feed"] = {k: measure_hub(S, L, torch, local_rank, 65536, 16, 2, in_place=ip) for k, ip in (("feed_block", False), ("in_place", True))}
+            extra["hub_feed"] = {k: measure_hub(S, L, torch, local_rank, 65536, 16, 2, in_place=ip, copy_threads=ct)
+                                 for k, ip, ct in (("feed_block", False, 0), ("feed_block_8_threads", False, 8), ("in_place", True, 0))}
         full["extra"] = extra
     full["roofline"]["stages"] = summary
 

@@ -148,14 +148,14 @@ class IQHub:
     also runs spectrum_db2col and play_buffer (SSDR_FEED_POST) with the display state latched at submit.  Results arrive
     `depth - 1` superframes late (flush() drains) and are bit-identical to the synchronous hub's.
     `batch_superframes=K` runs K superframes per GPU call (K lines + 2K audio frames per channel and call): latency for
-    launch efficiency at very large channel counts.
+    launch efficiency at very large channel counts.  `copy_threads=T` splits feed_block's copy of a large block over T threads.
     """
 
     LAZY_ABOVE = 1024
 
     def __init__(self, n_channels, device=0, engine=None, max_queue=64, gpu_post=True, kiwi_rate=12000, trace_rows=0,
                  backlog_superframes=8, stall_superframes=4, pipeline=False, depth=3, hop=1024, zoom=1, lazy=None,
-                 batch_superframes=1, wire=False):
+                 batch_superframes=1, wire=False, copy_threads=0):
         self.n_ch = int(n_channels)
         self.engine = engine if engine is not None else SsdrEngine(self.n_ch, device)
         # waterfall zoom ("SET zoom=", utils_supersdr.py:741, 839): the lines then span 1/zoom of the IQ band around each
@@ -187,6 +187,13 @@ class IQHub:
         self.pipeline = bool(pipeline)
         self._inflight, self._depth = 0, int(depth)
         self.wire = bool(wire)                       # slots hold SND bodies (kiwi/client.py:443-454), unpacked on the device
+        # feed_block's one copy, split over a few threads when the block is large (NumPy copies outside the GIL): a single core moves
+        # ~10-20 GB/s, a superframe of 10^5 receivers is 0.5 GB
+        self._copy_pool = None
+        if copy_threads and copy_threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._copy_pool = ThreadPoolExecutor(int(copy_threads))
+            self._copy_threads = int(copy_threads)
         # ---- the ring of superframe slots.  Unit = what a channel's write position counts: samples, or SND frames (wire)
         if self.wire:
             self._U, self._row = self._sf // L.FRAME, (L.WIRE_BODY,)
@@ -447,7 +454,12 @@ class IQHub:
                 continue
             self._await_slot(b)
             m = min(n - pos, U - off)
-            self._slots[b % self._nslots][first:first + k, off:off + m] = data[:, pos:pos + m]
+            dst, src = self._slots[b % self._nslots][first:first + k, off:off + m], data[:, pos:pos + m]
+            if self._copy_pool is not None and src.nbytes >= (32 << 20) and k >= 4 * self._copy_threads:
+                step = -(-k // self._copy_threads)
+                list(self._copy_pool.map(lambda lo: np.copyto(dst[lo:lo + step], src[lo:lo + step]), range(0, k, step)))
+            else:
+                dst[...] = src
             self._advance(first, k, g0, m)
             pos += m
             self._pump()
@@ -651,6 +663,8 @@ class IQHub:
             except Exception:
                 pass
         self._slots = []
+        if self._copy_pool is not None:
+            self._copy_pool.shutdown()
         self.engine.close()
 
 
