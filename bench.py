@@ -209,7 +209,7 @@ def spawn_ranks(gpus, argv):
 # ---------------------------------------------------------------------------------------------------------------
 # one measurement
 # ---------------------------------------------------------------------------------------------------------------
-def configure(S, eng, workload, channels, first_channel_id, hop=1024, fused=1, concurrent=0, exact=0):
+def configure(S, eng, workload, channels, first_channel_id, hop=1024, fused=1, concurrent=0, exact=0, overlap=1):
     """channel parameters of `workload` for the block of channels that starts at global id `first_channel_id`
     (mode by channel id mod len(modes), tuning by the generator's carrier formula)"""
     _, _, n_avg, modes, _, _ = WORKLOADS[workload]
@@ -224,6 +224,7 @@ def configure(S, eng, workload, channels, first_channel_id, hop=1024, fused=1, c
     eng.reset_state()
     eng.set_hop(hop)
     eng.set_fused(fused)
+    eng.set_overlap(overlap)
     eng.set_averaging(n_avg)
     eng.set_concurrent(concurrent)
     eng.set_exact_bins(exact)
@@ -250,7 +251,7 @@ def parity_probe(S, local_rank, workload, first_channel_id, channels=256, sframe
 
 
 def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sframes, steps, warmup, spinup,
-            concurrent=0, host_feed=0, hop=1024, fused=1, exact=0, first_channel_id=None):
+            concurrent=0, host_feed=0, hop=1024, fused=1, exact=0, first_channel_id=None, overlap=1):
     """Spin the clocks up, W warm-up steps, then exactly `steps` timed steps between barrier + synchronize pairs.
     -> dict(value, ms_per_step, stages, ...)."""
     _, _, _, modes, do_wf, do_audio = WORKLOADS[workload]
@@ -258,7 +259,7 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     if first_channel_id is None:
         first_channel_id = rank * channels
     eng = S.SsdrEngine(channels, device=local_rank)
-    n_avg, decim = configure(S, eng, workload, channels, first_channel_id, hop, fused, concurrent, exact)
+    n_avg, decim = configure(S, eng, workload, channels, first_channel_id, hop, fused, concurrent, exact, overlap)
     eng.synth_iq(n_frames, seed=0x5D5D, first_channel_id=first_channel_id)    # resident in HBM from here on
     eng.sync()
 
@@ -357,8 +358,11 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
         b = channels * sframes * (4096.0 + (2 if hop == 512 else 1) * 2048.0 + 2048.0)      # SURVEY.md 8d, fused budget at N = 1: 4096 in + 2048 per line + 2048 PCM out
         stages["fused"] = {"kernel": "ssdr_fused_am_kernel<%s>" % ("true" if hop == 512 else "false"), "avg_ms": avg, "launches": fu_n,
                            "bytes": b, "GBps": b / avg / 1e6, "units": channels * sframes}
+    side = bool(do_wf and do_audio and "fused" not in stages and (overlap or concurrent & 1))
+    for st in stages.values():
+        st["side_by_side"] = side                       # the two stages ran beside each other: their durations overlap
     return {"value": units / wall / RT_SUPERFRAMES_PER_S, "ms_per_step": wall / steps * 1e3, "stages": stages,
-            "n_avg": n_avg, "paths": paths, "decim": decim,
+            "n_avg": n_avg, "paths": paths, "decim": decim, "side_by_side": side,
             "own_value": channels * sframes * steps / own_wall / RT_SUPERFRAMES_PER_S}
 
 
@@ -576,6 +580,9 @@ def main():
     ap.add_argument("--fused", type=int, default=1,
                     help="1 (the library's default): ssdr_run_chain uses the fused superframe kernel where the configuration allows it "
                          "(every channel full-band AM, N = 1, hop 1024); 0: always the two per-stage kernels")
+    ap.add_argument("--overlap", type=int, default=1,
+                    help="1 (the library's default): batches ssdr_run_chain does not fuse run the audio stage beside the waterfall kernel on a "
+                         "second stream; 0: one after the other (per-stage durations that do not overlap)")
     ap.add_argument("--hop", type=int, default=1024, choices=[512, 1024],
                     help="samples between waterfall lines: 512 = 23.4 lines/s, the reference's waterfall rate (utils_supersdr.py:597)")
     ap.add_argument("--exact", type=int, default=0, help="1: ssdr_set_exact_bins -- the waterfall stage in float64 (bins equal the float64 oracle bit for bit)")
@@ -650,7 +657,7 @@ def main():
         rdv.close()
         return
     m = measure(S, L, torch, rdv, rank, world, local_rank, args.workload, channels, sframes, args.steps, args.warmup,
-                args.spinup, args.concurrent, args.host_feed, args.hop, args.fused, args.exact, first_id)
+                args.spinup, args.concurrent, args.host_feed, args.hop, args.fused, args.exact, first_id, args.overlap)
     # SURVEY.md 8e parity hash (untimed): every rank hashes a probe of its own channel block and of the NEXT rank's block;
     # rank r's view of block r+1 must equal rank r+1's own (at N = 1: a second fresh ctx must reproduce the first)
     firsts = [int(v[0]) for v in rdv.gather_ints([first_id])]
@@ -679,7 +686,7 @@ def main():
                    "input_decimation": m["decim"], "wf_exact_bins": bool(args.exact),
                    "chain": ("ssdr_run_chain: one fused kernel for both stages (one read of the input; bit-identical to the two per-stage "
                              "kernels, which extra.full_two_kernels times)" if "fused" in m["stages"] else
-                             "the per-stage kernels" + (" side by side on two streams" if args.concurrent & 1 else " one after the other")),
+                             "the per-stage kernels" + (" side by side on two streams" if m["side_by_side"] else " one after the other")),
                    "clock_spinup_s": args.spinup,
                    "input": {0: "resident in HBM", 1: "pinned host memory, pipelined H2D / kernels / D2H (PCIe-inclusive)",
                              2: "SND wire bodies in pinned host memory, pipelined, unpacked on the device (PCIe-inclusive)"}[args.host_feed],
@@ -697,6 +704,8 @@ def main():
     def note(label, stage, tr=None, tsrc=None):
         r = roofline(stage, stage_traffic(tr, stage) if tr else None, tsrc)
         e = {"kernel": stage["kernel"], "ms": round(stage["avg_ms"], 4), "frac_hbm": round(r["frac_hbm"], 4)}
+        if stage.get("side_by_side"):
+            e["side_by_side"] = True            # ran beside the other stage: ms is its (longer) duration in company, frac_hbm is per that duration
         if "issue" in r:
             e["frac_f32_issue"] = round(r["issue"]["frac_f32"], 3)
         if r.get("traffic"):
@@ -743,14 +752,15 @@ def main():
         nst = max(20, args.steps // 3)
         # configs[1] and configs[3] in the same driver-timed line: shorter runs, each with its own rooflines
         run_extra("wf", "wf", max(20, args.steps // 2))
-        run_extra("mixed", "mixed", max(20, args.steps // 2))
+        run_extra("mixed", "mixed", max(20, args.steps // 2), ", the two stages side by side (ssdr_run_chain's default for what it does not fuse)")
+        run_extra("mixed_serial", "mixed", max(20, args.steps // 2), ", the two stages one after the other (--overlap 0): per-kernel durations and rooflines", overlap=0)
         # variants of the default workload that the design discusses, timed by the same run
-        run_extra("full_two_kernels", "full", nst, ", the two per-stage kernels one after the other (--fused 0)", fused=0)
-        run_extra("full_exact", "full", nst, ", float64 waterfall stage (--exact 1: bins equal the NumPy float64 path bit for bit) + audio stage", exact=1)
+        run_extra("full_two_kernels", "full", nst, ", the two per-stage kernels one after the other (--fused 0 --overlap 0)", fused=0, overlap=0)
+        run_extra("full_exact", "full", nst, ", float64 waterfall stage (--exact 1: bins equal the NumPy float64 path bit for bit) beside the audio stage", exact=1)
         run_extra("wf_exact_bins", "wf", nst, ", float64 waterfall stage (--exact 1)", exact=1)
         e = run_extra("wf_hop512", "wf", nst, ", hop 512 (23.4 lines/s)", hop=512)
         extra["wf_hop512"]["lines_per_s"] = e["stages"]["wf"]["lines_per_launch"] / e["ms_per_step"] * 1e3
-        run_extra("full_hop512", "full", nst, ", waterfall at hop 512 (23.4 lines/s, the reference's line rate)", hop=512)
+        run_extra("full_hop512", "full", nst, ", waterfall at hop 512 (23.4 lines/s, the reference's line rate), the two stages side by side", hop=512)
         # configs[4] at N = 1 (2^20 channels on this one GPU, 16 superframes per call) and the decimating front end
         run_extra("million", "million", 5, warm=1, spin=0.3)
         run_extra("decim4", "decim4", nst, warm=1, spin=0.3)

@@ -177,10 +177,18 @@ int ssdr_audio_iq(ssdr_ctx *ctx, int16_t *iq_out, int out_is_device);
  * ssdr_run_wf followed by ssdr_run_audio do.  When every channel is on the reference's full-band AM passband, N = 1, hop
  * 1024, 12 kHz IQ, no zoom, and the batch holds an even number of at least 8 frames (the configuration of the metric), ONE
  * kernel does both: each 4 KB line is read once for its FFT and its two audio frames; results are bit-identical to the two
- * kernels'.  *fused (may be NULL) tells which way it went; ssdr_set_fused(ctx, 0) keeps the two kernels in every case (the
- * default is 1).  The pipelined feed (ssdr_feed_*) runs its batches through this call. */
+ * kernels'.  *fused (may be NULL) tells which way it went; ssdr_set_fused(ctx, 0) keeps the two kernels in every case.
+ * Every other batch runs the two stages side by side on two streams (ssdr_set_overlap).  The pipelined feed (ssdr_feed_*)
+ * runs its batches through this call. */
 int ssdr_run_chain(ssdr_ctx *ctx, uint32_t *lines_ready, int *fused);
+/* 0: never the fused kernel; 1 (default): at hop 1024; 2: at hop 512 as well (there the two stages side by side are faster:
+ * ssdr_set_overlap) */
 int ssdr_set_fused(ssdr_ctx *ctx, int on);
+/* Batches ssdr_run_chain does not fuse (mixed modes, N > 1, hop 512, float64 bins, ...) run their two stages SIDE BY SIDE: the audio
+ * stage on a second HIP stream beside the waterfall kernel, both reading the same input batch (default on; results are those of
+ * one after the other, bit for bit).  Every later call that needs the audio stage's results, its state or the input buffer
+ * waits for it first.  0: one after the other (per-stage timings that do not overlap). */
+int ssdr_set_overlap(ssdr_ctx *ctx, int on);
 int ssdr_sync(ssdr_ctx *ctx);
 
 /* -- the reference's own post-processing of the two streams, on the GPU.

@@ -88,6 +88,7 @@ _SIGS = {
     "ssdr_audio_iq": (C.c_int, [_P, _P, C.c_int]),
     "ssdr_run_chain": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "ssdr_set_fused": (C.c_int, [_P, C.c_int]),
+    "ssdr_set_overlap": (C.c_int, [_P, C.c_int]),
     "ssdr_sync": (C.c_int, [_P]),
     "ssdr_set_post_channels": (C.c_int, [_P, _P, C.c_uint32]),
     "ssdr_run_db2col": (C.c_int, [_P, C.POINTER(Db2colChan), _P, C.c_int]),

@@ -62,7 +62,8 @@ struct ssdr_ctx {
     bool sum_any_iq = false;
     hipStream_t path_stream[SSDR_PATH_COUNT - 1] = {};  // the audio kernels of different paths run side by side
     hipEvent_t ev_fork = nullptr, ev_path[SSDR_PATH_COUNT - 1] = {};
-    bool fused_enabled = true;                          // ssdr_set_fused: ssdr_run_chain may use the fused superframe kernel
+    int fused_enabled = 1;                              // ssdr_set_fused: 0 never, 1 at hop 1024 (default), 2 at hop 512 as well
+    bool overlap_enabled = true;                        // ssdr_set_overlap: un-fused ssdr_run_chain batches run the audio stage beside the waterfall kernel
     bool fuse_next = false;                             // ssdr_run_chain: run_wf parks its arguments, run_audio launches the fused kernel
     SsdrWfArgs fused_wf;
     uint32_t fused_grid = 0;
@@ -313,12 +314,15 @@ int ssdr_table(int which, float *out, uint32_t n)
 }
 
 static int zoom_restart(ssdr_ctx *c, uint32_t first, uint32_t count, bool restart_group = true);
+static int join_audio(ssdr_ctx *c);
+static int drain_audio(ssdr_ctx *c);
 
 int ssdr_reset_state(ssdr_ctx *c, uint32_t first, uint32_t count)
 {
     if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     if (!count) return SSDR_OK;
     HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     std::vector<ssdr_chan_consts> k(count);
     HIP_TRY(hipMemcpyAsync(k.data(), c->d_consts + first, count * sizeof(ssdr_chan_consts), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -354,6 +358,7 @@ int ssdr_set_params(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan
     for (uint32_t i = 0; i < count; i++) c->h_consts[first + i] = k[i];
     c->chan_list_dirty = true;
     c->summary_dirty = true;
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     HIP_TRY(hipMemcpyAsync(c->d_consts + first, k.data(), count * sizeof(ssdr_chan_consts), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemcpyAsync(c->d_taps + (size_t)first * SSDR_NTAP_MAX, taps.data(), taps.size() * sizeof(float),
                            hipMemcpyHostToDevice, c->stream));
@@ -670,13 +675,21 @@ int ssdr_sync(ssdr_ctx *c)
     if (!c) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->concurrent) HIP_TRY(hipStreamSynchronize(c->stream2));
+    if (c->concurrent || c->audio_pending) HIP_TRY(hipStreamSynchronize(c->stream2));
     return SSDR_OK;
 }
 
+// An audio stage that ran beside the waterfall kernel (stream2) and has not been joined yet: everything that follows on the
+// main stream and touches what it reads or writes (input, constants, state, PCM, RSSI, flags) waits for it first.
 static int join_audio(ssdr_ctx *c)
 {
     if (c->audio_pending) { HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_a, 0)); c->audio_pending = false; }
+    return SSDR_OK;
+}
+// ... and before a buffer it uses is freed on the host side
+static int drain_audio(ssdr_ctx *c)
+{
+    if (c->audio_pending) { HIP_TRY(hipStreamSynchronize(c->stream2)); c->audio_pending = false; }
     return SSDR_OK;
 }
 
@@ -860,6 +873,8 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
     if (!c) return SSDR_EINVAL;
     if (!c->have_input) return SSDR_ESTATE;
     HIP_TRY(hipSetDevice(c->device));
+    if (!c->concurrent) { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }      // the previous frame's state before this one
+    if (c->audio_frames < c->in_frames || c->flags_frames < c->in_frames) { int rcd = drain_audio(c); if (rcd != SSDR_OK) return rcd; }
     if (c->audio_frames < c->in_frames) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_pcm) { HIP_TRY(hipFree(c->d_pcm)); c->d_pcm = nullptr; }
@@ -895,6 +910,7 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         const bool any_iq = c->sum_any_iq;
         if (any_iq && c->feed.empty()) {          // (the pipelined feed hands out PCM rows only: an IQ channel's row carries I)
             if (c->iq_out_frames < c->in_frames) {
+                { int rcd = drain_audio(c); if (rcd != SSDR_OK) return rcd; }
                 HIP_TRY(hipStreamSynchronize(c->stream));
                 if (c->d_iq_out) { HIP_TRY(hipFree(c->d_iq_out)); c->d_iq_out = nullptr; }
                 c->iq_out_frames = 0;
@@ -1001,19 +1017,39 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
     const bool hop512 = c->hop == SSDR_NFFT / 2;            // (one line per frame: any frame count; hop 1024 needs whole lines)
     const bool eligible = n_am == c->n_ch && c->n_avg == 1 && c->decim == 1 && (hop512 || !(c->in_frames & 1u)) &&
                           c->in_frames >= 8 &&
-                          !c->concurrent && c->fused_grid != 0 && c->fused_enabled && !c->exact_bins && c->zoom == 1;
+                          !c->concurrent && c->fused_grid != 0 && c->fused_enabled >= (hop512 ? 2 : 1) && !c->exact_bins && c->zoom == 1;
     if (fused) *fused = eligible ? 1 : 0;
     c->fuse_next = eligible;
-    int rc = ssdr_run_wf(c, nullptr, lines_ready, 0);
-    if (rc == SSDR_OK) rc = ssdr_run_audio(c, nullptr, nullptr, 0);
+    // Everything else: the two stages side by side -- the audio stage on a second stream beside the waterfall kernel (one workgroup
+    // per CU then), each filling the issue slots the other leaves: +2.7 % on configs[3], +9 % on the full chain at hop 512
+    // (profiles/r04_ab_overlap.txt; there it beats the one-read kernel too, which is why that one is opt-in at hop 512)
+    const bool overlap = !eligible && c->overlap_enabled && !c->concurrent;
+    int rc;
+    if (overlap) {
+        // the audio stage first: its stream waits for what is queued so far (the input), not for the waterfall kernel that follows
+        c->concurrent = true;
+        rc = ssdr_run_audio(c, nullptr, nullptr, 0);
+        if (rc == SSDR_OK) rc = ssdr_run_wf(c, nullptr, lines_ready, 0);
+        c->concurrent = false;                       // (audio_pending stays set: whoever needs the results or the input joins first)
+    } else {
+        rc = ssdr_run_wf(c, nullptr, lines_ready, 0);
+        if (rc == SSDR_OK) rc = ssdr_run_audio(c, nullptr, nullptr, 0);
+    }
     c->fuse_next = false;
     return rc;
 }
 
 int ssdr_set_fused(ssdr_ctx *c, int on)
 {
+    if (!c || on < 0 || on > 2) return SSDR_EINVAL;
+    c->fused_enabled = on;
+    return SSDR_OK;
+}
+
+int ssdr_set_overlap(ssdr_ctx *c, int on)
+{
     if (!c) return SSDR_EINVAL;
-    c->fused_enabled = on != 0;
+    c->overlap_enabled = on != 0;
     return SSDR_OK;
 }
 
@@ -1085,6 +1121,7 @@ int ssdr_feed_close(ssdr_ctx *c)
     if (c->feed.empty()) return SSDR_OK;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     if (c->feed_s_in) (void)hipStreamSynchronize(c->feed_s_in);
     if (c->feed_s_out) (void)hipStreamSynchronize(c->feed_s_out);
     for (auto &s : c->feed) {
@@ -1212,6 +1249,7 @@ static int feed_submit_impl(ssdr_ctx *c, const void *host_in)
     uint32_t lines = 0;
     s.n_avg = c->n_avg;
     int rc = ssdr_run_chain(c, &lines, nullptr);           // the fused superframe kernel where the batch allows it
+    if (rc == SSDR_OK) rc = join_audio(c);                  // (or the two stages side by side: what follows reads both results)
     if (rc == SSDR_OK && c->feed_post) rc = [&]() -> int {
         // spectrum_db2col of this batch's lines and play_buffer of its frames, on the slot's buffers, in batch order
         s.n_post = c->n_post;
@@ -1385,6 +1423,7 @@ int ssdr_get_consts(ssdr_ctx *c, uint32_t first, uint32_t count, ssdr_chan_const
 {
     if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     if (consts) HIP_TRY(hipMemcpyAsync(consts, c->d_consts + first, count * sizeof(ssdr_chan_consts), hipMemcpyDeviceToHost, c->stream));
     if (taps) HIP_TRY(hipMemcpyAsync(taps, c->d_taps + (size_t)first * SSDR_NTAP_MAX, (size_t)count * SSDR_NTAP_MAX * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1395,6 +1434,7 @@ int ssdr_get_state(ssdr_ctx *c, uint32_t first, uint32_t count, ssdr_chan_state 
 {
     if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     if (state) HIP_TRY(hipMemcpyAsync(state, c->d_state + first, count * sizeof(ssdr_chan_state), hipMemcpyDeviceToHost, c->stream));
     if (hist) HIP_TRY(hipMemcpyAsync(hist, c->d_hist + (size_t)first * SSDR_HIST, (size_t)count * SSDR_HIST * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1405,6 +1445,7 @@ int ssdr_set_state(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan_
 {
     if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
     if (state) {
         HIP_TRY(hipMemcpyAsync(c->d_state + first, state, count * sizeof(ssdr_chan_state), hipMemcpyHostToDevice, c->stream));
         c->audio_started = true;             // a restored stream is live: ssdr_set_params must not re-seed its state
@@ -1986,6 +2027,7 @@ int ssdr_set_pcm(ssdr_ctx *c, const int16_t *pcm, uint32_t n_frames)
 {
     if (!c || !pcm || n_frames == 0) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
+    { int rcd = drain_audio(c); if (rcd != SSDR_OK) return rcd; }
     if (c->audio_frames < n_frames) {
         HIP_TRY(hipStreamSynchronize(c->stream));
         if (c->d_pcm) { HIP_TRY(hipFree(c->d_pcm)); c->d_pcm = nullptr; }

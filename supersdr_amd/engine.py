@@ -178,7 +178,12 @@ class SsdrEngine:
         return pcm, rssi
 
     def set_fused(self, on):
-        check(lib.ssdr_set_fused(self._ctx, int(bool(on))), "ssdr_set_fused")
+        """0 / False: never the fused superframe kernel; 1 / True (default): at hop 1024; 2: at hop 512 as well"""
+        check(lib.ssdr_set_fused(self._ctx, int(on)), "ssdr_set_fused")
+
+    def set_overlap(self, on):
+        """un-fused run_chain batches: the audio stage beside the waterfall kernel on a second stream (default on)"""
+        check(lib.ssdr_set_overlap(self._ctx, int(bool(on))), "ssdr_set_overlap")
 
     def run_chain(self):
         """both stages on the current batch, results left on the device -> (lines ready, fused?)"""

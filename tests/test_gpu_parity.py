@@ -1167,7 +1167,7 @@ def test_fused_kernel_at_hop_512_equals_the_two_kernels(S, twin, n_ch):
         with S.SsdrEngine(n_ch) as eng:
             eng.set_hop(512)
             eng.set_params(0, ps)
-            eng.set_fused(fused)
+            eng.set_fused(2 if fused else 0)           # (at hop 512 the one-read kernel is opt-in: the two stages side by side are faster)
             wfs, pcms, rssis, flags, pos = [], [], [], [], 0
             for nf in calls:
                 eng.push_iq(iq[:, pos * 512:(pos + nf) * 512])
@@ -1190,6 +1190,46 @@ def test_fused_kernel_at_hop_512_equals_the_two_kernels(S, twin, n_ch):
     assert np.array_equal(outs[True][1], pcm_t) and np.array_equal(outs[True][2], rssi_t) and np.array_equal(outs[True][3], flags_t)
     stream = np.concatenate([np.zeros((n_ch, 512, 2), np.int16), iq], axis=1)
     assert np.array_equal(outs[True][0], twin.wf_hop(stream, 512, 1, consts["wf_cal_lin"])) and outs[True][3].sum() == 1
+
+
+def test_run_chain_side_by_side_stages_are_bit_identical_and_joined_before_what_depends_on_them(S):
+    """Round 4: a batch ssdr_run_chain does not fuse runs its audio stage on a second stream beside the waterfall kernel
+    (ssdr_set_overlap, default on).  Same bytes as one after the other -- waterfall sums (N = 3 groups straddling calls, hop 512),
+    PCM, RSSI, flags, carried state, history, checksums -- with everything that depends on the audio stage issued right behind
+    the call: the next input, a parameter change, a state read-back, a reset of some channels, play_buffer, a checkpoint."""
+    from supersdr_amd._lib import PlayChan
+    n_ch, calls = 333, [6, 10, 3, 9, 12]
+    iq = O.synth_iq(n_ch, sum(calls) * 512, seed=404)
+    ps, _ = mixed_params(S, n_ch)
+    play = [PlayChan(100.0, 0.0)] * n_ch
+    outs = {}
+    for overlap in (0, 1):
+        with S.SsdrEngine(n_ch) as eng:
+            eng.set_overlap(overlap)
+            eng.set_hop(512)
+            eng.set_averaging(3)
+            eng.set_params(0, ps)
+            got, pos = [], 0
+            for i, nf in enumerate(calls):
+                eng.push_iq(iq[:, pos * 512:(pos + nf) * 512])
+                lines, fused = eng.run_chain()
+                assert not fused
+                if i == 1:
+                    eng.set_params(5, [S.default_params("cw", f_shift_hz=700.0)])        # right behind the launch
+                if i == 2:
+                    eng.reset_state(100, 7)
+                if i == 3:
+                    blob = eng.checkpoint()
+                got.append((eng.output_checksum(), eng.get_state()[0].tobytes()))
+                got.append(eng.fetch_wf(lines).copy())
+                got.append(eng.fetch_audio()[0].copy())
+                got.append(eng.audio_flags().copy())
+                got.append(eng.run_playbuffer(play)[:, :64].copy())
+                pos += nf
+            got.append(blob)
+        outs[overlap] = got
+    for a, b in zip(outs[0], outs[1]):
+        assert (a == b) if isinstance(a, (bytes, tuple)) else np.array_equal(a, b)
 
 
 # ------------------------------------------------------------------ round 3
