@@ -358,7 +358,7 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
         b = channels * sframes * (4096.0 + (2 if hop == 512 else 1) * 2048.0 + 2048.0)      # SURVEY.md 8d, fused budget at N = 1: 4096 in + 2048 per line + 2048 PCM out
         stages["fused"] = {"kernel": "ssdr_fused_am_kernel<%s>" % ("true" if hop == 512 else "false"), "avg_ms": avg, "launches": fu_n,
                            "bytes": b, "GBps": b / avg / 1e6, "units": channels * sframes}
-    side = bool(do_wf and do_audio and "fused" not in stages and (overlap or concurrent & 1))
+    side = bool(do_wf and do_audio and "fused" not in stages and ((overlap and not exact) or concurrent & 1))
     for st in stages.values():
         st["side_by_side"] = side                       # the two stages ran beside each other: their durations overlap
     return {"value": units / wall / RT_SUPERFRAMES_PER_S, "ms_per_step": wall / steps * 1e3, "stages": stages,
@@ -756,7 +756,7 @@ def main():
         run_extra("mixed_serial", "mixed", max(20, args.steps // 2), ", the two stages one after the other (--overlap 0): per-kernel durations and rooflines", overlap=0)
         # variants of the default workload that the design discusses, timed by the same run
         run_extra("full_two_kernels", "full", nst, ", the two per-stage kernels one after the other (--fused 0 --overlap 0)", fused=0, overlap=0)
-        run_extra("full_exact", "full", nst, ", float64 waterfall stage (--exact 1: bins equal the NumPy float64 path bit for bit) beside the audio stage", exact=1)
+        run_extra("full_exact", "full", nst, ", float64 waterfall stage (--exact 1: bins equal the NumPy float64 path bit for bit), then the audio stage", exact=1)
         run_extra("wf_exact_bins", "wf", nst, ", float64 waterfall stage (--exact 1)", exact=1)
         e = run_extra("wf_hop512", "wf", nst, ", hop 512 (23.4 lines/s)", hop=512)
         extra["wf_hop512"]["lines_per_s"] = e["stages"]["wf"]["lines_per_launch"] / e["ms_per_step"] * 1e3

@@ -1023,7 +1023,9 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
     // Everything else: the two stages side by side -- the audio stage on a second stream beside the waterfall kernel (one workgroup
     // per CU then), each filling the issue slots the other leaves: +2.7 % on configs[3], +9 % on the full chain at hop 512
     // (profiles/r04_ab_overlap.txt; there it beats the one-read kernel too, which is why that one is opt-in at hop 512)
-    const bool overlap = !eligible && c->overlap_enabled && !c->concurrent;
+    // (not with the float64 waterfall kernel: it fills the CUs' LDS by itself, and beside it the audio stage only gets in the way:
+    //  3.61 ms one after the other, 3.75 ms side by side)
+    const bool overlap = !eligible && c->overlap_enabled && !c->concurrent && !c->exact_bins;
     int rc;
     if (overlap) {
         // the audio stage first: its stream waits for what is queued so far (the input), not for the waterfall kernel that follows
