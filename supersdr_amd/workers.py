@@ -148,14 +148,14 @@ class IQHub:
     also runs spectrum_db2col and play_buffer (SSDR_FEED_POST) with the display state latched at submit.  Results arrive
     `depth - 1` superframes late (flush() drains) and are bit-identical to the synchronous hub's.
     `batch_superframes=K` runs K superframes per GPU call (K lines + 2K audio frames per channel and call): latency for
-    launch efficiency at very large channel counts.  `copy_threads=T` splits feed_block's copy of a large block over T threads.
+    launch efficiency at very large channel counts.  `copy_threads=T` splits feed_block's copy of a large block over T threads (default: up to 8 on hubs of 8192+ receivers).
     """
 
     LAZY_ABOVE = 1024
 
     def __init__(self, n_channels, device=0, engine=None, max_queue=64, gpu_post=True, kiwi_rate=12000, trace_rows=0,
                  backlog_superframes=8, stall_superframes=4, pipeline=False, depth=3, hop=1024, zoom=1, lazy=None,
-                 batch_superframes=1, wire=False, copy_threads=0):
+                 batch_superframes=1, wire=False, copy_threads=None):
         self.n_ch = int(n_channels)
         self.engine = engine if engine is not None else SsdrEngine(self.n_ch, device)
         # waterfall zoom ("SET zoom=", utils_supersdr.py:741, 839): the lines then span 1/zoom of the IQ band around each
@@ -190,6 +190,9 @@ class IQHub:
         # feed_block's one copy, split over a few threads when the block is large (NumPy copies outside the GIL): a single core moves
         # ~10-20 GB/s, a superframe of 10^5 receivers is 0.5 GB
         self._copy_pool = None
+        if copy_threads is None:                     # a hub of 10^4+ receivers moves hundreds of MB per superframe: a few threads by default
+            import os
+            copy_threads = min(8, max(1, (os.cpu_count() or 1) // 2)) if self.n_ch >= 8192 else 0
         if copy_threads and copy_threads > 1:
             from concurrent.futures import ThreadPoolExecutor
             self._copy_pool = ThreadPoolExecutor(int(copy_threads))

@@ -119,15 +119,25 @@ class TwinEngine:
     def playbuffer_frame_len(self):
         return 2048 if getattr(self, "kiwi_rate", 12000) == 12000 else 1213
 
+    def set_post_channels(self, channels=None):
+        """ssdr_set_post_channels: the post-processing works on these channels only, arrays in list order"""
+        self.post_sel = None if channels is None else [int(c) for c in channels]
+
+    def _post_list(self):
+        sel = getattr(self, "post_sel", None)
+        return list(range(self.n_ch)) if sel is None else sel
+
     def run_db2col(self, chans, n_lines):
-        out = np.empty((n_lines, self.n_ch, 1024), np.float32)
-        for c, k in enumerate(chans):
+        sel = self._post_list()
+        out = np.empty((n_lines, len(sel), 1024), np.float32)
+        for pos, k in enumerate(list(chans)[:len(sel)]):
+            c = sel[pos]
             for i in range(n_lines):
                 spec = self.last_wf[i, c].astype(np.float32) / np.float32(self.n_avg)
                 col, lo, hi, dyn, mn, mx = O.spectrum_db2col(
                     spec, int(k.zoom), auto=bool(k.auto_scale), low_clip_db=k.low_clip_db, high_clip_db=k.high_clip_db,
                     dynamic_range=k.dynamic_range, delta_low_db=k.delta_low_db, delta_high_db=k.delta_high_db)
-                out[i, c] = col
+                out[i, pos] = col
                 k.low_clip_db, k.high_clip_db, k.dynamic_range, k.wf_min_db, k.wf_max_db = lo, hi, dyn, mn, mx
         return out
 
@@ -137,12 +147,14 @@ class TwinEngine:
             self.players = [O.PlayBufferResampled() if wide else O.PlayBuffer() for _ in range(self.n_ch)]
         L = self.playbuffer_frame_len()
         nf = self.pcm.shape[1] // 512
-        out = np.empty((self.n_ch, nf * L, 2), np.int16)
-        self.mono = np.empty((self.n_ch, nf * L), np.int16)
-        for c, k in enumerate(chans):
+        sel = self._post_list()
+        out = np.empty((len(sel), nf * L, 2), np.int16)
+        self.mono = np.empty((len(sel), nf * L), np.int16)
+        for pos, k in enumerate(list(chans)[:len(sel)]):
+            c = sel[pos]
             for f in range(nf):
-                out[c, f * L:(f + 1) * L] = self.players[c](self.pcm[c, f * 512:(f + 1) * 512], k.volume, k.balance)
-                self.mono[c, f * L:(f + 1) * L] = self.players[c].rec
+                out[pos, f * L:(f + 1) * L] = self.players[c](self.pcm[c, f * 512:(f + 1) * 512], k.volume, k.balance)
+                self.mono[pos, f * L:(f + 1) * L] = self.players[c].rec
         return out
 
     def close(self):
@@ -958,3 +970,48 @@ def test_start_audio_stream_opens_the_bound_worker_at_both_rates(ref, rate, monk
         kw["callback"](out, L, None, None)
         assert np.array_equal(out, player(pcm[0, f * 512:(f + 1) * 512], volume=snd.volume, balance=snd.audio_balance)), f
     snd.terminate = True                                           # the run thread ends with its next frame (or its queue time-out)
+
+
+def test_lazy_hub_post_processes_its_listeners_only_and_they_see_what_they_always_saw(gpu):
+    """the hub side of ssdr_set_post_channels on the CPU (engine double): a lazy hub names the channels with workers to the
+    engine, keeps its display-state arrays in that order, and the workers get the same colours, clip levels and 48 kHz blocks
+    as on a hub that post-processes everybody -- also after a third worker attaches mid-stream and one leaves."""
+    from supersdr_amd.workers import IQHub
+    n_ch = 9
+    iq = O.synth_iq(n_ch, 6 * 1024, seed=91)
+    seen = {}
+    for lazy in (False, True):
+        eng = TwinEngine(n_ch)
+        hub = IQHub(n_ch, engine=eng, lazy=lazy)
+        wfs = {c: gpu.kiwi_waterfall("gpu", 0, "", 6 + c, 7100.0, Eibi(), Disp(), hub=hub, channel=c, timeout=0.2) for c in (2, 7)}
+        snds = {c: gpu.kiwi_sound(7100.0, "AM", -6000, 6000, "", wfs[c], 8) for c in (2, 7)}
+        snds[7].volume, snds[7].audio_balance = 140, -0.5
+        got = []
+        for k in range(6):
+            if k == 3:                                             # a third listener arrives, one leaves
+                wfs[4] = gpu.kiwi_waterfall("gpu", 0, "", 3, 7100.0, Eibi(), Disp(), hub=hub, channel=4, timeout=0.2)
+                snds[4] = gpu.kiwi_sound(7100.0, "AM", -6000, 6000, "", wfs[4], 8)
+                hub.wf_clients[2] = None
+                hub.snd_clients[2] = None
+                if not lazy:                                       # (a hub that queues for everybody holds channel 4's earlier lines, made
+                    while hub.wf_queue[4].qsize():                 #  before anybody looked: a viewer that arrives now starts with the next one)
+                        hub.wf_queue[4].get_nowait()
+                    while hub.snd_queue[4].qsize():
+                        hub.snd_queue[4].get_nowait()
+            hub.feed_block(0, iq[:, k * 1024:(k + 1) * 1024])
+            if lazy:
+                assert hub.post_channels == ([2, 7] if k < 3 else [4, 7]) and eng.post_sel == hub.post_channels
+                assert hub.last.color.shape[1] == 2 and hub.last.play.shape[0] == 2
+            for c in ((7,) if k < 3 else (4, 7)):
+                wfs[c].step()
+                got.append((wfs[c].wf_color.copy(), wfs[c].wf_min_db, wfs[c].wf_max_db))
+                for f in range(2):
+                    fr = snds[c].process_audio_stream()
+                    # (a listener's very first block starts from play_buffer's zero history, utils_supersdr.py:1005, on the lazy hub -- as a
+                    #  new kiwi_sound does -- and from three superframes of history on the hub that interpolated for nobody: not compared)
+                    first_block = c == 4 and k == 3 and f == 0
+                    got.append((np.asarray(fr).copy(), fr.play_block[64:].copy() if first_block else fr.play_block.copy()))
+        seen[lazy] = got
+    assert len(seen[False]) == len(seen[True]) > 20
+    for a, b in zip(seen[False], seen[True]):
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
