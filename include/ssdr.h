@@ -181,8 +181,8 @@ int ssdr_audio_iq(ssdr_ctx *ctx, int16_t *iq_out, int out_is_device);
  * Every other batch runs the two stages side by side on two streams (ssdr_set_overlap).  The pipelined feed (ssdr_feed_*)
  * runs its batches through this call. */
 int ssdr_run_chain(ssdr_ctx *ctx, uint32_t *lines_ready, int *fused);
-/* 0: never the fused kernel; 1 (default): at hop 1024; 2: at hop 512 as well (there the two stages side by side are faster:
- * ssdr_set_overlap) */
+/* 0: never the fused kernel; 1 (default): at hop 1024 with N = 1; 2: at hop 512 and with N > 1 as well (there the two stages side
+ * by side are as fast or faster: ssdr_set_overlap) */
 int ssdr_set_fused(ssdr_ctx *ctx, int on);
 /* Batches ssdr_run_chain does not fuse (mixed modes, N > 1, hop 512, float64 bins, ...) run their two stages SIDE BY SIDE: the audio
  * stage on a second HIP stream beside the waterfall kernel, both reading the same input batch (default on; results are those of

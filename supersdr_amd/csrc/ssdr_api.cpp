@@ -1015,9 +1015,10 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
     // rate (hop 1024, or hop 512 = the reference's 23 lines/s); from eight frames per call on (a wave sets a channel pair's
     // carried state up once per call: measured ahead from there)
     const bool hop512 = c->hop == SSDR_NFFT / 2;            // (one line per frame: any frame count; hop 1024 needs whole lines)
-    const bool eligible = n_am == c->n_ch && c->n_avg == 1 && c->decim == 1 && (hop512 || !(c->in_frames & 1u)) &&
+    // (N > 1 and hop 512 are opt-in, ssdr_set_fused(ctx, 2): there the two stages side by side are faster)
+    const bool eligible = n_am == c->n_ch && c->decim == 1 && (hop512 || !(c->in_frames & 1u)) &&
                           c->in_frames >= 8 &&
-                          !c->concurrent && c->fused_grid != 0 && c->fused_enabled >= (hop512 ? 2 : 1) && !c->exact_bins && c->zoom == 1;
+                          !c->concurrent && c->fused_grid != 0 && c->fused_enabled >= ((hop512 || c->n_avg > 1) ? 2 : 1) && !c->exact_bins && c->zoom == 1;
     if (fused) *fused = eligible ? 1 : 0;
     c->fuse_next = eligible;
     // Everything else: the two stages side by side -- the audio stage on a second stream beside the waterfall kernel (one workgroup

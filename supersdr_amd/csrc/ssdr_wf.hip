@@ -550,7 +550,9 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
 // HOP (round 4): the waterfall at the reference's line rate (hop 512, utils_supersdr.py:597, 742).  A step is then one half-line:
 // the 512 new samples of each channel are its next audio frame, and the line is the previous half (re-read -- the wave fetched
 // it one step earlier, and only that read is left to the L2: plain load, everything else streams) followed by the new one.
-template <bool HOP>
+// AVG (round 4): time binning N > 1 -- the wave owns its channel pair for the whole call, so the N-line sums stay in 16 registers
+// per lane across the lines of a group (carry in / out of partial groups as in ssdr_wf_kernel<true, .>).
+template <bool HOP, bool AVG = false>
 __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fused_am_kernel(SsdrFusedArgs fa)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];
@@ -597,6 +599,9 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
 
         const uint32_t *src = a.iq + (uint64_t)ch * a.ch_stride + l;
         uint32_t last_raw31 = 0;
+        uint32_t acc[AVG ? 16 : 1];                            // AVG: sums of the group's lines so far (two bins per register)
+#pragma unroll
+        for (int j = 0; j < (AVG ? 16 : 1); j++) acc[j] = 0;
         constexpr uint32_t LINE_STEP = HOP ? SSDR_NFFT / 2 : SSDR_NFFT;
         constexpr int FRAMES_PER_LINE = HOP ? 1 : 2;
         for (uint32_t line = 0; line < a.n_lines; line++, src += LINE_STEP) {
@@ -701,24 +706,41 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
             window_line(raw, smem, l, z);
             SCHED_FENCE();
             fft_line<true>(z, smem, xch_wave, h, l);          // the averaging kernel's twiddle schedule: fewer registers in flight
-            quantise32(z, cal_wf, lut, [&](int j, uint32_t q01) { qn[j] = q01; });
+            if (AVG) quantise32(z, cal_wf, lut, [&](int j, uint32_t q01) { acc[j] += q01; });
+            else quantise32(z, cal_wf, lut, [&](int j, uint32_t q01) { qn[j] = q01; });
 #endif
-            float *xch = xch_wave + opaque(h) * XCH_FLOATS;
-            int16_t *x16 = reinterpret_cast<int16_t *>(xch) + opaque(l);
+            // AVG: line `line` is line (phase + line) of the stream of groups; a group leaves when its N-th line is in, the last
+            // (partial) one of the call goes to acc_out
+            const uint32_t pos = a.phase + line;
+            const bool group_done = !AVG || (pos + 1) % a.n_avg == 0;
+            const bool last_line = line + 1 == a.n_lines;
+            if (group_done || last_line) {
+                float *xch = xch_wave + opaque(h) * XCH_FLOATS;
+                int16_t *x16 = reinterpret_cast<int16_t *>(xch) + opaque(l);
 #pragma unroll
-            for (int j = 0; j < 16; j++) {
-                x16[32 * (j + 16)] = (int16_t)(qn[j] & 0xFFFFu);
-                x16[32 * j] = (int16_t)(qn[j] >> 16);
-            }
-            wave_lds_sync();
-            const u32x4 *x128 = reinterpret_cast<const u32x4 *>(xch);
-            int16_t *dst = a.out + ((uint64_t)line * a.n_ch + ch) * SSDR_NFFT;
+                for (int j = 0; j < 16; j++) {
+                    const uint32_t v = AVG ? acc[j] : qn[j];
+                    x16[32 * (j + 16)] = (int16_t)(v & 0xFFFFu);
+                    x16[32 * j] = (int16_t)(v >> 16);
+                }
+                wave_lds_sync();
+                const u32x4 *x128 = reinterpret_cast<const u32x4 *>(xch);
+                const uint32_t grp = AVG ? pos / a.n_avg : line;
+                int16_t *dst = group_done ? a.out + ((uint64_t)grp * a.n_ch + ch) * SSDR_NFFT : a.acc_out + (uint64_t)ch * SSDR_NFFT;
+                const bool carry_in = AVG && grp == 0 && a.phase != 0;           // wave-uniform
+                const int16_t *cin = a.acc_in + (uint64_t)ch * SSDR_NFFT;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const u32x4 v = x128[q * 32 + l];
-                if (ch_ok) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst) + q * 32 + l);
+                for (int q = 0; q < 4; q++) {
+                    u32x4 v = x128[q * 32 + l];
+                    if (carry_in) v += reinterpret_cast<const u32x4 *>(cin)[q * 32 + l];      // sums stay < 2^15: a packed 2 x 16 add
+                    if (ch_ok) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst) + q * 32 + l);
+                }
+                wave_lds_sync();
+                if (AVG) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) acc[j] = 0;
+                }
             }
-            wave_lds_sync();
         }
 
         // ---- state back to HBM
@@ -799,17 +821,25 @@ hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream
 
 hipError_t ssdr_launch_fused_am(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream)
 {
-    if (a.wf.tail) hipLaunchKernelGGL(ssdr_fused_am_kernel<true>, dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
-    else hipLaunchKernelGGL(ssdr_fused_am_kernel<false>, dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
+    if (a.wf.n_avg > 1) {
+        if (a.wf.tail) hipLaunchKernelGGL((ssdr_fused_am_kernel<true, true>), dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((ssdr_fused_am_kernel<false, true>), dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
+    } else {
+        if (a.wf.tail) hipLaunchKernelGGL((ssdr_fused_am_kernel<true, false>), dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
+        else hipLaunchKernelGGL((ssdr_fused_am_kernel<false, false>), dim3(grid), dim3(SSDR_WF_BLOCK), 0, stream, a);
+    }
     return hipGetLastError();
 }
 
 hipError_t ssdr_fused_blocks_per_cu(int *blocks)
 {
-    int b0 = 0, b1 = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b0, ssdr_fused_am_kernel<false>, SSDR_WF_BLOCK, 0);
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, ssdr_fused_am_kernel<true>, SSDR_WF_BLOCK, 0);
-    *blocks = b0 < b1 ? b0 : b1;
+    int b[4] = {0, 0, 0, 0};
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b[0], ssdr_fused_am_kernel<false, false>, SSDR_WF_BLOCK, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b[1], ssdr_fused_am_kernel<true, false>, SSDR_WF_BLOCK, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b[2], ssdr_fused_am_kernel<false, true>, SSDR_WF_BLOCK, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b[3], ssdr_fused_am_kernel<true, true>, SSDR_WF_BLOCK, 0);
+    *blocks = b[0];
+    for (int i = 1; i < 4; i++) *blocks = b[i] < *blocks ? b[i] : *blocks;
     return e;
 }
 

@@ -1192,6 +1192,36 @@ def test_fused_kernel_at_hop_512_equals_the_two_kernels(S, twin, n_ch):
     assert np.array_equal(outs[True][0], twin.wf_hop(stream, 512, 1, consts["wf_cal_lin"])) and outs[True][3].sum() == 1
 
 
+@pytest.mark.parametrize("hop", [1024, 512])
+def test_fused_kernel_with_time_binning_equals_the_two_kernels(S, hop):
+    """ssdr_fused_am_kernel<., AVG = true> (round 4, opt-in: ssdr_set_fused(ctx, 2)): N = 3 sums kept in registers across the lines
+    a wave walks, groups straddling the calls both ways -- bit-identical to the two kernels (waterfall sums, PCM, state)."""
+    n_ch, calls = 7, [8, 10, 12, 9 if hop == 512 else 14]
+    iq = O.synth_iq(n_ch, sum(calls) * 512, seed=77)
+    outs = {}
+    for f in (0, 2):
+        with S.SsdrEngine(n_ch) as eng:
+            eng.set_hop(hop)
+            eng.set_averaging(3)
+            eng.set_fused(f)
+            got, pos = [], 0
+            for nf in calls:
+                eng.push_iq(iq[:, pos * 512:(pos + nf) * 512])
+                lines, was = eng.run_chain()
+                assert was == (f == 2)
+                got += [eng.fetch_wf(lines).copy(), eng.fetch_audio()[0].copy()]
+                pos += nf
+            got.append(eng.get_state()[0].tobytes())
+        outs[f] = got
+    assert sum(len(g) for g in outs[2][:-1:2]) == (sum(calls) // 3 if hop == 512 else sum(calls) // 2 // 3)
+    for a, b in zip(outs[0], outs[2]):
+        assert (a == b) if isinstance(a, bytes) else np.array_equal(a, b)
+    with S.SsdrEngine(2) as eng:                            # the default (1) keeps N > 1 on the two kernels side by side
+        eng.set_averaging(3)
+        eng.push_iq(O.synth_iq(2, 8 * 512, seed=1))
+        assert eng.run_chain()[1] is False
+
+
 def test_run_chain_side_by_side_stages_are_bit_identical_and_joined_before_what_depends_on_them(S):
     """Round 4: a batch ssdr_run_chain does not fuse runs its audio stage on a second stream beside the waterfall kernel
     (ssdr_set_overlap, default on).  Same bytes as one after the other -- waterfall sums (N = 3 groups straddling calls, hop 512),
