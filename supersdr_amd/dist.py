@@ -24,6 +24,24 @@ def channel_block(rank, world, total_channels):
     return first, base + (1 if rank < extra else 0)
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """file descriptor 1 -> 2 for the duration (native libraries that print to stdout)"""
+    import sys
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
 class Rendezvous:
     """barrier() and max_over_ranks() for the bench; a no-op world of one needs no process group."""
 
@@ -41,9 +59,9 @@ class Rendezvous:
                 kw = {}
                 if backend == "nccl" and device is not None:
                     kw["device_id"] = device
-                dist.init_process_group(backend=backend, **kw)
-                if backend == "nccl":
-                    dist.barrier()                    # forces communicator creation now, not inside the timed region
+                with _stdout_to_stderr():             # (gloo announces its peers on stdout: the bench's stdout is ONE JSON line)
+                    dist.init_process_group(backend=backend, **kw)
+                    dist.barrier()                    # forces communicator / connection creation now, not inside the timed region
             except Exception as e:
                 # The rendezvous carries no data (a barrier and a few scalars): if RCCL cannot come up, gloo does the
                 # same job over TCP and the measurement is unaffected -- but it is said, loudly, and it is in the JSON.
@@ -56,7 +74,9 @@ class Rendezvous:
                 if dist.is_initialized():
                     dist.destroy_process_group()
                 self.backend = backend = "gloo"
-                dist.init_process_group(backend="gloo")
+                with _stdout_to_stderr():
+                    dist.init_process_group(backend="gloo")
+                    dist.barrier()
             self._dist = dist
 
     def barrier(self):
