@@ -160,6 +160,22 @@ def cpu_baseline(workload, budget_s=5.0):
     with ThreadPoolExecutor(cores) as ex:
         list(ex.map(work, [block] * cores))
     wall = time.perf_counter() - t0
+    # ---- SURVEY.md 8f on this host: the oracle's restatements of spectrum_db2col and play_buffer (NumPy / SciPy, what the reference runs),
+    #      one core, next to extra.post
+    rng = np.random.default_rng(3)
+    lines = rng.integers(60, 200, (200, 1024)).astype(np.float32)
+    t0 = time.perf_counter()
+    for ln in lines:
+        O.spectrum_db2col(ln, 0)
+    db_us = (time.perf_counter() - t0) / len(lines) * 1e6
+    frames = rng.integers(-20000, 20000, (400, 512)).astype(np.int16)
+    pb = O.PlayBuffer()
+    t0 = time.perf_counter()
+    for fr in frames:
+        pb(fr, volume=100, balance=0.0)
+    pb_us = (time.perf_counter() - t0) / len(frames) * 1e6
+    out["post"] = {"spectrum_db2col_us_per_line": round(db_us, 1), "play_buffer_us_per_frame": round(pb_us, 1), "cores": 1, "kind": "port",
+                   "sample": "200 lines / 400 frames, oracle/ssdr_oracle.py restatements of utils_supersdr.py:787-813, 1106-1148"}
     out["c_twin"] = {"value": nch_core * cores * sf / wall / RT_SUPERFRAMES_PER_S, "unit": "rt_channels", "cores": cores,
                      "kind": "port",
                      "sample": "%d ch x %d superframes per thread on %d threads, oracle/ssdr_twin.c (fp32 C port), %.1f s"
