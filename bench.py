@@ -752,7 +752,19 @@ def main():
             b = ch * sf * (4096.0 + (2 if hop == 512 else 1) * 2048.0 / navg + 2048.0)
             return {"chain_GBps": b / e["ms_per_step"] / 1e6, "chain_frac": b / e["ms_per_step"] / 1e6 / HBM_PEAK_GBPS}
 
+        def guarded(key, fn):
+            """an extra that fails (memory, a box without 8 GiB to pin, ...) is reported, not fatal: the main measurement stands"""
+            try:
+                return fn()
+            except Exception as ex:                                  # noqa: BLE001
+                extra[key] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+                print("bench.py: extra.%s failed: %r" % (key, ex), file=sys.stderr, flush=True)
+                return None
+
         def run_extra(key, wl, nsteps, text="", warm=2, spin=0.5, **kw):
+            return guarded(key, lambda: run_extra_(key, wl, nsteps, text, warm, spin, **kw))
+
+        def run_extra_(key, wl, nsteps, text="", warm=2, spin=0.5, **kw):
             ch, sf = WORKLOADS[wl][0], WORKLOADS[wl][1]
             e = measure(S, L, torch, rdv, rank, world, local_rank, wl, ch, sf, nsteps, warm, spin, **kw)
             tr, tsrc = pmc_traffic(wl, ch, sf, kw.get("hop", 1024))
@@ -775,26 +787,35 @@ def main():
         run_extra("full_exact", "full", nst, ", float64 waterfall stage (--exact 1: bins equal the NumPy float64 path bit for bit), then the audio stage", exact=1)
         run_extra("wf_exact_bins", "wf", nst, ", float64 waterfall stage (--exact 1)", exact=1)
         e = run_extra("wf_hop512", "wf", nst, ", hop 512 (23.4 lines/s)", hop=512)
-        extra["wf_hop512"]["lines_per_s"] = e["stages"]["wf"]["lines_per_launch"] / e["ms_per_step"] * 1e3
+        if e is not None:
+            extra["wf_hop512"]["lines_per_s"] = e["stages"]["wf"]["lines_per_launch"] / e["ms_per_step"] * 1e3
         run_extra("full_hop512", "full", nst, ", waterfall at hop 512 (23.4 lines/s, the reference's line rate), the two stages side by side", hop=512)
         # configs[4] at N = 1 (2^20 channels on this one GPU, 16 superframes per call) and the decimating front end
         run_extra("million", "million", 5, warm=1, spin=0.3)
         run_extra("decim4", "decim4", nst, warm=1, spin=0.3)
         # the reference's own post-processing on the GPU, next to the reference's own timings
-        post = measure_post(S, L, local_rank)
-        extra["post"] = {"workload": "spectrum_db2col / play_buffer (x4 and 64/27) / IQ wire unpack on the results of a 65536-channel x 16-superframe chain run",
-                         "rooflines": [note("post." + k, v) for k, v in post.items()],
-                         "reference_cpu": {v["kernel"]: v["reference_cpu"] for v in post.values() if "reference_cpu" in v}}
+        def post_extra():
+            post = measure_post(S, L, local_rank)
+            extra["post"] = {"workload": "spectrum_db2col / play_buffer (x4 and 64/27) / IQ wire unpack on the results of a 65536-channel x 16-superframe chain run",
+                             "rooflines": [note("post." + k, v) for k, v in post.items()],
+                             "reference_cpu": {v["kernel"]: v["reference_cpu"] for v in post.values() if "reference_cpu" in v}}
+        guarded("post", post_extra)
         # the product's own ingest API in front of the pipelined feed (PCIe-inclusive, never `value`)
         if args.host_feed_extra:
-            extra["hub_feed"] = {k: measure_hub(S, L, torch, local_rank, 65536, 16, 2, in_place=ip, copy_threads=ct)
-                                 for k, ip, ct in (("feed_block", False, 0), ("feed_block_8_threads", False, 8), ("in_place", True, 0))}
+            def hub_extra():
+                extra["hub_feed"] = {k: measure_hub(S, L, torch, local_rank, 65536, 16, 2, in_place=ip, copy_threads=ct)
+                                     for k, ip, ct in (("feed_block", False, 0), ("feed_block_8_threads", False, 8), ("in_place", True, 0))}
+            guarded("hub_feed", hub_extra)
         full["extra"] = extra
     full["roofline"]["stages"] = summary
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            full["cpu_baseline"] = cpu_baseline(args.workload)
+            try:
+                full["cpu_baseline"] = cpu_baseline(args.workload)
+            except Exception as ex:                                      # noqa: BLE001  (a box that cannot start 256 workers still reports its GPU line)
+                full["cpu_baseline"] = {"value": None, "unit": "rt_channels", "cores": os.cpu_count() or 1, "kind": "port",
+                                        "sample": "FAILED: %s: %s" % (type(ex).__name__, str(ex)[:200])}
         if args.record:
             with open(args.record, "w") as f:
                 json.dump(full, f, indent=1)
@@ -831,7 +852,9 @@ def compact_line(full):
     if "extra" in full:
         out["extra"] = {}
         for k, v in full["extra"].items():
-            if "value" in v:
+            if "error" in v:
+                out["extra"][k] = {"error": v["error"]}
+            elif "value" in v:
                 out["extra"][k] = {kk: (round(v[kk], 4) if isinstance(v[kk], float) else v[kk]) for kk in ("value", "ms_per_step", "chain_frac") if kk in v}
             elif k == "hub_feed":
                 out["extra"][k] = {kk: {"value": vv["value"], "ms_per_superframe": round(vv["ms_per_superframe"], 3)} for kk, vv in v.items()}
