@@ -780,8 +780,8 @@ def main():
         nst = max(20, args.steps // 3)
         # configs[1] and configs[3] in the same driver-timed line: shorter runs, each with its own rooflines
         run_extra("wf", "wf", max(20, args.steps // 2))
-        run_extra("mixed", "mixed", max(20, args.steps // 2), ", the two stages side by side (ssdr_run_chain's default for what it does not fuse)")
-        run_extra("mixed_serial", "mixed", max(20, args.steps // 2), ", the two stages one after the other (--overlap 0): per-kernel durations and rooflines", overlap=0)
+        run_extra("mixed", "mixed", max(60, args.steps // 2), ", the two stages side by side (ssdr_run_chain's default for what it does not fuse)", spin=1.0)
+        run_extra("mixed_serial", "mixed", max(60, args.steps // 2), ", the two stages one after the other (--overlap 0): per-kernel durations and rooflines", spin=1.0, overlap=0)
         # variants of the default workload that the design discusses, timed by the same run
         run_extra("full_two_kernels", "full", nst, ", the two per-stage kernels one after the other (--fused 0 --overlap 0)", fused=0, overlap=0)
         run_extra("full_exact", "full", nst, ", float64 waterfall stage (--exact 1: bins equal the NumPy float64 path bit for bit), then the audio stage", exact=1)
