@@ -77,8 +77,8 @@ KERNEL_VALU = {
     "ssdr_audio_kernel<0>": ("frame", 832.6, 0.75),
     "ssdr_audio_kernel<1>": ("frame", 579.2, 0.42),
     "ssdr_audio_kernel<2>": ("frame", 241, 0.22),
-    "ssdr_fused_am_kernel<false>": ("channel-superframe", 1077.2, 0.45),
-    "ssdr_fused_am_kernel<true>": ("channel-superframe", 1658.0, 0.50),
+    "ssdr_fused_am_kernel<false, false>": ("channel-superframe", 1077.2, 0.45),
+    "ssdr_fused_am_kernel<true, false>": ("channel-superframe", 1658.0, 0.50),
     "ssdr_audio_dec_kernel<4>": ("frame", 2682, 0.85),
 }
 
@@ -372,7 +372,8 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     if fu_n:
         avg = fu_ms / fu_n
         b = channels * sframes * (4096.0 + (2 if hop == 512 else 1) * 2048.0 + 2048.0)      # SURVEY.md 8d, fused budget at N = 1: 4096 in + 2048 per line + 2048 PCM out
-        stages["fused"] = {"kernel": "ssdr_fused_am_kernel<%s>" % ("true" if hop == 512 else "false"), "avg_ms": avg, "launches": fu_n,
+        stages["fused"] = {"kernel": "ssdr_fused_am_kernel<%s, %s>" % ("true" if hop == 512 else "false", "true" if n_avg > 1 else "false"),
+                           "avg_ms": avg, "launches": fu_n,
                            "bytes": b, "GBps": b / avg / 1e6, "units": channels * sframes}
     side = bool(do_wf and do_audio and "fused" not in stages and ((overlap and not exact) or concurrent & 1))
     for st in stages.values():
@@ -523,7 +524,7 @@ def stage_traffic(traffic, stage):
     bare = {}                                      # a kernel named without its template arguments: the one instance that was profiled
     for k, v in traffic.items():
         bare.setdefault(k.split("<")[0], []).append(v)
-    vals = [traffic.get(n, bare.get(n, [None])[0] if len(bare.get(n, [])) == 1 else None) for n in names]
+    vals = [traffic.get(n, bare[n.split("<")[0]][0] if len(bare.get(n.split("<")[0], [])) == 1 else None) for n in names]
     return sum(vals) if vals and all(v is not None for v in vals) else None
 
 
