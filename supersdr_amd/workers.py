@@ -148,14 +148,14 @@ class IQHub:
     also runs spectrum_db2col and play_buffer (SSDR_FEED_POST) with the display state latched at submit.  Results arrive
     `depth - 1` superframes late (flush() drains) and are bit-identical to the synchronous hub's.
     `batch_superframes=K` runs K superframes per GPU call (K lines + 2K audio frames per channel and call): latency for
-    launch efficiency at very large channel counts.  `copy_threads=T` splits feed_block's copy of a large block over T threads (default: up to 8 on hubs of 8192+ receivers).
+    launch efficiency at very large channel counts.  `exact_bins=True`: the waterfall stage in float64 (ssdr_set_exact_bins).  `copy_threads=T` splits feed_block's copy of a large block over T threads (default: up to 8 on hubs of 8192+ receivers).
     """
 
     LAZY_ABOVE = 1024
 
     def __init__(self, n_channels, device=0, engine=None, max_queue=64, gpu_post=True, kiwi_rate=12000, trace_rows=0,
                  backlog_superframes=8, stall_superframes=4, pipeline=False, depth=3, hop=1024, zoom=1, lazy=None,
-                 batch_superframes=1, wire=False, copy_threads=None):
+                 batch_superframes=1, wire=False, copy_threads=None, exact_bins=False):
         self.n_ch = int(n_channels)
         self.engine = engine if engine is not None else SsdrEngine(self.n_ch, device)
         # waterfall zoom ("SET zoom=", utils_supersdr.py:741, 839): the lines then span 1/zoom of the IQ band around each
@@ -169,6 +169,8 @@ class IQHub:
         self._sf = L.NFFT * self.zoom * self.batch_superframes       # samples per channel and GPU run
         if hop != L.NFFT:                            # 512: two waterfall lines per superframe, 23.4 lines/s (MAX_FPS = 23, utils:597)
             self.engine.set_hop(hop)
+        if exact_bins:                               # the waterfall stage in float64: lines equal the NumPy float64 path bit for bit
+            self.engine.set_exact_bins(True)
         # spectrum_db2col and play_buffer run on the GPU with every superframe
         self.gpu_post = bool(gpu_post)
         # kiwi_sound.KIWI_RATE as the server announces it (:988-994): the rate of the IQ the channels receive (12000, or 20250 from
