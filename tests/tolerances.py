@@ -1,55 +1,81 @@
-"""The north_star audio tolerance (PCM within 1e-5 RMS of full scale vs the float64 oracle) and the conditioning rule it
-is asserted under -- one statement, used by the CPU sweep (twin vs oracle) and the GPU sweeps (kernels vs oracle).
+"""The north_star audio tolerance (PCM within 1e-5 RMS of full scale vs the float64 oracle) and the condition it is
+asserted under -- one statement, used by the CPU sweep (twin vs oracle) and the GPU sweeps (kernels vs oracle).
 
-fp32 conditioning: the chain's roundings sit ~140 dB under the INPUT level, so what is left of a signal that the
-channel filter takes 40+ dB down (out-of-band carrier, narrow passband) is only known to ~1e-4 relative, and the FM
-discriminator turns that straight into phase.  Rule:
-  * a channel is WELL CONDITIONED when its filtered power (the oracle's RSSI) stays within 40 dB of its input power in
-    every frame;
-  * every well-conditioned channel -- all of them, no best-of selection -- must meet 1e-5 RMS of full scale UNTRIMMED
-    (every sample counted); the one exception is stated: an NBFM channel may reach 5e-5 untrimmed, and must then meet
-    1e-5 once its 0.5 % largest sample deviations are set aside -- the discriminator takes the phase of samples whose
-    filtered magnitude passes through zero (a burst at the rails, a deep AM trough), where 1e-7 relative in I and Q is
-    radians in the output; measured: one such channel in five sweeps, 1.8e-5 with a largest deviation of 25 LSB;
-  * at least three quarters of a sweep's channels must be well conditioned (the draw of tests/random_params.py gives 75-96 %);
-  * every channel, conditioned or not, must stay within 1e-3 RMS.
-The untrimmed figures are reported (REPORT, printed with pytest -s) next to the trimmed ones.
+An fp32 chain cannot be within 1e-5 of full scale of the float64 chain on EVERY input: the channel filter takes an
+out-of-band carrier 60 dB down and what is left is only known to 2^-24 of the INPUT; the FM discriminator takes the
+phase of samples whose magnitude passes through zero; 99 dB of manual gain behind an AM detector amplifies the
+cancellation of envelope and DC estimate.  Instead of excusing such channels by hand (rounds 1-3 did: a 40 dB rule, an
+NBFM exception, a trimmed RMS -- and a 120-seed soak then found 3 % of sweeps outside it), the rule is the numerical
+analyst's: the kernels must be a BACKWARD-STABLE evaluation of the float64 chain.
+
+  * The oracle propagates, per output sample, what a relative error EPS in the channel filter's sums does to ITS OWN
+    output, to first order (oracle/ssdr_oracle.py: AudioChannel.error_sensitivity -- the dot-product bound
+    sum |h||z| through envelope / product detector / discriminator incl. its branch cut / AGC gain law / int16 clip):
+    bound[ch, n], in LSB.
+  * EPS = 2^-20 = 16 units of fp32 roundoff (the classical bound for a 127-tap sum alone is 127 u).
+  * EVERY sample of EVERY channel:   |pcm - pcm_oracle| <= 1 LSB + bound             (1 LSB: the two roundings to int16)
+  * EVERY channel:                   RMS(pcm - pcm_oracle) <= sqrt(1e-5^2 + RMS(bound)^2)   of full scale
+  * a channel is WELL CONDITIONED when RMS(bound) <= 1e-5 of full scale (1/3 LSB: the float64 chain itself moves by
+    less than the tolerance under that perturbation); every well-conditioned channel must meet the plain north_star
+    figure, 1e-5 RMS UNTRIMMED -- no per-mode exception.  So that this says something, a sweep must hold its share of
+    well-conditioned channels: the draw of tests/random_params.py gives 84 %; a sweep of n channels must have at least
+    0.8 n - 4 sqrt(0.16 n) of them (four standard deviations under 80 %: 61 of 96, 11 of 24).
+
+Calibration (tools/soak_parity.py, profiles/r04_soak_parity.txt): 600 sweeps x 96 channels x 3072 samples of
+tests/random_params.py: the largest EPS any sample needed was 2^-21.3; 83 % (AM/SSB/CW) and 90 % (NBFM) of the channels
+are well conditioned, their largest untrimmed RMS deviation is 5.2e-6.
+The figures of each sweep are kept in REPORT (printed with pytest -s).
 """
 import numpy as np
 
+from oracle import ssdr_oracle as O
+
 PCM_RMS_TOL = 1e-5
-NBFM_UNTRIMMED_TOL = 5e-5
-LOOSE_TOL = 1e-3
-MIN_WELL_FRACTION = 0.75
-REPORT = []                     # one dict per sweep: what was measured, trimmed and untrimmed
+EPS = 2.0 ** -20
+WELL_FRACTION = 0.8            # of a random sweep, expected (measured: 0.84); min_well_for(n) is four sigma under it
+REPORT = []                     # one dict per sweep
 
 
-def well_conditioned(iq, rssi_o, smeter_cal_db):
-    """iq int16 [n_ch, n, 2]; rssi_o [n_ch, n_frames] of the oracle; smeter_cal_db [n_ch] -> bool [n_ch]"""
+def min_well_for(n_ch):
+    return max(int(np.floor(WELL_FRACTION * n_ch - 4.0 * np.sqrt(WELL_FRACTION * (1.0 - WELL_FRACTION) * n_ch))), 1)
+
+
+def rssi_well_conditioned(iq, rssi_o, smeter_cal_db):
+    """The S-meter's own condition (it reads the filtered POWER, whatever the AGC then does with the audio): the channel
+    filter leaves, in every frame, a power within 40 dB of the input's -> the fp32 RSSI is good to 1e-3 dB.
+    iq int16 [n_ch, n, 2]; rssi_o [n_ch, n_frames] of the oracle; smeter_cal_db [n_ch] -> bool [n_ch]"""
     in_db = 10 * np.log10(np.maximum((iq.astype(np.float64) ** 2).sum(axis=2).mean(axis=1), 1e-20) / 32768.0 ** 2)
     in_db = in_db + np.asarray(smeter_cal_db, np.float64)
     return (rssi_o > in_db[:, None] - 40).all(axis=1)
 
 
-def assert_pcm_within_tolerance(pcm, pcm_o, iq, rssi_o, smeter_cal_db, modes=None, min_well=None, what=""):
-    """modes: the channels' mode names (the NBFM exception applies to "nbfm" only; None: to nobody).  min_well: channels that
-    must be well conditioned (default: MIN_WELL_FRACTION of them)."""
-    pcm = np.asarray(pcm, np.float64)
-    n_ch = pcm.shape[0]
-    well = well_conditioned(iq, rssi_o, smeter_cal_db)
-    need = int(np.ceil(MIN_WELL_FRACTION * n_ch)) if min_well is None else int(min_well)
-    assert well.sum() >= need, (int(well.sum()), need, n_ch)
-    rms = np.sqrt(((pcm - pcm_o) ** 2).mean(axis=1)) / 32768.0
-    dev = np.sort(np.abs(pcm - pcm_o), axis=1)[:, : int(pcm_o.shape[1] * 0.995)]
-    rms_trim = np.sqrt((dev ** 2).mean(axis=1)) / 32768.0
-    fm = np.array([m == "nbfm" for m in modes], bool) if modes is not None else np.zeros(n_ch, bool)
+def oracle_with_bound(iq, params, decim=1, rate=O.RATE):
+    """(pcm_o, rssi_o, bound): the float64 chain and, per sample, how far a backward-stable fp32 evaluation may lie from it"""
+    return O.audio_chain_with_bound(iq, params, EPS, decim, rate)
+
+
+def assert_pcm_within_tolerance(pcm, pcm_o, bound, min_well=None, what=""):
+    """pcm, pcm_o [n_ch, n]; bound [n_ch, n] of oracle_with_bound.  min_well: channels that must be well conditioned
+    (default: min_well_for(n_ch)).  Returns (well [n_ch] bool, rms [n_ch])."""
+    err = np.abs(np.asarray(pcm, np.float64) - np.asarray(pcm_o, np.float64))
+    n_ch = err.shape[0]
+    rms = np.sqrt((err ** 2).mean(axis=1)) / 32768.0
+    brms = np.sqrt((bound ** 2).mean(axis=1)) / 32768.0
+    well = brms <= PCM_RMS_TOL
+    need = min_well_for(n_ch) if min_well is None else int(min_well)
+    with np.errstate(divide="ignore", invalid="ignore"):       # the share of its bound a sample uses beyond the rounding LSB
+        worst = np.where(err > 1.0, (err - 1.0) / bound, 0.0)
+    turn = bound >= 30000.0                                     # the discriminator at its branch cut: +pi or -pi, a full turn apart
     REPORT.append({"what": what, "channels": n_ch, "well_conditioned": int(well.sum()),
-                   "untrimmed_max_well": float(rms[well].max(initial=0.0)), "untrimmed_max_well_not_nbfm": float(rms[well & ~fm].max(initial=0.0)),
-                   "trimmed_max_well": float(rms_trim[well].max(initial=0.0)), "untrimmed_max_all": float(rms.max())})
-    print("pcm vs float64 oracle %s: %d/%d well conditioned; untrimmed RMS max %.2e (NBFM excluded %.2e), trimmed %.2e; all channels %.2e"
-          % (what, well.sum(), n_ch, rms[well].max(initial=0.0), rms[well & ~fm].max(initial=0.0), rms_trim[well].max(initial=0.0), rms.max()))
-    assert rms[well & ~fm].max(initial=0.0) < PCM_RMS_TOL, (int(np.argmax(rms * (well & ~fm))), float((rms * (well & ~fm)).max()))
-    assert rms[well & fm].max(initial=0.0) < NBFM_UNTRIMMED_TOL, (int(np.argmax(rms * (well & fm))), float((rms * (well & fm)).max()))
-    assert rms_trim[well].max(initial=0.0) < PCM_RMS_TOL, (int(np.argmax(rms_trim * well)), float((rms_trim * well).max()))
-    assert rms.max() < LOOSE_TOL, (int(np.argmax(rms)), float(rms.max()))
-    return well, rms_trim
+                   "untrimmed_max_well": float(rms[well].max(initial=0.0)), "untrimmed_max_all": float(rms.max()),
+                   "worst_sample_over_its_bound": float(worst.max()), "worst_sample_not_at_the_branch_cut": float(worst[~turn].max(initial=0.0)),
+                   "samples_at_the_branch_cut": int(turn.sum())})
+    print("pcm vs float64 oracle %s: %d/%d well conditioned, their untrimmed RMS max %.2e; all channels %.2e; beyond the rounding LSB the worst sample uses %.2f of its bound (%d samples at the FM branch cut set aside)"
+          % (what, well.sum(), n_ch, rms[well].max(initial=0.0), rms.max(), worst[~turn].max(initial=0.0), turn.sum()))
+    assert well.sum() >= need, (int(well.sum()), need, n_ch)
+    c, n = np.unravel_index(int(np.argmax(worst)), worst.shape)
+    assert worst.max() <= 1.0, ("sample beyond its bound", int(c), int(n), float(err[c, n]), float(bound[c, n]))
+    over = rms - np.sqrt(PCM_RMS_TOL ** 2 + brms ** 2)
+    assert over.max() < 0.0, ("channel RMS beyond its bound", int(np.argmax(over)), float(rms[np.argmax(over)]), float(brms[np.argmax(over)]))
+    assert rms[well].max(initial=0.0) < PCM_RMS_TOL, (int(np.argmax(rms * well)), float((rms * well).max()))
+    return well, rms
