@@ -14,7 +14,7 @@ analyst's: the kernels must be a BACKWARD-STABLE evaluation of the float64 chain
     bound[ch, n], in LSB.
   * EPS = 2^-20 = 16 units of fp32 roundoff (the classical bound for a 127-tap sum alone is 127 u).
   * EVERY sample of EVERY channel:   |pcm - pcm_oracle| <= 1 LSB + bound             (1 LSB: the two roundings to int16)
-  * EVERY channel:                   RMS(pcm - pcm_oracle) <= sqrt(1e-5^2 + RMS(bound)^2)   of full scale
+  * EVERY channel:                   RMS(pcm - pcm_oracle) <= 1e-5 + RMS(bound)             of full scale (Minkowski)
   * a channel is WELL CONDITIONED when RMS(bound) <= 1e-5 of full scale (1/3 LSB: the float64 chain itself moves by
     less than the tolerance under that perturbation); every well-conditioned channel must meet the plain north_star
     figure, 1e-5 RMS UNTRIMMED -- no per-mode exception.  So that this says something, a sweep must hold its share of
@@ -23,7 +23,7 @@ analyst's: the kernels must be a BACKWARD-STABLE evaluation of the float64 chain
 
 Calibration (tools/soak_parity.py, profiles/r04_soak_parity.txt): 600 sweeps x 96 channels x 3072 samples of
 tests/random_params.py: the largest EPS any sample needed was 2^-21.3; 83 % (AM/SSB/CW) and 90 % (NBFM) of the channels
-are well conditioned, their largest untrimmed RMS deviation is 5.2e-6.
+are well conditioned, their largest untrimmed RMS deviation is 5.2e-6 (GPU soak, 54 048 channels: 5.6e-6).
 The figures of each sweep are kept in REPORT (printed with pytest -s).
 """
 import numpy as np
@@ -75,7 +75,7 @@ def assert_pcm_within_tolerance(pcm, pcm_o, bound, min_well=None, what=""):
     assert well.sum() >= need, (int(well.sum()), need, n_ch)
     c, n = np.unravel_index(int(np.argmax(worst)), worst.shape)
     assert worst.max() <= 1.0, ("sample beyond its bound", int(c), int(n), float(err[c, n]), float(bound[c, n]))
-    over = rms - np.sqrt(PCM_RMS_TOL ** 2 + brms ** 2)
+    over = rms - (PCM_RMS_TOL + brms)
     assert over.max() < 0.0, ("channel RMS beyond its bound", int(np.argmax(over)), float(rms[np.argmax(over)]), float(brms[np.argmax(over)]))
     assert rms[well].max(initial=0.0) < PCM_RMS_TOL, (int(np.argmax(rms * well)), float((rms * well).max()))
     return well, rms

@@ -43,6 +43,12 @@ def main():
         ("parameter surface, 96 ch x 48 frames", lambda s: TP.test_random_parameter_surface_bit_exact_vs_twin(S, twin, s, 48) if s % 8 == 0 else None),
         ("waterfall batching / averaging", lambda s: TP.test_wf_random_batching_and_averaging(S, twin, s)),
     ]
+    shapes = [(64, 1, 1024), (33, 10, 1024), (7, 3, 512), (20, 1, 512)]
+    sweeps += [
+        ("exact bins == NumPy float64, random levels", lambda s: TP.test_exact_bins_equal_the_float64_oracle_bit_for_bit(S, *shapes[s % 4], seed=s)),
+        ("decimating front end, D = 2 / 4", lambda s: TP.test_decimating_front_end_bit_exact_vs_twin_and_oracle(S, twin, 2 + 2 * (s & 1), seed=s)),
+        ("IQ at 20.25 kHz", lambda s: TP.test_iq_chain_at_20250_hz_bit_exact_vs_twin_and_oracle(S, twin, seed=s) if s % 2 == 0 else None),
+    ]
     avgs = [1, 2, 7, 10, 33, 100]
     sweeps.append(("spectrum_db2col, random lines vs the oracle", lambda s: TQ.test_db2col_random_lines_vs_oracle(S, s, avgs[s % len(avgs)])))
     return run_sweeps(a, sweeps, T)
