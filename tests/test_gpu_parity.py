@@ -1629,3 +1629,68 @@ def test_waterfall_zoom_bit_exact_vs_twin_and_oracle(S, twin, Z, hop, n_avg, dec
         assert np.array_equal(z2[0], t0) and np.array_equal(z2[1], t1)
         ph, hist = np.zeros(2, np.uint32), np.zeros((2, 256, 2), np.int16)
         assert np.array_equal(z3, twin.zoom(iq[:2, :4096], 2, d2, O.zoom_taps(2), ph, hist))
+
+
+def test_contexts_release_their_device_memory(S):
+    """ssdr_destroy gives back everything a ctx took, whatever it was used for: contexts that each touch every lazily
+    allocated buffer (pipelined feed with post-processing, zoom, exact bins, hop 512, decimation, wf_data ring, trace,
+    playbuffer at both rates, wire input, pinned slots) are opened and closed in a loop; the device's free memory (hipMemGetInfo)
+    does not drift."""
+    import ctypes
+    from supersdr_amd._lib import Db2colChan, PlayChan
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+
+    def free_bytes():
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    n_ch = 512
+    iq = O.synth_iq(n_ch, 4 * 512, seed=5)
+
+    def one_life(k):
+        with S.SsdrEngine(n_ch) as eng:
+            ps, _ = mixed_params(S, n_ch)
+            eng.set_params(0, ps)
+            if k % 3 == 1:
+                eng.set_hop(512)
+            eng.set_averaging(1 + k % 3)
+            eng.set_exact_bins(k % 2 == 1)
+            eng.push_iq(iq)
+            eng.run_chain()
+            wf = eng.run_wf()
+            eng.run_audio()
+            eng.set_wfdata_rows(16)
+            if len(wf):
+                eng.run_db2col([Db2colChan(zoom=0, auto_scale=1, low_clip_db=-120.0, high_clip_db=-60.0, dynamic_range=40.0)] * n_ch, len(wf))
+                eng.run_trace()
+            eng.run_playbuffer([PlayChan(volume=100.0, balance=0.0)] * n_ch)
+            eng.set_recording(True)
+            eng.set_kiwi_rate(20250)
+            eng.push_iq(iq)
+            eng.run_audio()
+            eng.run_playbuffer([PlayChan(volume=100.0, balance=0.0)] * n_ch)
+            eng.set_kiwi_rate(12000)
+            eng.set_exact_bins(False)
+            eng.set_hop(1024)
+            eng.set_wf_zoom(4)
+            eng.push_iq(np.concatenate([iq, iq], axis=1))         # 4096 samples: one zoomed line
+            eng.run_wf()
+            eng.set_wf_zoom(1)
+            eng.set_averaging(1)
+            eng.feed_open(4, depth=3, post=True)
+            buf = eng.host_alloc((n_ch, 4 * 512, 2), np.int16)
+            buf[:] = iq
+            for _ in range(4):
+                eng.feed_submit_from(buf)
+                eng.feed_collect()
+
+    one_life(0)                                                   # the first ctx also pays for what the runtime keeps (code objects, pools)
+    one_life(1)
+    series = [free_bytes()]
+    for k in range(36):
+        one_life(k)
+        series.append(free_bytes())
+    print("free device memory after each ctx, MiB relative to the first:", [(x - series[0]) >> 20 for x in series])
+    # the runtime grows its own pools in steps now and then; a leaked buffer would take its size with EVERY ctx
+    assert abs(series[-1] - series[12]) <= 8 << 20 and abs(series[12] - series[0]) <= 32 << 20, series
