@@ -376,13 +376,15 @@ class SsdrEngine:
         return trace, y
 
     def run_smeter(self, chans, fps, rssi=None):
-        """One display frame of the S-meter smoothing (supersdr.py:936-947) per channel; chans (list of SmeterChan) is
-        updated in place.  rssi float64 [n_ch] or None (= last frame of the last run_audio)."""
-        arr = (SmeterChan * self.n_ch)(*chans)
+        """One display frame of the S-meter smoothing (supersdr.py:936-947) per channel; chans (list of SmeterChan, or a ctypes
+        array SmeterChan * n_ch: no per-channel objects) is updated in place.  rssi float64 [n_ch] or None (= last frame of the
+        last run_audio)."""
+        arr = chans if isinstance(chans, C.Array) else (SmeterChan * self.n_ch)(*chans)
         r = None if rssi is None else np.ascontiguousarray(rssi, np.float64)
         check(lib.ssdr_run_smeter(self._ctx, arr, None if r is None else r.ctypes.data, float(fps)), "ssdr_run_smeter")
-        for i in range(self.n_ch):
-            chans[i] = arr[i]
+        if arr is not chans:
+            for i in range(self.n_ch):
+                chans[i] = arr[i]
         return chans
 
     def set_kiwi_rate(self, kiwi_rate):

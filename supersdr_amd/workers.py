@@ -222,6 +222,7 @@ class IQHub:
         self._gmax = 0                               # max(gw), kept incrementally
         self.dropped = np.zeros(self.n_ch, np.int64)
         self.stalled = np.zeros(self.n_ch, np.int64)
+        self._reserved = {}                          # first channel of a reserve() -> the write position it was given at
         # ---- results
         self.last = None                             # SuperframeResult of the newest GPU run
         self._subscribers = []
@@ -407,7 +408,9 @@ class IQHub:
     def reserve(self, first_channel, k):
         """-> writable view [k, room, 2] (wire: [k, room, 2065]) of where the next samples of channels [first, first + k) go,
         or None when they do not stand at one write position (use feed_block then).  Fill view[:, :n] and commit(first, k, n):
-        the ingest writes where the H2D copy reads, no copy in between."""
+        the ingest writes where the H2D copy reads, no copy in between.  A block that sits on its reservation until the others are
+        `stall_superframes` ahead is overtaken like any stalled receiver (its superframe runs zero-filled): commit() then returns
+        False, the samples count as dropped, and the block reserves again."""
         with self._lock:
             g = self._gw[first_channel:first_channel + k]
             g0 = int(g[0])
@@ -417,16 +420,22 @@ class IQHub:
             if b >= self._base + self._cap:
                 return None
             self._await_slot(b)
+            self._reserved[int(first_channel)] = g0
             return self._slots[b % self._nslots][first_channel:first_channel + k, off:]
 
     def commit(self, first_channel, k, n):
+        """n samples (wire: frames) per channel were written into the reserved view -> True (False: the reservation was overtaken)"""
         with self._lock:
             g0 = int(self._gw[first_channel])
+            if self._reserved.pop(int(first_channel), g0) != g0:     # the stall rule moved these channels on: the view was a slot that has run
+                self.dropped[first_channel:first_channel + k] += n
+                return False
             b, off = divmod(g0, self._U)
             if n < 0 or off + n > self._U:
                 raise ValueError("commit beyond the reserved room")
             self._advance(first_channel, k, g0, n)
             self._pump()
+            return True
 
     def _feed_runs(self, first, data):
         """split a block into runs of channels that stand at the same write position"""
@@ -645,12 +654,20 @@ class IQHub:
         audio frame's RSSI.  Returns (rssi_smooth [n_ch], rssi_smooth_slow [n_ch])."""
         from ._lib import SmeterChan
         with self._lock:
-            if self._smeter is None:
-                self._smeter = [SmeterChan.start(-127.0) for _ in range(self.n_ch)]      # kiwi_sound.rssi before any frame
-            for c, s in enumerate(self.snd_clients):
-                self._smeter[c].decay_ms = float(decay_ms if decay_ms is not None else (s.decay if s is not None else 4000))
+            if self._smeter is None:                 # one ctypes array for all channels, read and written through a NumPy view
+                self._smeter = (SmeterChan * self.n_ch)()
+                _fill_struct_array(self._smeter, SmeterChan.start(-127.0))               # kiwi_sound.rssi before any frame
+                self._smeter_np = np.frombuffer(self._smeter, dtype=np.dtype(
+                    [("rssi_smooth", "f8"), ("rssi_smooth_slow", "f8"), ("hist", "f8", (10,)), ("hist_pos", "u4"), ("run_index", "u4"), ("decay_ms", "f8")]))
+            v = self._smeter_np
+            v["decay_ms"] = 4000.0 if decay_ms is None else float(decay_ms)
+            if decay_ms is None:
+                for c in self._snd_att:              # the workers' own AGC decay (utils_supersdr.py:941), where there is a worker
+                    s = self.snd_clients[c]
+                    if s is not None:
+                        v["decay_ms"][c] = float(s.decay)
             self.engine.run_smeter(self._smeter, fps)
-            return (np.array([s.rssi_smooth for s in self._smeter]), np.array([s.rssi_smooth_slow for s in self._smeter]))
+            return v["rssi_smooth"].copy(), v["rssi_smooth_slow"].copy()
 
     @staticmethod
     def _db2col_chan(w):

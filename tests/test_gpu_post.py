@@ -657,3 +657,30 @@ def test_post_processing_for_the_listeners_only(S):
     for name in ("listeners", "listeners, pipelined"):
         for a, b in zip(seen["everybody"], seen[name]):
             assert all(np.array_equal(x, y) for x, y in zip(a, b)), name
+
+
+def test_hub_smeter_step_keeps_all_channels_in_one_array(S):
+    """IQHub.smeter_step (supersdr.py:936-947 for every channel at once): state and decay live in one ctypes array / NumPy view,
+    no per-channel objects; a worker's own AGC decay is used where there is a worker, 4000 ms elsewhere; == the oracle's
+    restatement of the reference's lines, frame after frame"""
+    from types import SimpleNamespace
+    from supersdr_amd.workers import IQHub
+    n_ch, fps = 5, 30.0
+    hub = IQHub(n_ch, gpu_post=False, lazy=True)
+    try:
+        hub.snd_clients[3] = SimpleNamespace(decay=1000, volume=100, audio_balance=0.0, audio_rec=SimpleNamespace(recording_flag=False))
+        ref = [O.SMeter(-127.0) for _ in range(n_ch)]
+        apart = 0.0
+        for i in range(25):
+            hub.feed_block(0, O.synth_iq(n_ch, 1024, seed=40 + i, amp=12000.0 if i < 6 else 100.0))     # a strong signal, then the decay
+            rssi = hub.last.rssi[:, -1].astype(np.float64)
+            sm, sl = hub.smeter_step(fps)
+            for c in range(n_ch):
+                want = ref[c].step(float(rssi[c]), 1000.0 if c == 3 else 4000.0, fps, i)
+                assert abs(sm[c] - want[0]) < 1e-9 and sl[c] == want[1], (i, c)
+            apart = max(apart, float(sm[0] - sm[3]))
+        assert sm.shape == sl.shape == (n_ch,) and apart > 0.05                           # on the way down the faster decay was ahead
+        sm2, _ = hub.smeter_step(fps, decay_ms=500.0)              # an explicit decay overrides the workers'
+        assert np.isfinite(sm2).all()
+    finally:
+        hub.close()

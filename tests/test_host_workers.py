@@ -1058,3 +1058,30 @@ def test_hub_fed_from_many_threads_delivers_every_stream_in_order():
     got = np.concatenate(eng.batches, axis=1)                      # [n_ch, n_sf * 1024, 2]
     for c in range(n_ch):
         assert np.array_equal(got[c], stream(c)), c
+
+
+def test_a_reservation_overtaken_by_the_stall_rule_is_refused_not_misfiled():
+    """reserve() hands out a view of the open slot; if the block then sits on it until the others are `stall_superframes` ahead,
+    its superframe runs zero-filled and the view is a slot that has left: commit() says so (False, samples counted as dropped)
+    instead of advancing the channel over samples that are not where the next run will read them."""
+    from supersdr_amd.workers import IQHub
+    eng = RecordingEngine(3)
+    hub = IQHub(3, engine=eng, gpu_post=False, backlog_superframes=8, stall_superframes=2)
+    rng = np.random.default_rng(9)
+    v = hub.reserve(2, 1)
+    assert v is not None and v.shape[0] == 1
+    for _ in range(3):                                                   # channels 0 and 1 run ahead: the hub stops waiting for 2
+        hub.feed_block(0, rng.integers(-900, 900, (2, 1024, 2)).astype(np.int16))
+    assert eng.runs >= 1 and hub.stalled[2] >= 1 and not eng.batches[0][2].any()
+    v[:, :512] = 7000
+    assert hub.commit(2, 1, 512) is False and hub.dropped[2] == 512
+    pos = hub.backlog(2)
+    v2 = hub.reserve(2, 1)                                                # the block reserves again: now it is filed where the next run reads
+    v2[:, :512] = 7000
+    assert hub.commit(2, 1, 512) is True and hub.backlog(2) == pos + 512
+    runs = eng.runs
+    while eng.runs == runs:
+        hub.feed_block(0, rng.integers(-900, 900, (3, 256, 2)).astype(np.int16))
+    stream = np.concatenate([b[2] for b in eng.batches])                  # channel 2 as the engine saw it, run after run
+    at = np.flatnonzero((stream == 7000).all(axis=1))
+    assert len(at) == 512 and at[-1] - at[0] == 511                      # the second block, once, in one piece; the first nowhere
