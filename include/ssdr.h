@@ -358,7 +358,8 @@ int ssdr_audio_device(ssdr_ctx *ctx, int16_t **pcm, float **rssi);
 int ssdr_output_checksum(ssdr_ctx *ctx, uint64_t sums[3]);
 
 /* -- measurement */
-int ssdr_set_stream(ssdr_ctx *ctx, void *hip_stream);           /* NULL = ctx's own stream */
+int ssdr_set_stream(ssdr_ctx *ctx, void *hip_stream);           /* NULL = ctx's own stream.  On a caller's stream ssdr_run_chain joins its
+                                                                  * side-by-side audio stage before it returns: work ordered behind that stream sees both stages */
 int ssdr_set_profiling(ssdr_ctx *ctx, int on);                  /* HIP-event pair around every launch */
 /* bit 0: run the audio stage on a second stream beside the waterfall kernel (which then takes one workgroup per CU);
  * bit 1: run the audio stage's per-path kernels one after the other instead of side by side (measurement only) */

@@ -1034,6 +1034,7 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
         rc = ssdr_run_audio(c, nullptr, nullptr, 0);
         if (rc == SSDR_OK) rc = ssdr_run_wf(c, nullptr, lines_ready, 0);
         c->concurrent = false;                       // (audio_pending stays set: whoever needs the results or the input joins first)
+        if (rc == SSDR_OK && c->stream != c->own_stream) rc = join_audio(c);     // a caller's stream (ssdr_set_stream): what they order behind it covers both stages
     } else {
         rc = ssdr_run_wf(c, nullptr, lines_ready, 0);
         if (rc == SSDR_OK) rc = ssdr_run_audio(c, nullptr, nullptr, 0);
@@ -1417,6 +1418,8 @@ int ssdr_copy_from_device(ssdr_ctx *c, void *host_dst, const void *device_src, u
 int ssdr_audio_device(ssdr_ctx *c, int16_t **pcm, float **rssi)
 {
     if (!c) return SSDR_EINVAL;
+    HIP_TRY(hipSetDevice(c->device));
+    { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }       // a consumer ordered behind the ctx stream sees the audio stage too
     if (pcm) *pcm = c->d_pcm;
     if (rssi) *rssi = c->d_rssi;
     return SSDR_OK;

@@ -1261,6 +1261,46 @@ def test_run_chain_side_by_side_stages_are_bit_identical_and_joined_before_what_
         assert (a == b) if isinstance(a, (bytes, tuple)) else np.array_equal(a, b)
 
 
+def test_run_chain_on_a_callers_stream_leaves_both_stages_ordered_behind_it(S):
+    """ssdr_set_stream: a caller that orders its own work behind its own stream (and never calls ssdr_sync) must see the audio
+    stage too, although that one ran on the ctx's second stream: ssdr_run_chain joins it before returning.  The results are read
+    with the caller's own copies on the caller's stream."""
+    import ctypes
+    from supersdr_amd import _lib as L
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_ch, nf = 2048, 16
+    iq = O.synth_iq(n_ch, nf * 512, seed=77)
+    ps, _ = mixed_params(S, n_ch)
+    with S.SsdrEngine(n_ch) as eng:                                 # the reference run: one stage after the other
+        eng.set_overlap(0)
+        eng.set_params(0, ps)
+        eng.set_averaging(2)
+        eng.push_iq(iq)
+        eng.run_chain()
+        want = eng.fetch_audio()[0].copy()
+    stream = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithFlags(ctypes.byref(stream), 1) == 0          # hipStreamNonBlocking
+    try:
+        with S.SsdrEngine(n_ch) as eng:
+            eng.set_params(0, ps)
+            eng.set_averaging(2)
+            eng.set_stream(stream)
+            eng.push_iq(iq)
+            for rep in range(3):                                     # (state carries: only the first pass is compared)
+                _, fused = eng.run_chain()
+                assert not fused
+                if rep == 0:
+                    p, r = L._P(), L._P()
+                    L.check(L.lib.ssdr_audio_device(eng._ctx, ctypes.byref(p), ctypes.byref(r)), "ssdr_audio_device")
+                    got = np.empty_like(want)
+                    assert hip.hipMemcpyAsync(ctypes.c_void_p(got.ctypes.data), p, ctypes.c_size_t(got.nbytes), 2, stream) == 0     # D2H
+                    assert hip.hipStreamSynchronize(stream) == 0
+                    assert np.array_equal(got, want)
+            eng.set_stream(None)
+    finally:
+        hip.hipStreamDestroy(stream)
+
+
 # ------------------------------------------------------------------ round 3
 def test_set_concurrent_bits_are_bit_identical_to_the_default(S):
     """ssdr_set_concurrent: bit 0 (audio stage on a second stream beside the waterfall kernel, which then takes
