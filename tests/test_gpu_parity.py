@@ -201,6 +201,42 @@ def test_audio_bit_exact_vs_twin_and_oracle(S, twin, n_ch, n_frames):
     assert np.abs(rssi - rssi_o).max() < 1e-3
 
 
+def test_one_very_long_call(S, twin):
+    """a single call of 1000 frames (85 s of IQ) on a few channels: the frame loops, the NCO's 64-frame table refresh, the RSSI
+    conversion in batches and the waterfall's group runs (hop 512, N = 7: 1000 lines, 142 groups and a remainder that carries)
+    all cross their internal boundaries many times inside ONE launch; bit-exact vs the twin, PCM within tolerance of the oracle"""
+    n_ch, n_frames = 5, 1000
+    iq = O.synth_iq(n_ch, n_frames * 512, seed=1001)
+    ps, ops = mixed_params(S, n_ch)
+    ps[4], ops[4] = S.default_params("am"), O.ChanParams("am")                # one channel on the full-band AM path too
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.set_hop(512)
+        eng.set_averaging(7)
+        eng.push_iq(iq)
+        lines, fused = eng.run_chain()
+        wf = eng.fetch_wf(lines).copy()
+        pcm, rssi = eng.fetch_audio()
+        flags = eng.audio_flags()
+        consts, taps = eng.get_consts()
+        st_g, hist_g = eng.get_state()
+    assert not fused and lines == 1000 // 7
+    st, hist = twinlib.fresh_state(consts)
+    pcm_t, rssi_t, flags_t = twin.audio(iq, consts, taps, st, hist, want_flags=True)
+    assert np.array_equal(pcm, pcm_t) and np.array_equal(rssi, rssi_t) and np.array_equal(flags, flags_t)
+    assert st_g.tobytes() == st.tobytes() and np.array_equal(hist_g, hist)
+    for c in range(n_ch):                                                        # hop 512: silence in front of the first half-line
+        stream = np.concatenate([np.zeros((512, 2), np.int16), iq[c]])
+        b = O.wf_lines_hop(stream, 512, 0.0).astype(np.int16)[:1000]
+        ref = b[: lines * 7].reshape(lines, 7, 1024).sum(axis=1)
+        seg = stream[np.arange(lines * 7)[:, None] * 512 + np.arange(1024)[None, :]]
+        gb = O.wf_allowed_diff(seg).reshape(lines, 7, 1024).sum(axis=1)
+        assert not (np.abs(wf[:, c].astype(np.int32) - ref) > gb).any(), c
+    import tolerances as T
+    pcm_o, rssi_o, bound = T.oracle_with_bound(iq, ops)
+    T.assert_pcm_within_tolerance(pcm, pcm_o, bound, what="one 1000-frame call")
+
+
 def test_full_band_paths_mode_switch_and_adc_overflow_flags(S, twin):
     """The reference's full-band passband (+-6 kHz at 12 kHz: the filter is a 4-sample delay) takes the kernel's shift
     paths -- AM without NCO and FIR (integer power), NBFM with a lane shift instead of the FIR.  PCM, RSSI, carried
