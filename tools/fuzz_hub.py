@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the ingest hub on the GPU box: the SAME random traffic into a synchronous IQHub and into a pipelined one
+(pinned slots, ssdr_feed_submit_from, three streams, post-processing inside the slot pipeline; optionally several superframes per
+GPU run) -- ragged per-channel feeds, blocks of channels, in-place reserve / commit, receivers that fall behind until the stall rule
+runs without them, parameter and averaging changes in mid-stream, display-state changes of the attached workers.  After a flush the
+attached channels' queues must hold the same lines, frames, colours and 48 kHz blocks, item for item, and the hubs' stall / drop
+counters must agree.
+
+    python tools/fuzz_hub.py [--first 1] [--count 40] [--steps 150] [--out gpurun_out/fuzz_hub.txt]
+"""
+import argparse
+import os
+import queue
+import sys
+import time
+import traceback
+from types import SimpleNamespace
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+
+
+def drain(q):
+    out = []
+    while True:
+        try:
+            out.append(q.get_nowait())
+        except queue.Empty:
+            return out
+
+
+def one_sequence(S, IQHub, seed, steps):
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([2, 3, 7, 20, 48]))
+    post = bool(rng.random() < 0.6)
+    lazy = bool(rng.random() < 0.5)
+    K = int(rng.choice([1, 1, 2]))
+    kw = dict(gpu_post=post, lazy=lazy, max_queue=1 << 14, backlog_superframes=8 * K, stall_superframes=3 * K, batch_superframes=K)
+    hubs = [IQHub(n, **kw), IQHub(n, pipeline=True, depth=int(rng.choice([2, 3, 4])), **kw)]
+    listeners = sorted(set(int(c) for c in rng.integers(0, n, max(1, n // 3))))
+    compared = 0
+    try:
+        workers = {}
+        for c in listeners:                                        # display state per listener, shared by both hubs (read at every run)
+            w = SimpleNamespace(zoom=int(rng.integers(0, 15)), wf_auto_scaling=bool(rng.random() < 0.5), delta_low_db=int(rng.integers(-10, 11)),
+                                delta_high_db=int(rng.integers(-10, 11)), low_clip_db=-120.0, high_clip_db=-60.0, dynamic_range=40.0)
+            s = SimpleNamespace(volume=int(rng.choice([50, 100, 150])), audio_balance=float(rng.choice([-0.5, 0.0, 0.5])), decay=4000,
+                                audio_rec=SimpleNamespace(recording_flag=False))
+            workers[c] = (w, s)
+            for h in hubs:
+                h.attach(c, wf=True, snd=True)
+                if post:
+                    h.wf_clients[c], h.snd_clients[c] = w, s
+        for step in range(steps):
+            op = int(rng.integers(0, 12))
+            m = int(rng.choice([64, 512, 700, 1024, 1500, 2048]))
+            if op <= 3:                                            # one receiver; the last one is often silent for long
+                c = int(rng.integers(0, n if step % 50 < 12 else max(n - 1, 1)))
+                iq = rng.integers(-6000, 6000, (m, 2)).astype(np.int16)
+                for h in hubs:
+                    h.feed(c, iq)
+            elif op <= 7:                                          # a block of receivers, by copy or in place
+                f = int(rng.integers(0, n))
+                k = int(rng.integers(1, n - f + 1))
+                iq = rng.integers(-6000, 6000, (k, m, 2)).astype(np.int16)
+                in_place = rng.random() < 0.4
+                for h in hubs:
+                    v = h.reserve(f, k) if in_place else None
+                    if v is not None and v.shape[1] >= m:
+                        v[:, :m] = iq
+                        assert h.commit(f, k, m)
+                    else:
+                        h.feed_block(f, iq)
+            elif op == 8:
+                c = int(rng.integers(0, n))
+                mode = ["am", "usb", "lsb", "cw", "nbfm"][int(rng.integers(0, 5))]
+                p = S.default_params(mode, f_shift_hz=float(rng.integers(-3000, 3000)))
+                for h in hubs:
+                    h.set_params(c, p)
+            elif op == 9:
+                nn = int(rng.choice([1, 1, 2, 5]))
+                for h in hubs:
+                    h.set_averaging(nn)
+            elif op == 10 and post:
+                c = listeners[int(rng.integers(0, len(listeners)))]
+                workers[c][0].zoom = int(rng.integers(0, 15))
+                workers[c][1].volume = int(rng.choice([50, 100, 150]))
+            # op 11: nothing (a pause in the traffic)
+        for h in hubs:
+            h.flush()
+        assert list(hubs[0].stalled) == list(hubs[1].stalled) and list(hubs[0].dropped) == list(hubs[1].dropped)
+        assert hubs[0].superframes == hubs[1].superframes
+        for c in listeners:
+            wa, wb = drain(hubs[0].wf_queue[c]), drain(hubs[1].wf_queue[c])
+            assert len(wa) == len(wb), ("lines", c, len(wa), len(wb))
+            for (la, na, pa), (lb, nb, pb) in zip(wa, wb):
+                assert na == nb and np.array_equal(la, lb), ("line", c)
+                assert (pa is None) == (pb is None), ("post", c)
+                if pa is not None:
+                    assert np.array_equal(pa[0], pb[0], equal_nan=True) and np.array_equal(np.array(pa[1:], np.float64), np.array(pb[1:], np.float64), equal_nan=True), ("colour", c)
+            sa, sb = drain(hubs[0].snd_queue[c]), drain(hubs[1].snd_queue[c])
+            assert len(sa) == len(sb), ("frames", c, len(sa), len(sb))
+            for fa, fb in zip(sa, sb):
+                assert np.array_equal(np.asarray(fa), np.asarray(fb)) and fa.rssi == fb.rssi and fa.adc_overflow == fb.adc_overflow, ("frame", c)
+                assert (fa.play_block is None) == (fb.play_block is None)
+                if fa.play_block is not None:
+                    assert np.array_equal(fa.play_block, fb.play_block), ("play", c)
+            compared += len(wa) + len(sa)
+        return compared, int(hubs[0].stalled.sum())
+    finally:
+        for h in hubs:
+            h.close()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--first", type=int, default=1)
+    ap.add_argument("--count", type=int, default=40)
+    ap.add_argument("--steps", type=int, default=150)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    import supersdr_amd as S
+    from supersdr_amd.workers import IQHub
+    lines, bad, items, stalls, t0 = [], 0, 0, 0, time.time()
+    for seed in range(a.first, a.first + a.count):
+        try:
+            c, s = one_sequence(S, IQHub, seed, a.steps)
+            items += c
+            stalls += s
+        except Exception as e:                                     # noqa: BLE001 -- reported per seed, the run goes on
+            bad += 1
+            tb = traceback.format_exc().strip().splitlines()
+            lines.append("  seed %d: %s: %s | %s" % (seed, type(e).__name__, e, " / ".join(x.strip() for x in tb[-4:-1])[:300]))
+            print(lines[-1], flush=True)
+    lines.append("differential hub fuzz (synchronous vs pipelined IQHub): seeds %d..%d, %d steps each: %d sequences differed; %d queued lines / frames "
+                 "compared, %d stalled superframes on the way (%.0f s)" % (a.first, a.first + a.count - 1, a.steps, bad, items, stalls, time.time() - t0))
+    text = "\n".join(lines) + "\n"
+    print(text)
+    if a.out:
+        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+        with open(a.out, "w") as fh:
+            fh.write(text)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
