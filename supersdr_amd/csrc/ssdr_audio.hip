@@ -345,19 +345,33 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
     }
 }
 
+#ifndef SSDR_DEC_PHASED
+#define SSDR_DEC_PHASED 1
+#endif
+__host__ __device__ constexpr bool dec_phased(int D) { return SSDR_DEC_PHASED && D > 2; }
+__host__ __device__ constexpr int dec_streams_per_phase(int D) { return dec_phased(D) ? 2 : D; }
+
 // ---- decimating front end (ssdr_set_decimation: the IQ arrives at D * 12 kHz) -------------------------------------
 // Lane l owns the 8 D consecutive inputs that produce its 8 outputs.  Mixed, they de-interleave into D polyphase streams
 // v_q[m] = z[D m + q]; y[m] = sum_k h[k] z[D m - k] is then the sum of D ordinary FIRs, one per stream, each on the taps
 // the host laid out for it (stream q >= 1 carries its taps behind one zero tap: ssdr_tables.cpp) -- the same register-window
 // FIR as the 12 kHz path, run D times on D regions of LDS, 2 FMAs per tap and output sample in total.  Everything behind
 // the filter (demodulators, AGC, PCM, RSSI) is the 12 kHz chain.
+//
+// D = 4 runs the streams in TWO PHASES of two (SSDR_DEC_PHASED): the D regions of LDS are what holds the kernel to 7 waves per CU,
+// so the work area is two regions only -- streams 0, 1 are filed and filtered while the mixed samples of streams 2, 3 wait in
+// registers, then those take the same two regions -- and every stream's history (its last HOCT_S octets) lives in a small area of
+// its own, copied in front of the stream when its phase begins and refreshed by the lanes that hold the frame's tail when they file
+// it.  Same sums in the same order: stream 0 first, taps ascending.
 template <int D>
 SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, const int l, const ssdr_chan_consts &kc,
-                                 float2 *s_z, float *s_taps)
+                                 float2 *s_z, float2 *s_h, float *s_taps)
 {
     constexpr int SLOTS = SSDR_NTAP_MAX / D;             // tap slots per stream
     constexpr int HOCT_S = SSDR_HIST / D / 8;            // history octets per stream
     constexpr int ROCT = HOCT_S + 64;                    // octets per stream region
+    constexpr bool PHASED = dec_phased(D);
+    constexpr int SPP = dec_streams_per_phase(D);        // streams per phase (= regions of the work area)
     constexpr int NB = 8 * D;                            // inputs per lane and frame
     constexpr int TAIL_LANES = SSDR_HIST / NB;           // lanes of a frame whose inputs form the 128-sample raw tail
     const uint32_t mode = kc.mode;
@@ -401,7 +415,8 @@ SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, cons
             float2 V[8];
 #pragma unroll
             for (int j = 0; j < 8; j++) V[j] = Z[D * j + q];
-            store_oct(s_z + q * ROCT * OCT, l, V);
+            if constexpr (PHASED) store_oct(s_h + q * HOCT_S * OCT, l, V);
+            else store_oct(s_z + q * ROCT * OCT, l, V);
         }
     }
 
@@ -430,16 +445,40 @@ SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, cons
             // eight inputs at a time: input 8 sb + t belongs to stream (t mod D), element (8 sb + t) / D of the lane's octet there;
             // a sub-block fills 8 / D consecutive elements of every stream (only 8 mixed samples are ever live: 4 waves per SIMD)
             constexpr int EPS = 8 / D;                       // elements per stream and sub-block (2 at D = 4, 4 at D = 2)
+            float2 held[PHASED ? (D - SPP) * 8 : 1];         // the later phases' streams, mixed, until their turn
+            if constexpr (PHASED) {                          // phase 0: the streams' history in front of them (read before the tail lanes refresh it)
+                if (l < HOCT_S * SPP) {
+                    const int q = l / HOCT_S, o = l - q * HOCT_S;
+                    float2 T[8];
+                    load_oct(s_h + q * HOCT_S * OCT, o, T);
+                    store_oct(s_z + q * ROCT * OCT, o, T);
+                }
+            }
 #pragma unroll
             for (int sb = 0; sb < D; sb++) {
                 float2 Z8[8];
                 mix8_carry<true>(rw + 8 * sb, bc, bs, cs1, ss1, Z8, amax);
 #pragma unroll
                 for (int q = 0; q < D; q++) {
-                    float4 *dstq = reinterpret_cast<float4 *>(s_z + q * ROCT * OCT + (HOCT_S + l) * OCT + EPS * sb);
+                    if (!PHASED || q < SPP) {
+                        float4 *dstq = reinterpret_cast<float4 *>(s_z + q * ROCT * OCT + (HOCT_S + l) * OCT + EPS * sb);
 #pragma unroll
-                    for (int u = 0; u < EPS; u += 2)
-                        dstq[u >> 1] = make_float4(Z8[q + D * u].x, Z8[q + D * u].y, Z8[q + D * (u + 1)].x, Z8[q + D * (u + 1)].y);
+                        for (int u = 0; u < EPS; u += 2)
+                            dstq[u >> 1] = make_float4(Z8[q + D * u].x, Z8[q + D * u].y, Z8[q + D * (u + 1)].x, Z8[q + D * (u + 1)].y);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < EPS; u++) held[(q - SPP) * 8 + EPS * sb + u] = Z8[q + D * u];
+                    }
+                }
+            }
+            if constexpr (PHASED) {                          // the frame's tail is the next frame's history
+                if (l >= 64 - HOCT_S) {
+#pragma unroll
+                    for (int q = 0; q < SPP; q++) {
+                        float2 T[8];
+                        load_oct(s_z + q * ROCT * OCT, HOCT_S + l, T);
+                        store_oct(s_h + q * HOCT_S * OCT, l - (64 - HOCT_S), T);
+                    }
                 }
             }
             lds_sync();
@@ -448,7 +487,27 @@ SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, cons
             for (int j = 0; j < 8; j++) { yr[j] = 0.0f; yi[j] = 0.0f; }
             // the D stream filters, one after the other into the same accumulators: stream 0 first, taps ascending
             for (int q = 0; q < D; q++) {
-                const float2 *zq = s_z + q * ROCT * OCT;
+                if constexpr (PHASED) {
+                    if (q == SPP) {                          // phase 1: streams SPP.. take the work area over
+                        lds_sync();
+                        if (l < HOCT_S * SPP) {
+                            const int q2 = l / HOCT_S, o = l - q2 * HOCT_S;
+                            float2 T[8];
+                            load_oct(s_h + (SPP + q2) * HOCT_S * OCT, o, T);
+                            store_oct(s_z + q2 * ROCT * OCT, o, T);
+                        }
+#pragma unroll
+                        for (int q2 = 0; q2 < D - SPP; q2++) {
+                            float2 V[8];
+#pragma unroll
+                            for (int j = 0; j < 8; j++) V[j] = held[q2 * 8 + j];
+                            store_oct(s_z + q2 * ROCT * OCT, HOCT_S + l, V);
+                            if (l >= 64 - HOCT_S) store_oct(s_h + (SPP + q2) * HOCT_S * OCT, l - (64 - HOCT_S), V);
+                        }
+                        lds_sync();
+                    }
+                }
+                const float2 *zq = s_z + (PHASED ? q % SPP : q) * ROCT * OCT;
                 const float *gq = s_taps + q * SLOTS;
                 float2 A[8], B[8];
                 for (uint32_t b = 0; b < nblk; b += 2) {
@@ -489,13 +548,15 @@ SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, cons
         phi1 += (uint32_t)(SSDR_FRAME * D) * dphi1;
         phi2 += (uint32_t)SSDR_FRAME * dphi2;
         lds_sync();
-        if (l < HOCT_S * D) {                                    // each stream's tail becomes its history
-            const int q = l / HOCT_S, o = l - q * HOCT_S;
-            float2 T[8];
-            load_oct(s_z + q * ROCT * OCT, 64 + o, T);
-            store_oct(s_z + q * ROCT * OCT, o, T);
+        if constexpr (!PHASED) {
+            if (l < HOCT_S * D) {                                // each stream's tail becomes its history
+                const int q = l / HOCT_S, o = l - q * HOCT_S;
+                float2 T[8];
+                load_oct(s_z + q * ROCT * OCT, 64 + o, T);
+                store_oct(s_z + q * ROCT * OCT, o, T);
+            }
+            lds_sync();
         }
-        lds_sync();
     }
 
     if (a.n_frames) {
@@ -517,14 +578,16 @@ SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, cons
 }
 
 template <int D>
-__global__ __launch_bounds__(SSDR_AUDIO_BLOCK) void ssdr_audio_dec_kernel(SsdrAudioArgs a)
+__global__ __launch_bounds__(SSDR_AUDIO_BLOCK) __attribute__((amdgpu_waves_per_eu(dec_phased(D) ? 3 : 1, 8))) void ssdr_audio_dec_kernel(SsdrAudioArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float2 s_z[D * (SSDR_HIST / D / 8 + 64) * OCT];      // 11.5 KB (D = 2), 21.8 KB (D = 4)
+    constexpr int HOCT_S = SSDR_HIST / D / 8;
+    __shared__ __attribute__((aligned(16))) float2 s_z[dec_streams_per_phase(D) * (HOCT_S + 64) * OCT];     // 11.5 KB (D = 2), 10.9 KB (D = 4: two of four streams)
+    __shared__ __attribute__((aligned(16))) float2 s_h[dec_phased(D) ? D * HOCT_S * OCT : 1];              // D = 4: every stream's history, 1280 B
     __shared__ __attribute__((aligned(16))) float s_taps[SSDR_NTAP_MAX + 8];
     const int l = threadIdx.x;
     const uint32_t ch = blockIdx.x;
     if (ch >= a.n_ch) return;
-    channel_frames_dec<D>(a, ch, l, a.consts[ch], s_z, s_taps);
+    channel_frames_dec<D>(a, ch, l, a.consts[ch], s_z, s_h, s_taps);
 }
 
 // One kernel per frame path: the paths differ by a factor of two in registers (the general path holds a 16-sample FIR
