@@ -27,5 +27,5 @@ def test_pipelined_hub_equals_the_synchronous_hub_under_random_traffic(seed):
     import fuzz_hub
     import supersdr_amd as S
     from supersdr_amd.workers import IQHub
-    compared, _ = fuzz_hub.one_sequence(S, IQHub, seed, 150)
+    compared, _ = (fuzz_hub.one_wire_sequence if seed % 4 == 3 else fuzz_hub.one_sequence)(S, IQHub, seed, 150)      # every fourth: wire hubs
     assert compared > 0

@@ -115,6 +115,73 @@ def one_sequence(S, IQHub, seed, steps):
             h.close()
 
 
+def wire_bodies(rng, iq):
+    """iq int16 [k, f * 512, 2] -> SND bodies uint8 [k, f, 2065] as they come off the socket (kiwi/client.py:443-454): 7 header bytes,
+    a 10-byte GNSS stamp, 512 big-endian I,Q pairs"""
+    k, f = iq.shape[0], iq.shape[1] // 512
+    b = rng.integers(0, 256, (k, f, 2065)).astype(np.uint8)            # header and stamp: anything
+    b[:, :, 17:] = iq.astype(">i2").view(np.uint8).reshape(k, f, 2048)
+    return b
+
+
+def one_wire_sequence(S, IQHub, seed, steps):
+    """three hubs, one traffic: SND bodies into a synchronous wire hub and a pipelined wire hub (header strip and byte swap on the
+    device), the decoded samples into a synchronous sample hub"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.choice([2, 5, 12, 33]))
+    K = int(rng.choice([1, 2]))
+    kw = dict(gpu_post=False, lazy=False, max_queue=1 << 14, backlog_superframes=8 * K, stall_superframes=3 * K, batch_superframes=K)
+    hubs = [IQHub(n, wire=True, **kw), IQHub(n, wire=True, pipeline=True, depth=int(rng.choice([2, 3])), **kw), IQHub(n, **kw)]
+    compared = 0
+    try:
+        for step in range(steps):
+            op = int(rng.integers(0, 10))
+            f = int(rng.integers(1, 5))
+            if op <= 6:
+                first = int(rng.integers(0, n)) if op > 2 else int(rng.integers(0, n if step % 40 < 10 else max(n - 1, 1)))
+                k = 1 if op <= 2 else int(rng.integers(1, n - first + 1))
+                iq = rng.integers(-9000, 9000, (k, f * 512, 2)).astype(np.int16)
+                bodies = wire_bodies(rng, iq)
+                in_place = rng.random() < 0.3
+                for h in hubs[:2]:
+                    v = h.reserve(first, k) if in_place else None
+                    if v is not None and v.shape[1] >= f:
+                        v[:, :f] = bodies
+                        assert h.commit(first, k, f)
+                    else:
+                        h.feed_wire_block(first, bodies)
+                hubs[2].feed_block(first, iq)
+            elif op == 7:
+                c = int(rng.integers(0, n))
+                p = S.default_params(["am", "usb", "lsb", "cw", "nbfm"][int(rng.integers(0, 5))], f_shift_hz=float(rng.integers(-3000, 3000)))
+                for h in hubs:
+                    h.set_params(c, p)
+            elif op == 8:
+                nn = int(rng.choice([1, 1, 3]))
+                for h in hubs:
+                    h.set_averaging(nn)
+        for h in hubs:
+            h.flush()
+        for h in hubs[1:]:
+            assert list(h.stalled) == list(hubs[0].stalled) and h.superframes == hubs[0].superframes
+        assert hubs[0]._U * 512 == hubs[2]._U                             # a wire hub counts frames, a sample hub samples
+        assert list(hubs[0].dropped) == list(hubs[1].dropped) and list(hubs[0].dropped * 512) == list(hubs[2].dropped)
+        for c in range(n):
+            w = [drain(h.wf_queue[c]) for h in hubs]
+            s = [drain(h.snd_queue[c]) for h in hubs]
+            for other in (1, 2):
+                assert len(w[0]) == len(w[other]) and len(s[0]) == len(s[other]), ("counts", c, other)
+                for (la, na, _), (lb, nb, _) in zip(w[0], w[other]):
+                    assert na == nb and np.array_equal(la, lb), ("line", c, other)
+                for fa, fb in zip(s[0], s[other]):
+                    assert np.array_equal(np.asarray(fa), np.asarray(fb)) and fa.rssi == fb.rssi and fa.adc_overflow == fb.adc_overflow, ("frame", c, other)
+            compared += len(w[0]) + len(s[0])
+        return compared, int(hubs[0].stalled.sum())
+    finally:
+        for h in hubs:
+            h.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--first", type=int, default=1)
@@ -127,7 +194,7 @@ def main():
     lines, bad, items, stalls, t0 = [], 0, 0, 0, time.time()
     for seed in range(a.first, a.first + a.count):
         try:
-            c, s = one_sequence(S, IQHub, seed, a.steps)
+            c, s = (one_wire_sequence if seed % 4 == 3 else one_sequence)(S, IQHub, seed, a.steps)     # every fourth: SND bodies (wire hubs)
             items += c
             stalls += s
         except Exception as e:                                     # noqa: BLE001 -- reported per seed, the run goes on
@@ -135,7 +202,7 @@ def main():
             tb = traceback.format_exc().strip().splitlines()
             lines.append("  seed %d: %s: %s | %s" % (seed, type(e).__name__, e, " / ".join(x.strip() for x in tb[-4:-1])[:300]))
             print(lines[-1], flush=True)
-    lines.append("differential hub fuzz (synchronous vs pipelined IQHub): seeds %d..%d, %d steps each: %d sequences differed; %d queued lines / frames "
+    lines.append("differential hub fuzz (synchronous vs pipelined IQHub; every fourth sequence: SND bodies into wire hubs vs samples): seeds %d..%d, %d steps each: %d sequences differed; %d queued lines / frames "
                  "compared, %d stalled superframes on the way (%.0f s)" % (a.first, a.first + a.count - 1, a.steps, bad, items, stalls, time.time() - t0))
     text = "\n".join(lines) + "\n"
     print(text)
