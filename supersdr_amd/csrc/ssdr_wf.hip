@@ -65,6 +65,20 @@ static_assert(LDS_TOTAL <= 163840, "LDS budget");
 // (Scheduling fence only; emits no instruction.)
 #define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
+// Wave priority by phase (s_setprio): a SIMD issues from its highest-priority ready wave.  The butterfly stages have six independent
+// FMAs per butterfly and 16 butterflies per stage to pick from -- they can always issue; the audio chain's scans (DPP, dependent
+// chains), the quantiser's table look-ups, the loads and the stores mostly wait.  A wave in such a phase gets the issue slot the
+// moment it can use it, waves in the FFT take what is left: the four waves of a SIMD spread over the phases instead of
+// convoying through them.  +7 % on the fused kernel (profiles/r04_ab_wave_priority.txt); any level above 0 does it.
+#ifndef SSDR_PRIO
+#define SSDR_PRIO 1
+#endif
+#ifndef SSDR_PRIO_WF
+#define SSDR_PRIO_WF 1
+#endif
+SSDR_DEV void prio_latency_phase() { if (SSDR_PRIO) __builtin_amdgcn_s_setprio(3); }
+SSDR_DEV void prio_compute_phase() { if (SSDR_PRIO) __builtin_amdgcn_s_setprio(0); }
+
 __device__ constexpr int brev5(int v)
 {
     return ((v & 1) << 4) | ((v & 2) << 2) | (v & 4) | ((v & 8) >> 2) | ((v & 16) >> 4);
@@ -490,9 +504,11 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
 #pragma unroll
             for (int j = 0; j < 32; j++) x16[32 * ((j + 16) & 31)] = (int16_t)(raw[j] & 0xFF);
 #else
+            if (SSDR_PRIO_WF) prio_compute_phase();
             window_line(raw, smem, l, z);
             SCHED_FENCE();
             fft_line<AVG>(z, smem, xch_wave, h, l);
+            if (SSDR_PRIO_WF) prio_latency_phase();          // quantiser look-ups, the store, the next line's loads
 
             // |X|^2 -> 1-dB byte; bin k = 32 j + l lands at fftshifted position 32 ((j+16)&31) + l
             if (AVG) {
@@ -633,6 +649,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
             }
             wave_lds_sync();
             // ---- audio, phase 2: channel A, then channel B, two frames each, all 64 lanes on one channel
+            prio_latency_phase();                                             // (the call's first line; later ones arrive with it)
 #pragma unroll
             for (int c = 0; c < (SSDR_FUSED_ABLATE == 2 ? 0 : 2); c++) {      // (timing ablation 2: no audio chain)
                 if ((uint32_t)c >= n_sub) continue;                           // wave-uniform
@@ -669,6 +686,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                 }
             }
             wave_lds_sync();
+            prio_compute_phase();
             // ---- waterfall: the line out of the LDS (before the carried state takes its resting place in it again)
             uint32_t raw[32];
             {
@@ -706,6 +724,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
             window_line(raw, smem, l, z);
             SCHED_FENCE();
             fft_line<true>(z, smem, xch_wave, h, l);          // the averaging kernel's twiddle schedule: fewer registers in flight
+            prio_latency_phase();                             // quantiser look-ups, the line's store, the next line's loads and audio phase
             if (AVG) quantise32(z, cal_wf, lut, [&](int j, uint32_t q01) { acc[j] += q01; });
             else quantise32(z, cal_wf, lut, [&](int j, uint32_t q01) { qn[j] = q01; });
 #endif
