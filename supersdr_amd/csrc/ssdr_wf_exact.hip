@@ -31,6 +31,10 @@
 #define SSDR_WFX_WAVES_PER_EU 3
 #endif
 
+#ifndef SSDR_PRIO_EXACT
+#define SSDR_PRIO_EXACT 1            // wave priority by phase (ssdr_wf.hip: prio_latency_phase)
+#endif
+
 namespace {
 
 #define XDEV __device__ __forceinline__
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_wf
             for (uint32_t line = l0; line < l1; line++) {
                 // ---- the line: lane L holds samples 64 q + L
                 if (!PF) load_raw(ch_now, line, raw);
+                if (SSDR_PRIO_EXACT) __builtin_amdgcn_s_setprio(0);        // the butterflies yield to waves that load, look up or store
                 // ---- window (float32 table, products exact in double) with stage 1 folded in: sample n = 64 q + L pairs with
                 //      n + 512; w[n + 512] = w[512 - n] (symmetric table of 513)
                 cd z[16];
@@ -386,6 +391,7 @@ __global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_wf
                     }
                     XFENCE();
                 }
+                if (SSDR_PRIO_EXACT) __builtin_amdgcn_s_setprio(3);
                 // ---- power, exact threshold count.  Register 8 t + 4 c + mm holds FFT bin
                 //      k = 512 c + 256 t + 128 b4 + 64 b5 + 16 mm + lo4; pairs (c = 0, c = 1) share a dword: byte_c0 | byte_c1 << 16
                 uint32_t q01[8];
