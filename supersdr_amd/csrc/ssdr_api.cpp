@@ -954,7 +954,8 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         const uint64_t need = (pairs + SSDR_WF_BLOCK / 64 - 1) / (SSDR_WF_BLOCK / 64);
         const uint32_t grid = (uint32_t)(need < c->fused_grid ? need : c->fused_grid);
         if ((rc = timed_begin(c, s)) != SSDR_OK) return rc;
-        HIP_TRY(ssdr_launch_fused_am(fa, grid ? grid : 1, s));
+        if (c->exact_bins) HIP_TRY(ssdr_launch_fused_exact_am(fa, c->d_tw64, s));
+        else HIP_TRY(ssdr_launch_fused_am(fa, grid ? grid : 1, s));
         if ((rc = timed_end(c, SSDR_K_FUSED, s)) != SSDR_OK) return rc;
         if (fa.wf.tail)          // hop 512: only now may the carried half-line (the kernel's line 0 read it) become this batch's last one
             HIP_TRY(hipMemcpy2DAsync(c->d_wf_tail, (SSDR_NFFT / 2) * 4, fa.wf.iq + (size_t)(fa.wf.n_lines - 1) * SSDR_FRAME,
@@ -1016,9 +1017,11 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
     // carried state up once per call: measured ahead from there)
     const bool hop512 = c->hop == SSDR_NFFT / 2;            // (one line per frame: any frame count; hop 1024 needs whole lines)
     // (N > 1 and hop 512 are opt-in, ssdr_set_fused(ctx, 2): there the two stages side by side are faster)
+    // (with float64 bins: the float64 counterpart, ssdr_fused_exact_am_kernel -- hop 1024 and N = 1 only)
     const bool eligible = n_am == c->n_ch && c->decim == 1 && (hop512 || !(c->in_frames & 1u)) &&
                           c->in_frames >= 8 &&
-                          !c->concurrent && c->fused_grid != 0 && c->fused_enabled >= ((hop512 || c->n_avg > 1) ? 2 : 1) && !c->exact_bins && c->zoom == 1;
+                          !c->concurrent && c->fused_grid != 0 && c->fused_enabled >= ((hop512 || c->n_avg > 1) ? 2 : 1) && c->zoom == 1 &&
+                          (!c->exact_bins || (!hop512 && c->n_avg == 1));
     if (fused) *fused = eligible ? 1 : 0;
     c->fuse_next = eligible;
     // Everything else: the two stages side by side -- the audio stage on a second stream beside the waterfall kernel (one workgroup

@@ -152,6 +152,7 @@ hipError_t ssdr_launch_zoom(const SsdrZoomArgs &a, hipStream_t stream);
 struct SsdrFusedArgs { SsdrWfArgs wf; SsdrAudioArgs au; };
 hipError_t ssdr_launch_fused_am(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream);
 hipError_t ssdr_fused_blocks_per_cu(int *blocks);
+hipError_t ssdr_launch_fused_exact_am(const SsdrFusedArgs &a, const double2 *tw, hipStream_t stream);   // ssdr_wf_exact.hip: float64 bins; chooses its grid
 hipError_t ssdr_launch_wf(const SsdrWfArgs &a, uint32_t grid, hipStream_t stream);
 // float64 waterfall stage (ssdr_wf_exact.hip): twiddle tables of FFT stages 5..10, double2 entries (ssdr_make_tw64):
 //   T5[lo4] 16 | T6[q][lo4] 32 | T7[q][lo4] 64 | T8[q][lo4] 128 | T9[m][b4][lo4] 256 | T10[mm][b4][b5][lo4] 256

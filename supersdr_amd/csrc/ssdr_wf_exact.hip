@@ -22,7 +22,9 @@
 //     count table (ssdr_wf.hip:quantise, exhaustively verified) gives the exact count;
 //   * the int16 line is staged through the transpose buffer so that every lane stores 2 x 16 contiguous bytes.
 // 256-thread workgroups, three per CU (LDS: 4 x 8.1 KB transpose buffers + 16 KB of tables each), persistent grid.
+#include "ssdr_math.h"
 #include "ssdr_kernels.h"
+#include "ssdr_audio_dev.h"
 
 #ifndef SSDR_WFX_BLOCK
 #define SSDR_WFX_BLOCK 256
@@ -179,8 +181,147 @@ XDEV float scaled_power_trunc(cd x, double cal_scaled)
 XDEV double dbl_i16lo(uint32_t raw) { return (double)(int32_t)(raw << 16); }            // I * 2^16
 XDEV double dbl_i16hi(uint32_t raw) { return (double)(int32_t)(raw & 0xFFFF0000u); }    // Q * 2^16
 
+// One line: raw[q] = sample 64 q + lane (I | Q << 16) -> q01[4 t + mm] = byte of bin k (c = 0) | byte of bin k + 512 (c = 1) << 16,
+// k = 256 t + 128 b4 + 64 b5 + 16 mm + lo4 for this lane (b4, b5, lo4 = lane bits 4, 5, 0..3).  Window, FFT, power, threshold count.
+XDEV void exact_line_bytes(const uint32_t (&raw)[16], double cal, const unsigned char *smem, unsigned char *xch, const unsigned char *lut,
+                           int lane, uint32_t (&q01)[8])
+{
+    // ---- window (float32 table, products exact in double) with stage 1 folded in: sample n = 64 q + L pairs with
+    //      n + 512; w[n + 512] = w[512 - n] (symmetric table of 513)
+    cd z[16];
+    {
+        const int ll = opaque(lane);
+        const double *win_up = reinterpret_cast<const double *>(smem + LDS_WIN) + ll;
+        const double *win_dn = reinterpret_cast<const double *>(smem + LDS_WIN) + 512 - ll;
+        double wu[8], wd[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { wu[q] = win_up[64 * q]; wd[q] = win_dn[-64 * q]; }
+        XFENCE();
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            // I and Q converted where they sit in the dword, i.e. times 2^16 (one shift / one mask instead of a sign
+            // extension each); the window table carries the 2^-16: the products are the same doubles
+            const double w0 = wu[q], w1 = wd[q];
+            const double xr = dbl_i16lo(raw[q]), xi = dbl_i16hi(raw[q]);
+            const double yr = dbl_i16lo(raw[q + 8]), yi = dbl_i16hi(raw[q + 8]);
+            const double tr = xr * w0, ti = xi * w0;
+            z[brev4(q)] = cd{fma(yr, w1, tr), fma(yi, w1, ti)};
+            z[brev4(q) + 1] = cd{fma(-yr, w1, tr), fma(-yi, w1, ti)};
+        }
+    }
+    XFENCE();
+    stage_const<2>(z);
+    stage_const<3>(z);
+    stage_const<4>(z);
+    XFENCE();
+    // ---- transpose.  Register r of lane L is a-index 16 G + r, G = brev6(L) = hi2 << 4 | rho.  It goes to lane
+    //      L' = hi2 << 4 | lo4 (lo4 = r), register rho.  Slot of (rho, hi2, lo4): rho * 65 + hi2 * 16 + (lo4 ^ hi2).
+    {
+        const int lx = opaque(lane);
+        const int G = (int)(__builtin_bitreverse32((uint32_t)lx) >> 26);
+        const int hi2w = G >> 4, rho_w = G & 15;
+        double *wbase[4];
+#pragma unroll
+        for (int x = 0; x < 4; x++)
+            wbase[x] = reinterpret_cast<double *>(xch) + rho_w * XROW + hi2w * 16 + (x ^ hi2w);
+        const int hi2r = lx >> 4, lo4r = lx & 15;
+        const double *rbase = reinterpret_cast<const double *>(xch) + hi2r * 16 + (lo4r ^ hi2r);
+#pragma unroll
+        for (int r = 0; r < 16; r++) wbase[r & 3][r & 12] = z[r].r;
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 16; j++) z[j].r = rbase[j * XROW];
+        wave_lds_sync();
+#pragma unroll
+        for (int r = 0; r < 16; r++) wbase[r & 3][r & 12] = z[r].i;
+        wave_lds_sync();
+#pragma unroll
+        for (int j = 0; j < 16; j++) z[j].i = rbase[j * XROW];
+        wave_lds_sync();
+    }
+    // ---- stages 5..8: per-lane twiddles T_s[q][lo4]
+    {
+        const f64x2 *twl = reinterpret_cast<const f64x2 *>(smem + LDS_TW) + (opaque(lane) & 15);
+        f64x2 w5[1], w6[2], w7[4], w8[8];
+        w5[0] = twl[T5];
+#pragma unroll
+        for (int q = 0; q < 2; q++) w6[q] = twl[T6 + 16 * q];
+#pragma unroll
+        for (int q = 0; q < 4; q++) w7[q] = twl[T7 + 16 * q];
+        XFENCE();
+        stage_lane<0>(z, w5);
+        stage_lane<1>(z, w6);
+        XFENCE();
+#pragma unroll
+        for (int q = 0; q < 8; q++) w8[q] = twl[T8 + 16 * q];
+        XFENCE();
+        stage_lane<2>(z, w7);
+        XFENCE();
+        stage_lane<3>(z, w8);
+        XFENCE();
+    }
+    // ---- stage 9: pairs a-index bit 8 = lane bit 4.  After the swap lanes with bit 4 clear hold u, v of elements
+    //      rho = m (registers m, m + 8), the others of rho = m + 8; twiddle W_512^(16 rho + lo4)
+    {
+        const int lx = opaque(lane);
+        const f64x2 *t9 = reinterpret_cast<const f64x2 *>(smem + LDS_TW) + T9 + (lx & 31);     // [m][b4][lo4]
+        f64x2 w9[8];
+#pragma unroll
+        for (int m = 0; m < 8; m++) w9[m] = t9[32 * m];
+#pragma unroll
+        for (int m = 0; m < 8; m++) { swap16(z[m].r, z[m + 8].r); swap16(z[m].i, z[m + 8].i); }
+        XFENCE();
+#pragma unroll
+        for (int m = 0; m < 8; m++) bfly(z[m], z[m + 8], w9[m].x, w9[m].y);
+        XFENCE();
+    }
+    // ---- stage 10: pairs bit 9 = lane bit 5; register pairs (8 t + mm, 8 t + 4 + mm).  Afterwards the lane holds
+    //      elements rho = mm + 4 b5 + 8 b4 of both t; twiddle W_1024^(256 t + 16 rho + lo4) = (-j)^t W^(16 rho + lo4)
+    {
+        const int lx = opaque(lane);
+        const int e = ((lx >> 4) & 1) * 32 + (lx >> 5) * 16 + (lx & 15);                         // [mm][b4][b5][lo4]
+        const f64x2 *t10 = reinterpret_cast<const f64x2 *>(smem + LDS_TW) + T10 + e;
+        f64x2 w10[4];
+#pragma unroll
+        for (int mm = 0; mm < 4; mm++) w10[mm] = t10[64 * mm];
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int mm = 0; mm < 4; mm++) {
+                swap32(z[8 * t + mm].r, z[8 * t + 4 + mm].r);
+                swap32(z[8 * t + mm].i, z[8 * t + 4 + mm].i);
+            }
+        XFENCE();
+#pragma unroll
+        for (int mm = 0; mm < 4; mm++) {
+            bfly(z[mm], z[4 + mm], w10[mm].x, w10[mm].y);
+            bfly_mjw(z[8 + mm], z[12 + mm], w10[mm].x, w10[mm].y);
+        }
+        XFENCE();
+    }
+    // ---- power, exact threshold count.  Register 8 t + 4 c + mm holds FFT bin
+    //      k = 512 c + 256 t + 128 b4 + 64 b5 + 16 mm + lo4; pairs (c = 0, c = 1) share a dword: byte_c0 | byte_c1 << 16
+    {
+        float pc[16];
+        uint32_t e[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            pc[r] = scaled_power_trunc(z[r], cal);
+            e[r] = *reinterpret_cast<const uint32_t *>(lut + quant_addr(pc[r]));
+        }
+        XFENCE();
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+#pragma unroll
+            for (int mm = 0; mm < 4; mm++) {
+                const int r0 = 8 * t + mm, r1 = r0 + 4;
+                q01[4 * t + mm] = quant_pair(__float_as_uint(pc[r0]) + e[r0], __float_as_uint(pc[r1]) + e[r1]);
+            }
+    }
+}
+
 // AVG: averaging N > 1 (accumulators); HOP: lines overlap by half (hop 512)
-template <bool AVG, bool HOP, bool PF = false>
+template <bool AVG, bool HOP>
 __global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_wf_exact_kernel(SsdrWfArgs a, const double2 *tw_g)
 {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];
@@ -214,10 +355,6 @@ __global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_wf
             ge = gb + 1;
         }
     };
-    auto first_line = [&](uint32_t grp_) -> uint32_t {
-        const int64_t g0_ = (int64_t)grp_ * a.n_avg - a.phase;
-        return g0_ < 0 ? 0u : (uint32_t)g0_;
-    };
     // lane L fetches samples 64 q + L of line `ln` of channel `ch_` (hop 512: the older half, then the new one)
     auto load_raw = [&](uint32_t ch_, uint32_t ln, uint32_t (&raw_)[16]) {
         const uint32_t *src_ = a.iq + (uint64_t)ch_ * a.ch_stride + (uint64_t)ln * LINE_STEP + lane;
@@ -232,18 +369,7 @@ __global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_wf
             for (int q = 0; q < 16; q++) raw_[q] = __builtin_nontemporal_load(src_ + 64 * q);
         }
     };
-    // PF (A/B only, off): the samples of the NEXT line requested as soon as the window stage has consumed this line's.  Measured
-    // no gain (2.36 ms either way, profiles/r04_ab_wf_exact.txt): the kernel is bound by its ~940 VALU instructions per line
-    // (87 % of the issue slots busy), not by the memory round trip in front of each FFT -- and the second register set costs 32 moves
     uint32_t raw[16];
-    if (PF) {
-        const uint32_t it0 = blockIdx.x * WAVES + wave;
-        if (it0 < n_items) {
-            uint32_t c0, gb0, ge0;
-            decode(it0, c0, gb0, ge0);
-            load_raw(c0, first_line(gb0), raw);
-        }
-    }
 
     for (uint32_t item = blockIdx.x * WAVES + wave; item < n_items; item += wave_stride) {
         uint32_t ch, g_begin, g_end;
@@ -262,156 +388,11 @@ __global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_wf
             for (int j = 0; j < (AVG ? 8 : 1); j++) acc[j] = 0;
             for (uint32_t line = l0; line < l1; line++) {
                 // ---- the line: lane L holds samples 64 q + L
-                if (!PF) load_raw(ch_now, line, raw);
+                load_raw(ch_now, line, raw);
                 if (SSDR_PRIO_EXACT) __builtin_amdgcn_s_setprio(0);        // the butterflies yield to waves that load, look up or store
-                // ---- window (float32 table, products exact in double) with stage 1 folded in: sample n = 64 q + L pairs with
-                //      n + 512; w[n + 512] = w[512 - n] (symmetric table of 513)
-                cd z[16];
-                {
-                    const int ll = opaque(lane);
-                    const double *win_up = reinterpret_cast<const double *>(smem + LDS_WIN) + ll;
-                    const double *win_dn = reinterpret_cast<const double *>(smem + LDS_WIN) + 512 - ll;
-                    double wu[8], wd[8];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) { wu[q] = win_up[64 * q]; wd[q] = win_dn[-64 * q]; }
-                    XFENCE();
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        // I and Q converted where they sit in the dword, i.e. times 2^16 (one shift / one mask instead of a sign
-                        // extension each); the window table carries the 2^-16: the products are the same doubles
-                        const double w0 = wu[q], w1 = wd[q];
-                        const double xr = dbl_i16lo(raw[q]), xi = dbl_i16hi(raw[q]);
-                        const double yr = dbl_i16lo(raw[q + 8]), yi = dbl_i16hi(raw[q + 8]);
-                        const double tr = xr * w0, ti = xi * w0;
-                        z[brev4(q)] = cd{fma(yr, w1, tr), fma(yi, w1, ti)};
-                        z[brev4(q) + 1] = cd{fma(-yr, w1, tr), fma(-yi, w1, ti)};
-                    }
-                }
-                XFENCE();
-                if (PF) {                            // where the wave goes next (all of it scalar): the next line of this group, the first
-                    uint32_t n_ch_ = ch_now, n_ln = line + 1;       // line of the next group of the run, or of the next work item
-                    bool more = true;
-                    if (n_ln >= l1) {
-                        if (grp + 1 < g_end) n_ln = first_line(grp + 1);
-                        else if (item + wave_stride < n_items) {
-                            uint32_t gb, ge;
-                            decode(item + wave_stride, n_ch_, gb, ge);
-                            n_ln = first_line(gb);
-                        } else more = false;
-                    }
-                    if (more) load_raw(n_ch_, n_ln, raw);
-                    XFENCE();
-                }
-                stage_const<2>(z);
-                stage_const<3>(z);
-                stage_const<4>(z);
-                XFENCE();
-                // ---- transpose.  Register r of lane L is a-index 16 G + r, G = brev6(L) = hi2 << 4 | rho.  It goes to lane
-                //      L' = hi2 << 4 | lo4 (lo4 = r), register rho.  Slot of (rho, hi2, lo4): rho * 65 + hi2 * 16 + (lo4 ^ hi2).
-                {
-                    const int lx = opaque(lane);
-                    const int G = (int)(__builtin_bitreverse32((uint32_t)lx) >> 26);
-                    const int hi2w = G >> 4, rho_w = G & 15;
-                    double *wbase[4];
-#pragma unroll
-                    for (int x = 0; x < 4; x++)
-                        wbase[x] = reinterpret_cast<double *>(xch) + rho_w * XROW + hi2w * 16 + (x ^ hi2w);
-                    const int hi2r = lx >> 4, lo4r = lx & 15;
-                    const double *rbase = reinterpret_cast<const double *>(xch) + hi2r * 16 + (lo4r ^ hi2r);
-#pragma unroll
-                    for (int r = 0; r < 16; r++) wbase[r & 3][r & 12] = z[r].r;
-                    wave_lds_sync();
-#pragma unroll
-                    for (int j = 0; j < 16; j++) z[j].r = rbase[j * XROW];
-                    wave_lds_sync();
-#pragma unroll
-                    for (int r = 0; r < 16; r++) wbase[r & 3][r & 12] = z[r].i;
-                    wave_lds_sync();
-#pragma unroll
-                    for (int j = 0; j < 16; j++) z[j].i = rbase[j * XROW];
-                    wave_lds_sync();
-                }
-                // ---- stages 5..8: per-lane twiddles T_s[q][lo4]
-                {
-                    const f64x2 *twl = reinterpret_cast<const f64x2 *>(smem + LDS_TW) + (opaque(lane) & 15);
-                    f64x2 w5[1], w6[2], w7[4], w8[8];
-                    w5[0] = twl[T5];
-#pragma unroll
-                    for (int q = 0; q < 2; q++) w6[q] = twl[T6 + 16 * q];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) w7[q] = twl[T7 + 16 * q];
-                    XFENCE();
-                    stage_lane<0>(z, w5);
-                    stage_lane<1>(z, w6);
-                    XFENCE();
-#pragma unroll
-                    for (int q = 0; q < 8; q++) w8[q] = twl[T8 + 16 * q];
-                    XFENCE();
-                    stage_lane<2>(z, w7);
-                    XFENCE();
-                    stage_lane<3>(z, w8);
-                    XFENCE();
-                }
-                // ---- stage 9: pairs a-index bit 8 = lane bit 4.  After the swap lanes with bit 4 clear hold u, v of elements
-                //      rho = m (registers m, m + 8), the others of rho = m + 8; twiddle W_512^(16 rho + lo4)
-                {
-                    const int lx = opaque(lane);
-                    const f64x2 *t9 = reinterpret_cast<const f64x2 *>(smem + LDS_TW) + T9 + (lx & 31);     // [m][b4][lo4]
-                    f64x2 w9[8];
-#pragma unroll
-                    for (int m = 0; m < 8; m++) w9[m] = t9[32 * m];
-#pragma unroll
-                    for (int m = 0; m < 8; m++) { swap16(z[m].r, z[m + 8].r); swap16(z[m].i, z[m + 8].i); }
-                    XFENCE();
-#pragma unroll
-                    for (int m = 0; m < 8; m++) bfly(z[m], z[m + 8], w9[m].x, w9[m].y);
-                    XFENCE();
-                }
-                // ---- stage 10: pairs bit 9 = lane bit 5; register pairs (8 t + mm, 8 t + 4 + mm).  Afterwards the lane holds
-                //      elements rho = mm + 4 b5 + 8 b4 of both t; twiddle W_1024^(256 t + 16 rho + lo4) = (-j)^t W^(16 rho + lo4)
-                {
-                    const int lx = opaque(lane);
-                    const int e = ((lx >> 4) & 1) * 32 + (lx >> 5) * 16 + (lx & 15);                         // [mm][b4][b5][lo4]
-                    const f64x2 *t10 = reinterpret_cast<const f64x2 *>(smem + LDS_TW) + T10 + e;
-                    f64x2 w10[4];
-#pragma unroll
-                    for (int mm = 0; mm < 4; mm++) w10[mm] = t10[64 * mm];
-#pragma unroll
-                    for (int t = 0; t < 2; t++)
-#pragma unroll
-                        for (int mm = 0; mm < 4; mm++) {
-                            swap32(z[8 * t + mm].r, z[8 * t + 4 + mm].r);
-                            swap32(z[8 * t + mm].i, z[8 * t + 4 + mm].i);
-                        }
-                    XFENCE();
-#pragma unroll
-                    for (int mm = 0; mm < 4; mm++) {
-                        bfly(z[mm], z[4 + mm], w10[mm].x, w10[mm].y);
-                        bfly_mjw(z[8 + mm], z[12 + mm], w10[mm].x, w10[mm].y);
-                    }
-                    XFENCE();
-                }
-                if (SSDR_PRIO_EXACT) __builtin_amdgcn_s_setprio(3);
-                // ---- power, exact threshold count.  Register 8 t + 4 c + mm holds FFT bin
-                //      k = 512 c + 256 t + 128 b4 + 64 b5 + 16 mm + lo4; pairs (c = 0, c = 1) share a dword: byte_c0 | byte_c1 << 16
                 uint32_t q01[8];
-                {
-                    float pc[16];
-                    uint32_t e[16];
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        pc[r] = scaled_power_trunc(z[r], cal);
-                        e[r] = *reinterpret_cast<const uint32_t *>(lut + quant_addr(pc[r]));
-                    }
-                    XFENCE();
-#pragma unroll
-                    for (int t = 0; t < 2; t++)
-#pragma unroll
-                        for (int mm = 0; mm < 4; mm++) {
-                            const int r0 = 8 * t + mm, r1 = r0 + 4;
-                            q01[4 * t + mm] = quant_pair(__float_as_uint(pc[r0]) + e[r0], __float_as_uint(pc[r1]) + e[r1]);
-                        }
-                }
+                exact_line_bytes(raw, cal, smem, xch, lut, lane, q01);
+                if (SSDR_PRIO_EXACT) __builtin_amdgcn_s_setprio(3);
                 if (AVG) {
 #pragma unroll
                     for (int j = 0; j < 8; j++) acc[j] += q01[j];
@@ -441,6 +422,148 @@ __global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_wf
                     wave_lds_sync();
                 }
             }
+        }
+    }
+}
+
+// ---- both stages on one read of the input, float64 bins (the counterpart of ssdr_wf.hip:ssdr_fused_am_kernel<false, false>) -----------
+// ssdr_run_chain's kernel when ssdr_set_exact_bins is on and the batch is the metric's configuration: every channel on the full-band AM
+// path, N = 1, hop 1024.  A wave owns a channel for the whole call (the audio chain is sequential in time) and walks its lines.  Per
+// line: 16 streaming loads per lane bring the 4 KB line in the FFT's layout (lane L: samples 64 q + L) and stay in registers for the
+// FFT; a copy parks in the wave's transpose buffer, from which every lane takes its eight consecutive samples of each of the two
+// frames and runs exactly the stand-alone AM kernel's code (integer powers, demod_am, agc_pack_store, rssi_flag_step: same scans, same
+// orders); then exact_line_bytes as in the kernel above.  The audio chain runs at wave priority 3, the FFT at 0: the float64
+// butterflies of the other waves fill the time the scans wait.  Bit-identical to ssdr_wf_exact_kernel + ssdr_audio_kernel<2>.
+__global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_fused_exact_am_kernel(SsdrFusedArgs fa, const double2 *tw_g)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];
+    const SsdrWfArgs &a = fa.wf;
+    const SsdrAudioArgs &u = fa.au;
+    {
+        double *s_win = reinterpret_cast<double *>(smem + LDS_WIN);
+        uint32_t *s_lut = reinterpret_cast<uint32_t *>(smem + LDS_LUT0);
+        f64x2 *s_tw = reinterpret_cast<f64x2 *>(smem + LDS_TW);
+        for (int i = threadIdx.x; i < 513; i += blockDim.x) s_win[i] = (double)a.win[i] * 0x1p-16;
+        for (int i = threadIdx.x; i < SSDR_LUT_N; i += blockDim.x) s_lut[i] = a.lut[i];
+        for (int i = threadIdx.x; i < SSDR_TW64_N; i += blockDim.x) s_tw[i] = f64x2{tw_g[i].x, tw_g[i].y};
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char *xch = smem + LDS_XCH + wave * XCH_BYTES;
+    const unsigned char *lut = smem + LDS_LUT0;
+    uint32_t *q32 = reinterpret_cast<uint32_t *>(xch);                           // the raw line, sample n at q32[n]
+    const uint32_t wave_stride = gridDim.x * WAVES;
+    const uint32_t n_frames = u.n_frames;
+
+    for (uint32_t ch_v = blockIdx.x * WAVES + wave; ch_v < a.n_ch; ch_v += wave_stride) {
+        uint32_t ch = __builtin_amdgcn_readfirstlane(ch_v);
+        asm volatile("" : "+s"(ch));
+        const ssdr_chan_consts &kc = u.consts[ch];
+        const AgcK agc_c = {kc.agc_c0, kc.agc_c1, kc.agc_knee, kc.agc_delta8, kc.hang_frames};
+        const float cal_c = kc.smeter_cal_db;
+        const double cal = (double)kc.wf_cal_lin * (double)SSDR_LUT_SCALE;
+        // the audio chain's carried state (wave-uniform) and the two per-lane keepers
+        float dc, agc_d, agc_m[8];
+        uint32_t tail_q[4];
+        {
+            const ssdr_chan_state st = u.state[ch];
+            dc = st.dc; agc_d = st.agc_d;
+#pragma unroll
+            for (int i = 0; i < 8; i++) agc_m[i] = st.agc_m[i];
+            const uint4 t = *reinterpret_cast<const uint4 *>(u.hist + (size_t)ch * SSDR_HIST + SSDR_HIST - 4);
+            tail_q[0] = iq_power(t.x); tail_q[1] = iq_power(t.y); tail_q[2] = iq_power(t.z); tail_q[3] = iq_power(t.w);
+        }
+        float rssi_sum = 0.0f;
+        uint32_t flag_keep = 0u;
+        uint32_t raw[16];
+        const uint32_t *src = a.iq + (uint64_t)ch * a.ch_stride + lane;
+        if (SSDR_PRIO_EXACT) __builtin_amdgcn_s_setprio(3);
+        for (uint32_t line = 0; line < a.n_lines; line++, src += SSDR_NFFT) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) raw[q] = __builtin_nontemporal_load(src + 64 * q);
+            XFENCE();
+            {
+                uint32_t *qw = q32 + opaque(lane);
+#pragma unroll
+                for (int q = 0; q < 16; q++) qw[64 * q] = raw[q];
+            }
+            wave_lds_sync();
+            // ---- audio: two frames, lane l on samples 8 l .. 8 l + 7 of each
+#pragma unroll
+            for (int f = 0; f < 2; f++) {
+                const uint32_t frame = 2 * line + f;
+                const u32x4 *qp = reinterpret_cast<const u32x4 *>(q32 + SSDR_FRAME * f) + 2 * opaque(lane);
+                const u32x4 q0 = qp[0], q1 = qp[1];
+                const uint32_t rw[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+                uint32_t qv[8], d[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) qv[j] = iq_power(rw[j]);
+                float p[8], aud[8];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { d[j] = from_prev_lane_u(tail_q[j], qv[4 + j]); d[4 + j] = qv[j]; }
+#pragma unroll
+                for (int j = 0; j < 4; j++) tail_q[j] = lane63_u(qv[4 + j]);
+#pragma unroll
+                for (int j = 0; j < 8; j++) p[j] = (float)d[j];
+                const float pmx = block_peak(p);
+                const bool trig = wave_any(pmx >= 1073676160.0f) || tail_q[0] >= 0x3FFF0001u || tail_q[1] >= 0x3FFF0001u ||
+                                  tail_q[2] >= 0x3FFF0001u || tail_q[3] >= 0x3FFF0001u;
+                const bool clip = trig ? wave_any(raw_clipped(rw)) : false;
+                demod_am<true>(p, dc, aud);
+                agc_pack_store(p, aud, lane, agc_c, agc_d, agc_m, u.pcm + ((uint64_t)ch * n_frames + frame) * SSDR_FRAME + 8 * lane, pmx);
+                rssi_flag_step(p, clip, frame, n_frames, lane, cal_c, rssi_sum, flag_keep, u.rssi + (uint64_t)ch * n_frames, u.flags + (uint64_t)ch * n_frames);
+            }
+            wave_lds_sync();
+            // ---- waterfall: the line is still in registers
+            if (SSDR_PRIO_EXACT) __builtin_amdgcn_s_setprio(0);
+            uint32_t q01[8];
+            exact_line_bytes(raw, cal, smem, xch, lut, lane, q01);
+            if (SSDR_PRIO_EXACT) __builtin_amdgcn_s_setprio(3);
+            {
+                const int lx = opaque(lane);
+                int16_t *x16 = reinterpret_cast<int16_t *>(xch) + ((lx >> 4) & 1) * 128 + (lx >> 5) * 64 + (lx & 15);
+#pragma unroll
+                for (int t = 0; t < 2; t++)
+#pragma unroll
+                    for (int mm = 0; mm < 4; mm++) {
+                        const uint32_t v = q01[4 * t + mm];
+                        x16[512 + 256 * t + 16 * mm] = (int16_t)(v & 0xFFFFu);
+                        x16[256 * t + 16 * mm] = (int16_t)(v >> 16);
+                    }
+                wave_lds_sync();
+                const u32x4 *x128 = reinterpret_cast<const u32x4 *>(xch);
+                int16_t *dst = a.out + ((uint64_t)line * a.n_ch + ch) * SSDR_NFFT;
+#pragma unroll
+                for (int q = 0; q < 2; q++) __builtin_nontemporal_store(x128[q * 64 + lx], reinterpret_cast<u32x4 *>(dst) + q * 64 + lx);
+                wave_lds_sync();
+            }
+        }
+        // ---- state back to HBM
+        if (a.n_lines) {
+            // the raw tail of the call's last frame (its samples 384..511 = the line's 896..1023 = q 14, 15) is the next call's history
+#pragma unroll
+            for (int q = 14; q < 16; q++) u.hist[(size_t)ch * SSDR_HIST + 64 * (q - 14) + lane] = raw[q];
+            // the discriminator memory an AM channel leaves behind: y[511] = z1[507] of the last frame, mixed as the twin does (block 63 of
+            // the frame, element 3).  Sample 507 of that frame is the line's sample 1019 = raw[15] of lane 59.
+            ssdr_chan_state st = u.state[ch];
+            const uint32_t phi_last = st.phi1 + (uint32_t)(SSDR_FRAME * (n_frames - 1)) * kc.dphi1;
+            float fc, fs, qc, qs, bc, bs, cs, ss;
+            ssdr_phasor32(phi_last, fc, fs);
+            ssdr_phasor32((uint32_t)(8 * 63) * kc.dphi1, qc, qs);
+            ssdr_phasor32(kc.dphi1, cs, ss);
+            phasor_mul(fc, fs, qc, qs, bc, bs);
+#pragma unroll
+            for (int j = 0; j < 3; j++) { const float cn = fmaf(bc, cs, -(bs * ss)), sn = fmaf(bs, cs, bc * ss); bc = cn; bs = sn; }
+            const float xr = (float)(int16_t)(raw[15] & 0xFFFFu), xi = (float)((int32_t)raw[15] >> 16);
+            const float zr = fmaf(xr, bc, xi * bs) + 0.0f, zi = fmaf(xi, bc, -(xr * bs)) + 0.0f;
+            st.prev_re = lane_f(zr, 59);
+            st.prev_im = lane_f(zi, 59);
+            st.phi1 += (uint32_t)(SSDR_FRAME * n_frames) * kc.dphi1;
+            st.phi2 += (uint32_t)(SSDR_FRAME * n_frames) * kc.dphi2;
+            st.dc = dc; st.agc_d = agc_d;
+#pragma unroll
+            for (int i = 0; i < 8; i++) st.agc_m[i] = agc_m[i];
+            if (lane == 0) u.state[ch] = st;
         }
     }
 }
@@ -497,5 +620,25 @@ hipError_t ssdr_launch_wf_exact(const SsdrWfArgs &a_in, const double2 *tw, hipSt
         if (a.n_avg > 1) hipLaunchKernelGGL((ssdr_wf_exact_kernel<true, false>), g, b, 0, stream, a, tw);
         else hipLaunchKernelGGL((ssdr_wf_exact_kernel<false, false>), g, b, 0, stream, a, tw);
     }
+    return hipGetLastError();
+}
+
+// the fused float64 kernel: one wave per channel, persistent grid
+hipError_t ssdr_launch_fused_exact_am(const SsdrFusedArgs &a, const double2 *tw, hipStream_t stream)
+{
+    if (a.wf.n_ch == 0 || a.wf.n_lines == 0) return hipSuccess;
+    static uint32_t resident = 0;
+    if (!resident) {
+        int dev = 0, b = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ssdr_fused_exact_am_kernel, SSDR_WFX_BLOCK, 0)) != hipSuccess) return e;
+        resident = (uint32_t)prop.multiProcessorCount * (uint32_t)(b < 1 ? 1 : b);
+    }
+    constexpr uint32_t waves = SSDR_WFX_BLOCK / 64;
+    const uint64_t need = ((uint64_t)a.wf.n_ch + waves - 1) / waves;
+    hipLaunchKernelGGL(ssdr_fused_exact_am_kernel, dim3((uint32_t)(need < resident ? need : resident)), dim3(SSDR_WFX_BLOCK), 0, stream, a, tw);
     return hipGetLastError();
 }

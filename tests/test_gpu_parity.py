@@ -1185,6 +1185,58 @@ def test_fused_superframe_kernel_equals_the_two_kernels(S, twin, n_ch):
 
 
 @pytest.mark.parametrize("n_ch", [1, 7, 300])
+def test_fused_float64_kernel_equals_the_two_kernels_and_the_numpy_path(S, twin, n_ch):
+    """ssdr_set_exact_bins + ssdr_run_chain on the metric's configuration: ssdr_fused_exact_am_kernel reads each line once for its
+    float64 FFT and its two audio frames.  Waterfall, PCM, RSSI, flags, carried state and history are bit-identical to
+    ssdr_wf_exact_kernel followed by the AM audio kernel (ssdr_set_fused(0)), over several calls (state crossing them, > 64 frames in one,
+    a call under 8 frames through the two kernels in between), odd channel counts, clipping samples; the int16 bins equal the NumPy
+    float64 path bit for bit, the audio the fp32 twin.  Hop 512 and N > 1 keep the two kernels."""
+    rng = np.random.default_rng(40 + n_ch)
+    calls = [8, 2, 130] if n_ch <= 7 else [8, 2, 10]
+    n_frames = sum(calls)
+    iq = O.synth_iq(n_ch, n_frames * 512, seed=700 + n_ch)
+    iq[0, 3 * 512 + 511, 1] = -32768
+    cal = [float(rng.integers(-6, 7)) for _ in range(n_ch)]
+    ps = [S.default_params("am", f_shift_hz=float(rng.integers(-5900, 5900)), agc_hang=int(c % 3 == 0),
+                           agc_decay=float(rng.choice([400.0, 4000.0])), wf_cal_db=cal[c]) for c in range(n_ch)]
+    outs = {}
+    for fused in (False, True):
+        with S.SsdrEngine(n_ch) as eng:
+            eng.set_params(0, ps)
+            eng.set_exact_bins(True)
+            eng.set_fused(fused)
+            wfs, pcms, rssis, flags, pos = [], [], [], [], 0
+            for nf in calls:
+                eng.push_iq(iq[:, pos * 512:(pos + nf) * 512])
+                lines, was_fused = eng.run_chain()
+                assert was_fused == (fused and nf >= 8) and lines == nf // 2
+                wfs.append(eng.fetch_wf(lines))
+                p, r = eng.fetch_audio()
+                pcms.append(p), rssis.append(r), flags.append(eng.audio_flags())
+                pos += nf
+            consts, taps = eng.get_consts()
+            st, hist = eng.get_state()
+            if fused:                                                # what the float64 fused kernel does not cover stays with the two kernels
+                eng.set_hop(512)
+                eng.push_iq(iq[:, :8 * 512])
+                assert eng.run_chain()[1] is False
+                eng.set_hop(1024)
+                eng.set_averaging(3)
+                eng.push_iq(iq[:, :8 * 512])
+                assert eng.run_chain()[1] is False
+        outs[fused] = (np.concatenate(wfs), np.concatenate(pcms, axis=1), np.concatenate(rssis, axis=1),
+                       np.concatenate(flags, axis=1), st.tobytes(), hist)
+    for a, b in zip(outs[False], outs[True]):
+        assert (a == b) if isinstance(a, bytes) else np.array_equal(a, b)
+    st, hist = twinlib.fresh_state(consts)
+    pcm_t, rssi_t, flags_t = twin.audio(iq, consts, taps, st, hist, want_flags=True)
+    assert np.array_equal(outs[True][1], pcm_t) and np.array_equal(outs[True][2], rssi_t) and np.array_equal(outs[True][3], flags_t)
+    assert outs[True][4] == st.tobytes() and np.array_equal(outs[True][5], hist)
+    for c in range(0, n_ch, max(1, n_ch // 6)):                    # the NumPy float64 path, bit for bit
+        assert np.array_equal(outs[True][0][:, c], O.wf_sum_lines(iq[c].reshape(-1, 1024, 2), 1, cal[c])), c
+
+
+@pytest.mark.parametrize("n_ch", [1, 7, 300])
 def test_fused_kernel_at_hop_512_equals_the_two_kernels(S, twin, n_ch):
     """Round 4: ssdr_run_chain's one-read kernel at the reference's waterfall line rate (hop 512: a line per audio frame, the
     previous half-line re-read).  Waterfall lines, PCM, RSSI, flags, carried state, FIR history and the carried half-line are
