@@ -200,33 +200,13 @@ __global__ __launch_bounds__(256) void ssdr_db2col_kernel(SsdrDb2colArgs a)
 // history for the first frame of a call; the last frame's tail goes to `hist_out`, a different buffer).  Lane l takes input
 // positions m = 64 k + l: the nine samples it needs are nine conflict-free LDS reads shared by its four outputs, which
 // leave as ONE 16-byte store -- every store instruction of the wave writes 1 KB of contiguous output.
-__global__ __launch_bounds__(256) void ssdr_play_kernel(SsdrPlayArgs a)
+// PAN: which of the two pan factors is not 1.0 (0: neither, 1: left, 2: right, 3: both).  min(1 -+ balance, 1)^2 leaves at most one
+// of them below 1, and x * 1.0 == x: the unscaled side (and the recording branch's block) is the truncated sum itself.
+// The taps arrive multiplied by SAMPLE_RATIO = 4 (`h4`): a power of two commutes with every rounding of the sum (np.convolve's
+// products and partial sums are nowhere near the subnormals), so "* self.SAMPLE_RATIO" (:1134) costs nothing per output.
+template <int PAN>
+SSDR_DEV void play_frame(const double *s_x, const double (&h4)[33], double l2, double r2, int l, u32x4 *dst, int16_t *mono)
 {
-    __shared__ double s_xw[4][8 + SSDR_FRAME];                      // per wave: 8 carried samples + the frame, volume applied
-    const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t item = (uint64_t)blockIdx.x * 4 + wave;
-    if (item >= (uint64_t)a.n_sel * a.n_frames) return;
-    const uint32_t pos = (uint32_t)(item / a.n_frames), f = (uint32_t)(item - (uint64_t)pos * a.n_frames);
-    const uint32_t ch = a.sel ? a.sel[pos] : pos;
-    double *s_x = s_xw[wave];
-    const ssdr_play_chan pc = a.chans[pos];
-    const double vol = pc.volume / 100.0;
-    const double lv = fmin(1.0 - pc.balance, 1.0), rv = fmin(1.0 + pc.balance, 1.0);
-    const double l2 = lv * lv, r2 = rv * rv;
-    double h[33];
-#pragma unroll
-    for (int j = 0; j < 33; j++) h[j] = a.taps[j];                  // uniform address: scalar loads
-
-    const int16_t *src = a.pcm + ((uint64_t)ch * a.n_frames + f) * SSDR_FRAME;
-#pragma unroll
-    for (int k = 0; k < 8; k++) s_x[8 + 64 * k + l] = (double)src[64 * k + l] * vol;
-    if (l < 8) s_x[l] = f ? (double)src[l - 8] * vol : a.hist[(size_t)ch * 8 + l];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    u32x4 *dst = reinterpret_cast<u32x4 *>(a.out + ((uint64_t)pos * a.n_frames + f) * 2048 * 2);
-    int16_t *mono = a.mono ? a.mono + ((uint64_t)pos * a.n_frames + f) * 2048 : nullptr;
 #pragma unroll 2
     for (int k = 0; k < 8; k++) {
         const int m = 64 * k + l;
@@ -241,12 +221,12 @@ __global__ __launch_bounds__(256) void ssdr_play_kernel(SsdrPlayArgs a)
 #pragma unroll
             for (int t = 8; t >= 0; t--) {
                 const int j = r + 4 * t;
-                if (j <= 32) acc += h[j] * x[8 - t];
+                if (j <= 32) acc += h4[j] * x[8 - t];
             }
-            acc *= 4.0;
-            const int li = (int)(acc * l2), ri = (int)(acc * r2);        // trunc toward zero, then wrap to int16
+            const int mi = (int)acc;                                      // trunc toward zero, then wrap to int16
+            const int li = (PAN & 1) ? (int)(acc * l2) : mi, ri = (PAN & 2) ? (int)(acc * r2) : mi;
             o[r] = ((uint32_t)li & 0xFFFFu) | ((uint32_t)ri << 16);
-            mo[r] = (int)acc;
+            mo[r] = mi;
         }
         __builtin_nontemporal_store(u32x4{o[0], o[1], o[2], o[3]}, dst + m);
         if (mono) {                                                       // recording branch (:1139-1140)
@@ -255,6 +235,40 @@ __global__ __launch_bounds__(256) void ssdr_play_kernel(SsdrPlayArgs a)
             *reinterpret_cast<u32x2 *>(mono + 4 * m) = v;
         }
     }
+}
+
+__global__ __launch_bounds__(256) void ssdr_play_kernel(SsdrPlayArgs a)
+{
+    __shared__ double s_xw[4][8 + SSDR_FRAME];                      // per wave: 8 carried samples + the frame, volume applied
+    const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t item = (uint64_t)blockIdx.x * 4 + wave;
+    if (item >= (uint64_t)a.n_sel * a.n_frames) return;
+    const uint32_t pos = (uint32_t)(item / a.n_frames), f = (uint32_t)(item - (uint64_t)pos * a.n_frames);
+    const uint32_t ch = a.sel ? a.sel[pos] : pos;
+    double *s_x = s_xw[wave];
+    const ssdr_play_chan pc = a.chans[pos];
+    const double vol = pc.volume / 100.0;
+    const double lv = fmin(1.0 - pc.balance, 1.0), rv = fmin(1.0 + pc.balance, 1.0);
+    const double l2 = lv * lv, r2 = rv * rv;
+    double h4[33];
+#pragma unroll
+    for (int j = 0; j < 33; j++) h4[j] = a.taps[j] * 4.0;          // uniform address: scalar loads
+
+    const int16_t *src = a.pcm + ((uint64_t)ch * a.n_frames + f) * SSDR_FRAME;
+#pragma unroll
+    for (int k = 0; k < 8; k++) s_x[8 + 64 * k + l] = (double)src[64 * k + l] * vol;
+    if (l < 8) s_x[l] = f ? (double)src[l - 8] * vol : a.hist[(size_t)ch * 8 + l];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    u32x4 *dst = reinterpret_cast<u32x4 *>(a.out + ((uint64_t)pos * a.n_frames + f) * 2048 * 2);
+    int16_t *mono = a.mono ? a.mono + ((uint64_t)pos * a.n_frames + f) * 2048 : nullptr;
+    const int pan = __builtin_amdgcn_readfirstlane((l2 != 1.0 ? 1 : 0) | (r2 != 1.0 ? 2 : 0));      // per channel: wave-uniform
+    if (pan == 0) play_frame<0>(s_x, h4, l2, r2, l, dst, mono);
+    else if (pan == 1) play_frame<1>(s_x, h4, l2, r2, l, dst, mono);
+    else if (pan == 2) play_frame<2>(s_x, h4, l2, r2, l, dst, mono);
+    else play_frame<3>(s_x, h4, l2, r2, l, dst, mono);
     if (f + 1 == a.n_frames && l < 8) a.hist_out[(size_t)ch * 8 + l] = s_x[SSDR_FRAME + l];
 }
 
