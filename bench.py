@@ -372,7 +372,8 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     if fu_n:
         avg = fu_ms / fu_n
         b = channels * sframes * (4096.0 + (2 if hop == 512 else 1) * 2048.0 + 2048.0)      # SURVEY.md 8d, fused budget at N = 1: 4096 in + 2048 per line + 2048 PCM out
-        stages["fused"] = {"kernel": "ssdr_fused_am_kernel<%s, %s>" % ("true" if hop == 512 else "false", "true" if n_avg > 1 else "false"),
+        stages["fused"] = {"kernel": "ssdr_fused_exact_am_kernel (float64 waterfall)" if exact else
+                                     "ssdr_fused_am_kernel<%s, %s>" % ("true" if hop == 512 else "false", "true" if n_avg > 1 else "false"),
                            "avg_ms": avg, "launches": fu_n,
                            "bytes": b, "GBps": b / avg / 1e6, "units": channels * sframes}
     side = bool(do_wf and do_audio and "fused" not in stages and ((overlap and not exact) or concurrent & 1))

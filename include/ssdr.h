@@ -150,8 +150,10 @@ int ssdr_read_zoom(ssdr_ctx *ctx, uint32_t first, uint32_t count, int16_t *iq_ou
 /* Exact bins.  The waterfall kernel computes in float32; ~3e-4 of its bins, those whose |X| lies within the fp32 FFT's rounding
  * error of a 1-dB threshold, land one step away from where the float64 definition (oracle/ssdr_oracle.py: NumPy float64
  * FFT) puts them.  on = 1: ssdr_run_wf evaluates the stage in float64 instead (same window table, same thresholds) and
- * its int16 sums equal the float64 definition's bit for bit.  About 1.9x the default kernel's time (csrc/ssdr_wf_exact.hip); off by default;
- * not available to the fused kernel of ssdr_run_chain (which then runs the two stages). */
+ * its int16 sums equal the float64 definition's bit for bit.  About 1.9x the default kernel's time (csrc/ssdr_wf_exact.hip); off by default.
+ * ssdr_run_chain on the metric's configuration (every channel full-band AM, N = 1, hop 1024) then takes the float64 counterpart of
+ * its fused kernel (ssdr_fused_exact_am_kernel: one read of the input, same bits as the two kernels); every other batch runs the
+ * float64 waterfall kernel and the audio stage one after the other. */
 int ssdr_set_exact_bins(ssdr_ctx *ctx, int on);
 
 /* -- data plane.  ssdr_push_iq is the IQ ingest hook: KiwiSDRStream._process_iq_samples
