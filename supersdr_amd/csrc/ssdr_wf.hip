@@ -57,13 +57,8 @@ constexpr int LDS_LUT_END = LDS_LUT0 + SSDR_LUT_N * 4;
 constexpr int LDS_TW = (LDS_LUT_END + 15) & ~15;                // [4112, 12048)
 constexpr int LDS_XCH = LDS_TW + SSDR_TW_STAGE_N * 8;
 constexpr int LDS_TOTAL = LDS_XCH + WAVES * 2 * XCH_FLOATS * 4;
-// the fused kernel also keeps, per wave and channel of its pair, the audio chain's carried state (wave-uniform, 16 words):
-//   [0] dc  [1] agc_d  [4..7] integer powers of the previous frame's last four samples  [8..15] agc_m (hang only)
-constexpr int FSTATE_WORDS = 16;
-constexpr int LDS_FSTATE = LDS_TOTAL;
-constexpr int LDS_FUSED_TOTAL = LDS_FSTATE + WAVES * 2 * FSTATE_WORDS * 4;
-static_assert(LDS_XCH % 16 == 0 && LDS_TW % 8 == 0 && LDS_FSTATE % 16 == 0, "alignment");
-static_assert(2 * LDS_FUSED_TOTAL <= 163840, "LDS budget: two workgroups per CU");
+static_assert(LDS_XCH % 16 == 0 && LDS_TW % 8 == 0, "alignment");
+static_assert(LDS_TOTAL <= 163840, "LDS budget");
 
 // The register budget only holds if the phases of a line stay phases: without these fences
 // the machine scheduler hoists later phases' LDS table reads across the whole FFT and spills.
@@ -172,9 +167,6 @@ SSDR_DEV int opaque(int v)
     asm volatile("" : "+v"(v));
     return v;
 }
-
-SSDR_DEV uint32_t uni_u(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }      // a wave-uniform value into a scalar register
-SSDR_DEV float uni_f(float v) { return __uint_as_float(uni_u(__float_as_uint(v))); }
 
 SSDR_DEV void wave_lds_sync()
 {
@@ -579,7 +571,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
 template <bool HOP, bool AVG = false>
 __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fused_am_kernel(SsdrFusedArgs fa)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_FUSED_TOTAL];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];
     const SsdrWfArgs &a = fa.wf;
     const SsdrAudioArgs &u = fa.au;
     load_tables(smem, a.win, a.tw_stage, a.lut);
@@ -600,24 +592,24 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
         const float cal_wf = a.consts[ch].wf_cal_lin * SSDR_LUT_SCALE;
         const uint32_t n_sub = (2 * pair + 1 < a.n_ch) ? 2u : 1u;           // channels of this pair that exist
 
-        // The audio chain's carried state of both channels (wave-uniform) does not stay in registers across the FFT, which needs
-        // nearly all of them: it rests in the wave's own 2 x 16 words of LDS (a channel's audio phase reads what it needs with
-        // broadcast reads and lane 0 writes it back: the hang memory agc_m only where a hang is set).  Only the two per-lane keepers
-        // (RSSI sum, flag of frame f mod 64) stay in registers.
+        // The audio chain's carried state of both channels (wave-uniform: 14 words per channel) does not stay in registers
+        // across the FFT, which needs nearly all of them: between two audio phases it rests in the pad column of the wave's
+        // transpose buffer (index 33 i + 32, i >= 16: written by neither the transpose nor the line staging).  Only the two per-lane
+        // keepers (RSSI sum, flag of frame f mod 64) stay in registers.
         float rssi_sum[2] = {0.0f, 0.0f};
         uint32_t flag_keep[2] = {0u, 0u};
-        float *fstate = reinterpret_cast<float *>(smem + LDS_FSTATE) + wave * 2 * FSTATE_WORDS;          // wave-uniform
+        // (rows 16..31 of the pad column: the line staging reuses the first 2 KB of the buffer)
+        auto pad = [&](int c, int i) -> float & { return xch_wave[c * XCH_FLOATS + 33 * (i + 16) + 32]; };
         if (lane < 2) {
             const uint32_t cc = min(2 * pair + (uint32_t)lane, a.n_ch - 1);
             const ssdr_chan_state st = u.state[cc];
-            float *sc = fstate + lane * FSTATE_WORDS;
-            sc[0] = st.dc;
-            sc[1] = st.agc_d;
+            pad(lane, 0) = st.dc;
+            pad(lane, 1) = st.agc_d;
 #pragma unroll
-            for (int i = 0; i < 8; i++) sc[8 + i] = st.agc_m[i];
+            for (int i = 0; i < 8; i++) pad(lane, 2 + i) = st.agc_m[i];
             const uint4 t = *reinterpret_cast<const uint4 *>(u.hist + (size_t)cc * SSDR_HIST + SSDR_HIST - 4);
-            sc[4] = __uint_as_float(iq_power(t.x)); sc[5] = __uint_as_float(iq_power(t.y));
-            sc[6] = __uint_as_float(iq_power(t.z)); sc[7] = __uint_as_float(iq_power(t.w));
+            pad(lane, 10) = __uint_as_float(iq_power(t.x)); pad(lane, 11) = __uint_as_float(iq_power(t.y));
+            pad(lane, 12) = __uint_as_float(iq_power(t.z)); pad(lane, 13) = __uint_as_float(iq_power(t.w));
         }
         wave_lds_sync();
 
@@ -629,6 +621,18 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
         constexpr uint32_t LINE_STEP = HOP ? SSDR_NFFT / 2 : SSDR_NFFT;
         constexpr int FRAMES_PER_LINE = HOP ? 1 : 2;
         for (uint32_t line = 0; line < a.n_lines; line++, src += LINE_STEP) {
+            // ---- the carried state out of its resting place (the powers below overwrite it)
+            float dc[2], agc_d[2], agc_m[2][8];
+            uint32_t tail_q[2][4];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                dc[c] = pad(c, 0); agc_d[c] = pad(c, 1);
+#pragma unroll
+                for (int i = 0; i < 8; i++) agc_m[c][i] = pad(c, 2 + i);
+#pragma unroll
+                for (int i = 0; i < 4; i++) tail_q[c][i] = __float_as_uint(pad(c, 10 + i));
+            }
+            wave_lds_sync();
             // ---- audio, phase 1: the line's raw samples into the (still unused) transpose buffer, in the FFT's layout (lane l
             // of a half: samples 32 r + l).  The audio chain reads them back eight consecutive samples per lane, the FFT takes
             // them out of the LDS again afterwards: one read from HBM (streaming), none from the L2, and no 32 registers held
@@ -653,20 +657,8 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                 asm volatile("" : "+s"(pair_now));                              // fetched again (scalar loads) rather than kept across the FFT
                 const uint32_t cc = 2 * pair_now + c;
                 const ssdr_chan_consts &kc = u.consts[cc];
-                // (behind the line's stores the compiler no longer fetches these with scalar loads: wave-uniform values in vector
-                // registers, the hang count compared lane by lane.  Back into scalar registers, so that the hang branch is a scalar one.)
-                const AgcK agc_c = {uni_f(kc.agc_c0), uni_f(kc.agc_c1), uni_f(kc.agc_knee), uni_f(kc.agc_delta8), uni_u(kc.hang_frames)};
-                const float cal_c = uni_f(kc.smeter_cal_db);
-                float *sc = fstate + c * FSTATE_WORDS;
-                float dc_c = sc[0], agc_d_c = sc[1], agc_m_c[8];
-                const u32x4 tq = *reinterpret_cast<const u32x4 *>(sc + 4);
-                uint32_t tail_c[4] = {tq.x, tq.y, tq.z, tq.w};
-#pragma unroll
-                for (int i = 0; i < 8; i++) agc_m_c[i] = __builtin_nondeterministic_value(agc_m_c[i]);   // (never read without a hang)
-                if (agc_c.K != 0) {
-#pragma unroll
-                    for (int i = 0; i < 8; i++) agc_m_c[i] = sc[8 + i];
-                }
+                const AgcK agc_c = {kc.agc_c0, kc.agc_c1, kc.agc_knee, kc.agc_delta8, kc.hang_frames};
+                const float cal_c = kc.smeter_cal_db;
 #pragma unroll
                 for (int f = 0; f < FRAMES_PER_LINE; f++) {
                     const uint32_t frame = HOP ? line : 2 * line + f;               // hop 512: the new half of the line is the step's frame
@@ -678,37 +670,41 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                     for (int j = 0; j < 8; j++) qv[j] = iq_power(rw[j]);
                     float p[8], aud[8];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { d[j] = from_prev_lane_u(tail_c[j], qv[4 + j]); d[4 + j] = qv[j]; }
+                    for (int j = 0; j < 4; j++) { d[j] = from_prev_lane_u(tail_q[c][j], qv[4 + j]); d[4 + j] = qv[j]; }
 #pragma unroll
-                    for (int j = 0; j < 4; j++) tail_c[j] = lane63_u(qv[4 + j]);
+                    for (int j = 0; j < 4; j++) tail_q[c][j] = lane63_u(qv[4 + j]);
 #pragma unroll
                     for (int j = 0; j < 8; j++) p[j] = (float)d[j];
                     const float pmx = block_peak(p);                          // (also what the AGC takes as the block's peak)
-                    const bool trig = wave_any(pmx >= 1073676160.0f) || tail_c[0] >= 0x3FFF0001u || tail_c[1] >= 0x3FFF0001u ||
-                                      tail_c[2] >= 0x3FFF0001u || tail_c[3] >= 0x3FFF0001u;
+                    const bool trig = wave_any(pmx >= 1073676160.0f) || tail_q[c][0] >= 0x3FFF0001u || tail_q[c][1] >= 0x3FFF0001u ||
+                                      tail_q[c][2] >= 0x3FFF0001u || tail_q[c][3] >= 0x3FFF0001u;
                     const bool clip = trig ? wave_any(raw_clipped(rw)) : false;    // the exact check, only then
-                    demod_am<true>(p, dc_c, aud);
-                    agc_pack_store(p, aud, lane, agc_c, agc_d_c, agc_m_c, u.pcm + ((uint64_t)cc * n_frames + frame) * SSDR_FRAME + 8 * lane, pmx);
+                    demod_am<true>(p, dc[c], aud);
+                    agc_pack_store(p, aud, lane, agc_c, agc_d[c], agc_m[c], u.pcm + ((uint64_t)cc * n_frames + frame) * SSDR_FRAME + 8 * lane, pmx);
                     rssi_flag_step(p, clip, frame, n_frames, lane, cal_c, rssi_sum[c], flag_keep[c],
                                    u.rssi + (uint64_t)cc * n_frames, u.flags + (uint64_t)cc * n_frames);
-                }
-                if (lane == 0) {                                                   // ... and back to rest
-                    sc[0] = dc_c; sc[1] = agc_d_c;
-                    *reinterpret_cast<u32x4 *>(sc + 4) = u32x4{tail_c[0], tail_c[1], tail_c[2], tail_c[3]};
-                    if (agc_c.K != 0) {
-#pragma unroll
-                        for (int i = 0; i < 8; i++) sc[8 + i] = agc_m_c[i];
-                    }
                 }
             }
             wave_lds_sync();
             prio_compute_phase();
-            // ---- waterfall: the line out of the LDS
+            // ---- waterfall: the line out of the LDS (before the carried state takes its resting place in it again)
             uint32_t raw[32];
             {
                 const uint32_t *q = qbuf + opaque(h) * XCH_FLOATS + opaque(l);
 #pragma unroll
                 for (int r = 0; r < 32; r++) raw[r] = q[32 * r];
+            }
+            wave_lds_sync();
+            if (lane < 2) {                                                    // ... and back to rest
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    if (lane != c) continue;
+                    pad(c, 0) = dc[c]; pad(c, 1) = agc_d[c];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) pad(c, 2 + i) = agc_m[c][i];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) pad(c, 10 + i) = __uint_as_float(tail_q[c][i]);
+                }
             }
             wave_lds_sync();
             SCHED_FENCE();
@@ -790,9 +786,9 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                 st.prev_im = lane_f(zi, 32 * c + 27);
                 st.phi1 += (uint32_t)(SSDR_FRAME * n_frames) * kc.dphi1;
                 st.phi2 += (uint32_t)(SSDR_FRAME * n_frames) * kc.dphi2;
-                st.dc = fstate[c * FSTATE_WORDS]; st.agc_d = fstate[c * FSTATE_WORDS + 1];
+                st.dc = pad(c, 0); st.agc_d = pad(c, 1);
 #pragma unroll
-                for (int i = 0; i < 8; i++) st.agc_m[i] = fstate[c * FSTATE_WORDS + 8 + i];
+                for (int i = 0; i < 8; i++) st.agc_m[i] = pad(c, 2 + i);
                 if (lane == 0) u.state[cc] = st;
             }
         }
