@@ -1109,6 +1109,7 @@ static int ensure_play(ssdr_ctx *c)
         }
         double h[64];
         if (ssdr_design_lowpass(SSDR_RATE / 2.0, 48000.0, 63, h) != 33) return SSDR_EINVAL;             // filtering(KIWI_RATE/2, AUDIO_RATE)
+        for (int j = 0; j < 33; j++) h[j] *= 4.0;       // "* self.SAMPLE_RATIO" (:1134) folded into the taps: a power of two commutes with every rounding of the sum
         HIP_TRY(hipMemcpyAsync(c->d_play_taps, h, 33 * sizeof(double), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(c->d_play_rs_taps, SSDR_RS_TAPS, sizeof(SSDR_RS_TAPS), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));

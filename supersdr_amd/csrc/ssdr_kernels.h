@@ -91,7 +91,7 @@ struct SsdrPlayArgs {
     const int16_t *pcm;                      // [n_ch][n_frames*512]
     uint32_t n_ch, n_frames;
     const ssdr_play_chan *chans;             // [n_ch]
-    const double *taps;                      // [33] filtering(KIWI_RATE/2, AUDIO_RATE).h
+    const double *taps;                      // [33] filtering(KIWI_RATE/2, AUDIO_RATE).h times SAMPLE_RATIO = 4 (exact)
     const double *hist;                      // [n_ch][8] last 8 volume-scaled samples (the non-zero part of old_buffer) before the call
     double *hist_out;                        // [n_ch][8] ... after it (another buffer: frames of a channel run side by side)
     int16_t *out;                            // [n_ch][n_frames*2048][2]   (resampled path: [n_ch][n_frames*1213][2])

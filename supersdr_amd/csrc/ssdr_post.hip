@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void ssdr_play_kernel(SsdrPlayArgs a)
     const double l2 = lv * lv, r2 = rv * rv;
     double h4[33];
 #pragma unroll
-    for (int j = 0; j < 33; j++) h4[j] = a.taps[j] * 4.0;          // uniform address: scalar loads
+    for (int j = 0; j < 33; j++) h4[j] = a.taps[j];                // uniform address: scalar loads (the host uploads 4 h)
 
     const int16_t *src = a.pcm + ((uint64_t)ch * a.n_frames + f) * SSDR_FRAME;
 #pragma unroll
