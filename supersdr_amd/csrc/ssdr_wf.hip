@@ -32,6 +32,9 @@
 #ifndef SSDR_FUSED_ABLATE
 #define SSDR_FUSED_ABLATE 0                  // timing ablations of the fused kernel only (1: no FFT, 2: no audio chain)
 #endif
+#ifndef SSDR_FUSED_WIDE_LOADS
+#define SSDR_FUSED_WIDE_LOADS 1              // the fused kernel fetches a line 16 bytes per lane (A/B: 0 = 4 bytes per lane in the FFT's layout)
+#endif
 #ifndef SSDR_WF_PAIR_MAJOR
 #define SSDR_WF_PAIR_MAJOR 0
 #endif
@@ -633,10 +636,40 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                 for (int i = 0; i < 4; i++) tail_q[c][i] = __float_as_uint(pad(c, 10 + i));
             }
             wave_lds_sync();
-            // ---- audio, phase 1: the line's raw samples into the (still unused) transpose buffer, in the FFT's layout (lane l
-            // of a half: samples 32 r + l).  The audio chain reads them back eight consecutive samples per lane, the FFT takes
-            // them out of the LDS again afterwards: one read from HBM (streaming), none from the L2, and no 32 registers held
-            // across the audio chain.
+            // ---- audio, phase 1: the line's raw samples into the (still unused) transpose buffer, in natural order.  Nobody needs them
+            // in registers yet, so they come in the widest form: 16 bytes per lane, 1 KB contiguous per instruction, the whole wave on one
+            // channel at a time (8 load and 8 LDS store instructions per line pair instead of 32 and 16).  The audio chain reads them back
+            // eight consecutive samples per lane, the FFT takes them out of the LDS in its own layout afterwards: one read from HBM
+            // (streaming), none from the L2, and no 32 registers held across the audio chain.
+#if SSDR_FUSED_WIDE_LOADS
+            {
+                const uint32_t lw = opaque(lane);
+                u32x4 t[2][4];
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    uint32_t pair_now = __builtin_amdgcn_readfirstlane(pair);
+                    asm volatile("" : "+s"(pair_now));
+                    const uint32_t cc = min(2 * pair_now + (uint32_t)c, a.n_ch - 1);
+                    const uint32_t *row = a.iq + (uint64_t)cc * a.ch_stride + (uint64_t)line * LINE_STEP;       // the line's newest LINE_STEP samples
+                    if (HOP) {
+                        const uint32_t *older = line ? row - SSDR_NFFT / 2 : a.tail + (uint64_t)cc * (SSDR_NFFT / 2);
+#pragma unroll
+                        for (int i = 0; i < 2; i++) t[c][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(older) + 64 * i + lw);   // its last use
+#pragma unroll
+                        for (int i = 0; i < 2; i++) t[c][2 + i] = reinterpret_cast<const u32x4 *>(row)[64 * i + lw];      // read again one line later: L2
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; i++) t[c][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(row) + 64 * i + lw);
+                    }
+                }
+                SCHED_FENCE();
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) reinterpret_cast<u32x4 *>(qbuf + c * XCH_FLOATS)[64 * i + lw] = t[c][i];
+                SCHED_FENCE();
+            }
+#else
             {
                 uint32_t *q = qbuf + opaque(h) * XCH_FLOATS + opaque(l);
                 uint32_t t[32];                     // all 32 loads in flight, then the stores: left alone the compiler issues
@@ -647,6 +680,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                 for (int r = 0; r < 32; r++) q[32 * r] = t[r];
                 SCHED_FENCE();
             }
+#endif
             wave_lds_sync();
             // ---- audio, phase 2: channel A, then channel B, two frames each, all 64 lanes on one channel
             prio_latency_phase();                                             // (the call's first line; later ones arrive with it)
