@@ -65,7 +65,7 @@ F32_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: vector f
 RIDGE_FLOP_PER_BYTE = F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)          # 19.7
 # Executed vector work per unit: VALU wave-instructions from PMC SQ_INSTS_VALU / wave-units (profiles/r04_*_pmc_summary.txt:
 # 6.152e8 per 524 288 line pairs, 3.727e8 per 327 680, 1.2204e9 per 1 048 576 (hop 512); 5.456e8 / 1.898e8 / 7.958e7 per
-# 655 360 / 327 680 / 327 680 frames; the fused superframe kernel 1.1296e9 (hop 1024) / 1.7386e9 (hop 512) per 1 048 576
+# 655 360 / 327 680 / 327 680 frames; the fused superframe kernel 1.1262e9 (hop 1024) / 1.7386e9 (hop 512) per 1 048 576
 # channel-superframes; 7.031e8 per 262 144 frames at D = 4), FMA share from the opcode mix of the loops
 # (profiles/r04_isa_histograms.txt; the filters' multiply-adds -- 512 per frame for 33 taps, 2000 for 125 at D = 4 -- are dynamic).
 # lane-ops = 64 lanes x (instructions + FMA instructions): issue-slot work, see roofline().
@@ -77,7 +77,7 @@ KERNEL_VALU = {
     "ssdr_audio_kernel<0>": ("frame", 832.6, 0.75),
     "ssdr_audio_kernel<1>": ("frame", 579.2, 0.42),
     "ssdr_audio_kernel<2>": ("frame", 241, 0.22),
-    "ssdr_fused_am_kernel<false, false>": ("channel-superframe", 1077.2, 0.45),
+    "ssdr_fused_am_kernel<false, false>": ("channel-superframe", 1074.0, 0.45),
     "ssdr_fused_am_kernel<true, false>": ("channel-superframe", 1658.0, 0.50),
     "ssdr_audio_dec_kernel<4>": ("frame", 2682, 0.85),
 }
