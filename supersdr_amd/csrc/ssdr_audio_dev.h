@@ -294,7 +294,7 @@ SSDR_DEV float agc_pack_store(const float (&p)[8], const float (&aud)[8], int l,
         const int i0 = __float2int_rn(aud[j] * g), i1 = __float2int_rn(aud[j + 1] * g);
         w[j >> 1] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(i0, i1));
     }
-    __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(dst));
+    SSDR_NT_STORE(w, reinterpret_cast<u32x4 *>(dst));
     return g;
 }
 
@@ -307,8 +307,8 @@ SSDR_DEV void iq_pack_store(const float (&yr)[8], const float (&yi)[8], float g,
         const uint32_t v = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pk_i16(__float2int_rn(yr[j] * g), __float2int_rn(yi[j] * g)));
         if (j < 4) w0[j] = v; else w1[j - 4] = v;
     }
-    __builtin_nontemporal_store(w0, reinterpret_cast<u32x4 *>(dst));
-    __builtin_nontemporal_store(w1, reinterpret_cast<u32x4 *>(dst) + 1);
+    SSDR_NT_STORE(w0, reinterpret_cast<u32x4 *>(dst));
+    SSDR_NT_STORE(w1, reinterpret_cast<u32x4 *>(dst) + 1);
 }
 
 // Per-frame RSSI (sum over the frame = last lane of the inclusive sum scan) and ADC-overflow flag.  Lane (f mod 64)

@@ -8,6 +8,17 @@
 #include "ssdr_consts.h"
 
 #define SSDR_DEV __device__ __forceinline__
+// streaming accesses (A/B switches: -DSSDR_PLAIN_STORES / -DSSDR_PLAIN_LOADS)
+#ifdef SSDR_PLAIN_STORES
+#define SSDR_NT_STORE(v, p) (*(p) = (v))
+#else
+#define SSDR_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+#ifdef SSDR_PLAIN_LOADS
+#define SSDR_NT_LOAD(p) (*(p))
+#else
+#define SSDR_NT_LOAD(p) __builtin_nontemporal_load(p)
+#endif
 
 // sin/cos of 2*pi*(phase>>12)/2^20: 20-bit phase truncation (DDS practice), exact
 // integer quadrant reduction, minimax polynomials on [-pi/4, pi/4].

@@ -242,7 +242,7 @@ SSDR_DEV void quantise32(const f32x2 (&z)[32], float calq, const unsigned char *
 SSDR_DEV void load_line(const uint32_t *__restrict__ src /* + lane */, uint32_t (&raw)[32])
 {
 #pragma unroll
-    for (int r = 0; r < 32; r++) raw[r] = __builtin_nontemporal_load(src + 32 * r);
+    for (int r = 0; r < 32; r++) raw[r] = SSDR_NT_LOAD(src + 32 * r);
 }
 // hop 512: a line is the previous half-line followed by a new one.  The older half is the previous line's newer half,
 // which this very wave fetched one line earlier (a wave walks a run of consecutive lines of its channel pair, see the
@@ -250,7 +250,7 @@ SSDR_DEV void load_line(const uint32_t *__restrict__ src /* + lane */, uint32_t 
 SSDR_DEV void load_line_halves(const uint32_t *__restrict__ older, const uint32_t *__restrict__ newer, uint32_t (&raw)[32])
 {
 #pragma unroll
-    for (int r = 0; r < 16; r++) raw[r] = __builtin_nontemporal_load(older + 32 * r);        // its last use: do not keep it
+    for (int r = 0; r < 16; r++) raw[r] = SSDR_NT_LOAD(older + 32 * r);        // its last use: do not keep it
 #pragma unroll
     for (int r = 0; r < 16; r++) raw[16 + r] = newer[32 * r];
 }
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
             u32x4 v = x128[q * 32 + l];
             if (AVG && it.carry_in)         // wave-uniform; sums stay < 2^15 so a 32-bit add is a packed 2x16 add
                 v += reinterpret_cast<const u32x4 *>(cin)[q * 32 + l];
-            if (it.ch_ok) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst) + q * 32 + l);
+            if (it.ch_ok) SSDR_NT_STORE(v, reinterpret_cast<u32x4 *>(dst) + q * 32 + l);
         }
         wave_lds_sync();
       }
@@ -654,12 +654,12 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                     if (HOP) {
                         const uint32_t *older = line ? row - SSDR_NFFT / 2 : a.tail + (uint64_t)cc * (SSDR_NFFT / 2);
 #pragma unroll
-                        for (int i = 0; i < 2; i++) t[c][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(older) + 64 * i + lw);   // its last use
+                        for (int i = 0; i < 2; i++) t[c][i] = SSDR_NT_LOAD(reinterpret_cast<const u32x4 *>(older) + 64 * i + lw);   // its last use
 #pragma unroll
                         for (int i = 0; i < 2; i++) t[c][2 + i] = reinterpret_cast<const u32x4 *>(row)[64 * i + lw];      // read again one line later: L2
                     } else {
 #pragma unroll
-                        for (int i = 0; i < 4; i++) t[c][i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(row) + 64 * i + lw);
+                        for (int i = 0; i < 4; i++) t[c][i] = SSDR_NT_LOAD(reinterpret_cast<const u32x4 *>(row) + 64 * i + lw);
                     }
                 }
                 SCHED_FENCE();
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                 for (int q = 0; q < 4; q++) {
                     u32x4 v = x128[q * 32 + l];
                     if (carry_in) v += reinterpret_cast<const u32x4 *>(cin)[q * 32 + l];      // sums stay < 2^15: a packed 2 x 16 add
-                    if (ch_ok) __builtin_nontemporal_store(v, reinterpret_cast<u32x4 *>(dst) + q * 32 + l);
+                    if (ch_ok) SSDR_NT_STORE(v, reinterpret_cast<u32x4 *>(dst) + q * 32 + l);
                 }
                 wave_lds_sync();
                 if (AVG) {
