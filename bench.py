@@ -52,15 +52,22 @@ WORKLOADS = {
     "million": (1 << 20, 16,          1,     ("am",),               True, True),
     # the decimating front end (ssdr_set_decimation(4)): IQ at 48 kHz, 125-tap channel filters, waterfall lines from the wide stream
     "decim4": (16384,    8,           1,     ("usb", "lsb"),        True, True),
+    # configs[2]'s shape with the AM passband narrowed to +-4 kHz (change_passband, utils_supersdr.py:1078-1092): the channel filter is a
+    # real 25-tap FIR then and the NCO mixes -- every channel on the general path, which the default workload's full-band AM never times
+    "am_narrow": (65536, 16,          1,     ("am",),               True, True),
 }
 WORKLOAD_DECIM = {"decim4": 4}
+WORKLOAD_PARAMS = {"am_narrow": {"low_cut": -4000.0, "high_cut": 4000.0}}
 WORKLOAD_TEXT = {"full": "65536 channels full chain (WF + AM demod + AGC), BASELINE configs[2]",
                  "wf": "4096 channels batched 1024-pt FFT + log-mag waterfall only, BASELINE configs[1]",
                  "mixed": "65536 channels mixed AM/USB/LSB/NBFM + 10x time binning, BASELINE configs[3]",
                  "million": "2^20 channels full chain in total, channel-sharded, BASELINE configs[4]",
-                 "decim4": "16384 channels, IQ at 48 kHz (ssdr_set_decimation(4)): USB / LSB behind 125-tap decimating channel filters + waterfall"}
+                 "decim4": "16384 channels, IQ at 48 kHz (ssdr_set_decimation(4)): USB / LSB behind 125-tap decimating channel filters + waterfall",
+                 "am_narrow": "65536 channels full chain, every channel AM with the passband narrowed to +-4 kHz (NCO + 25-tap channel FIR: the general audio path)"}
 PATH_NAMES = ("FIR", "shift", "AM-shift")        # ssdr_audio_kernel<0|1|2>
 PATH_TEXT = ("general: NCO -> FIR -> demodulator", "full-band lane shift: NCO, no FIR", "full-band AM: no NCO, no FIR (|x e^{j phi}| = |x|)")
+# what the headline's audio stage does NOT time when every channel sits on the reference's default AM passband: extra.full_am_narrow does
+PATH_SHORT = ("general (NCO -> channel FIR -> demodulator)", "full-band lane shift (NCO, no FIR)", "full-band AM (no NCO, no FIR)")
 F32_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: vector f32 peak (an FMA = 2 flop)
 RIDGE_FLOP_PER_BYTE = F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)          # 19.7
 # Executed vector work per unit: VALU wave-instructions from PMC SQ_INSTS_VALU / wave-units (profiles/r04_*_pmc_summary.txt:
@@ -86,44 +93,90 @@ KERNEL_VALU = {
 # ---------------------------------------------------------------------------------------------------------------
 # CPU baseline (rank 0, N = 1 only): the oracle timed on the host cores on a bounded sample.  Reported, never the target.
 # ---------------------------------------------------------------------------------------------------------------
-def cpu_baseline(workload, budget_s=5.0):
-    """the NumPy float64 oracle (the code that defines parity) on all host cores
-    (`multiprocessing`, os.cpu_count() workers, channels block-sharded) and on one core; next to it the oracle's
-    fp32 C twin on all host threads."""
+def host_cores():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container that sees 256 logical CPUs
+    behind `cpu.max = 1600000 100000` gets 16 CPUs' worth of time: 256 busy workers are throttled to that).
+    -> (workers, dict with every number it was derived from)"""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota, src = None, None
+    try:                                                             # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        src = "/sys/fs/cgroup/cpu.max = %s %s" % (q, per)
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:                                                # noqa: BLE001
+        try:                                                         # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            src = "cpu.cfs_quota_us / cpu.cfs_period_us = %d / %d" % (q, per)
+            if q > 0:
+                quota = q / per
+        except Exception:                                            # noqa: BLE001
+            pass
+    workers = aff if quota is None else max(1, min(aff, int(quota)))
+    return workers, {"os_cpu_count": os.cpu_count(), "sched_affinity": aff, "cgroup_cpu_quota": quota, "cgroup_source": src, "workers": workers}
+
+
+def steady_oracle(CB, workers, job, seconds):
+    """`workers` processes, each on its own block of channels (oracle/cpu_bench.py:steady_worker): imports, IQ generation and a first
+    pass happen before a barrier; behind it every worker runs whole blocks back to back for >= `seconds`.
+    -> (channel-superframes per second over the slowest worker's elapsed time, wall of the slowest, per-worker rates)"""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")                # never fork a process that holds a HIP context
+    barrier, results = ctx.Barrier(workers), ctx.Queue()
+    procs = [ctx.Process(target=CB.steady_worker, args=(w,) + job + (seconds, barrier, results), daemon=True) for w in range(workers)]
+    for p in procs:
+        p.start()
+    got = []
+    try:
+        for _ in range(workers):
+            got.append(results.get(timeout=600))
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    errs = [g[3] for g in got if g[3]]
+    if errs:
+        raise RuntimeError("cpu_baseline worker failed: " + errs[0])
+    wall = max(g[2] for g in got)
+    return sum(g[1] for g in got) / wall, wall, sorted(g[1] / g[2] for g in got)
+
+
+def cpu_baseline(workload, seconds=3.0):
+    """the NumPy float64 oracle (the code that defines parity) on all the host cores this process may use
+    and on one; next to it the oracle's fp32 C twin on as many threads.  Round 5: the worker count is the affinity mask capped by
+    the cgroup quota (both in the line), the IQ is generated outside the timed region, every worker does >= `seconds` of back-to-back
+    blocks behind a barrier, and `scaling_efficiency` = all-core rate / (workers x one-process rate) is reported -- under 0.5 the
+    line says so, loudly."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import multiprocessing as mp
     import twinlib
     import ssdr_oracle as O
     import cpu_bench as CB                       # oracle/cpu_bench.py (test infrastructure, like the oracle itself)
     from concurrent.futures import ThreadPoolExecutor
     channels, sframes, n_avg, modes, do_wf, do_audio = WORKLOADS[workload]
-    cores = os.cpu_count() or 1
+    cores, host = host_cores()
     sf_np = min(sframes, 16)
+    n_blk = 8                                    # channels per block: 8 x 16 superframes is ~40 ms of one core
     for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):      # one thread per worker process (BASELINE.md 3a)
         os.environ[v] = "1"
-
-    # ---- NumPy oracle: one process first (calibration == the per-core figure), then all cores
-    CB.run_block((0, 1, 1, 1, modes, do_wf, do_audio))           # imports and first-call costs out of the way
-    t0 = time.perf_counter()
-    n1 = CB.run_block((0, 4, sf_np, n_avg, modes, do_wf, do_audio))
-    t1 = time.perf_counter() - t0
-    one = {"value": n1 * sf_np / t1 / RT_SUPERFRAMES_PER_S, "cores": 1, "sample": "4 ch x %d superframes, one process" % sf_np}
-    per = int(min(4096 // cores if cores <= 4096 else 1, max(1, budget_s / max(t1 / 4, 1e-9))))   # BASELINE.md: 4096 ch x 16 superframes
-    per = max(per, 1)
-    jobs = [(w * per, per, sf_np, n_avg, modes, do_wf, do_audio) for w in range(cores)]
-    ctx = mp.get_context("spawn")                # never fork a process that holds a HIP context
-    with ctx.Pool(cores) as pool:
-        # every worker up, imported and through one small block before the clock starts
-        pool.map(CB.run_block, [(0, 1, 1, 1, modes, do_wf, do_audio)] * (4 * cores), chunksize=1)
-        t0 = time.perf_counter()
-        done = sum(pool.map(CB.run_block, jobs, chunksize=1))
-        wall_np = time.perf_counter() - t0
-    box = done * sf_np / wall_np / RT_SUPERFRAMES_PER_S
+    job = (n_blk, sf_np, n_avg, modes, do_wf, do_audio)
+    r1, w1, _ = steady_oracle(CB, 1, job, seconds)
+    rN, wN, per = steady_oracle(CB, cores, job, seconds)
+    one = {"value": r1 / RT_SUPERFRAMES_PER_S, "cores": 1, "sample": "blocks of %d ch x %d superframes back to back for %.1f s, one process" % (n_blk, sf_np, w1)}
+    box = rN / RT_SUPERFRAMES_PER_S
+    eff = box / (cores * one["value"])
     out = {"value": box, "unit": "rt_channels", "cores": cores, "kind": "port", "per_core": box / cores,
-           "sample": "%d ch x %d superframes, block-sharded over %d processes, oracle/ssdr_oracle.py (NumPy float64), %.1f s"
-                     % (done, sf_np, cores, wall_np),
-           "one_process": one}
+           "sample": "%d processes (one per usable core), each blocks of %d ch x %d superframes of its own channels back to back for %.1f s behind a "
+                     "barrier, IQ generated before it; oracle/ssdr_oracle.py (NumPy float64)" % (cores, n_blk, sf_np, wN),
+           "one_process": one, "scaling_efficiency": eff, "host": host,
+           "worker_rates_rt_channels": {"min": per[0] / RT_SUPERFRAMES_PER_S, "median": per[len(per) // 2] / RT_SUPERFRAMES_PER_S, "max": per[-1] / RT_SUPERFRAMES_PER_S}}
+    if eff < 0.5:
+        out["scaling_note"] = ("LOW: %d workers give %.1fx one process (efficiency %.2f): shared memory bandwidth / SMT siblings / a quota "
+                               "tighter than cpu.max says" % (cores, box / one["value"], eff))
+        print("bench.py: cpu_baseline scaling efficiency %.2f < 0.5 on %d workers (%r)" % (eff, cores, host), file=sys.stderr, flush=True)
+    budget_s = seconds
 
     # ---- the fp32 C twin on all host threads (ctypes releases the GIL)
     twin = twinlib.load()
@@ -154,7 +207,7 @@ def cpu_baseline(workload, budget_s=5.0):
     t0 = time.perf_counter()
     work(blk)
     per_ch = (time.perf_counter() - t0) / 8
-    nch_core = int(max(8, min(1024, 0.5 * budget_s / max(per_ch, 1e-9))))       # threads share cores: half the single-thread estimate
+    nch_core = int(max(8, min(4096, budget_s / max(per_ch, 1e-9))))             # >= budget_s of work per thread, one thread per usable core
     block = make(nch_core)                        # same bytes for every worker
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:
@@ -233,7 +286,8 @@ def configure(S, eng, workload, channels, first_channel_id, hop=1024, fused=1, c
     if decim != 1:
         eng.set_decimation(decim)
     period = 97 * len(modes)                               # the parameter pattern repeats every len(modes) * 97 channels
-    params = [S.default_params(modes[(first_channel_id + c) % len(modes)], f_shift_hz=(((first_channel_id + c) * 37) % 97 - 48) * 100.0)
+    params = [S.default_params(modes[(first_channel_id + c) % len(modes)], f_shift_hz=(((first_channel_id + c) * 37) % 97 - 48) * 100.0,
+                               **WORKLOAD_PARAMS.get(workload, {}))
               for c in range(min(channels, period))]
     for first in range(0, channels, len(params)):
         eng.set_params(first, params[: min(len(params), channels - first)])
@@ -495,6 +549,18 @@ def measure_hub(S, L, torch, local_rank, channels, sframes, steps, in_place, bat
             "host_GBps": units * 4096.0 / wall / 1e9, "frames_queued_for_the_one_listener": q}
 
 
+def csrc_sha256():
+    """content hash of what libssdr.so is built from (supersdr_amd/csrc + include/ssdr.h): ties a PMC pass to the kernels it was taken on
+    (the GPU box has no .git; tools/profile_round.sh stores this hash, and the commit it was told, in the traffic JSON)"""
+    import glob, hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "supersdr_amd", "csrc", "*"))) + [os.path.join(ROOT, "include", "ssdr.h")]
+    for f in files:
+        if os.path.isfile(f) and not f.endswith((".o", ".so")):
+            h.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(workload, channels, sframes, hop=1024):
     """HBM bytes per launch from the PMC passes committed under profiles/ (collected with rocprofv3 in separate
     runs, corrected as MI355X_MICROARCH.md prescribes; tools/profile_round.sh + tools/traffic_json.py).
@@ -515,7 +581,12 @@ def pmc_traffic(workload, channels, sframes, hop=1024):
         if rnd == newest:
             found.update({k: v["hbm_bytes_per_launch"] for k, v in t["kernels"].items()})
             src = name if src is None else src + ", " + name
+            TRAFFIC_BUILD[name] = (t.get("git_commit"), t.get("csrc_sha256"))
     return found, src
+
+
+TRAFFIC_BUILD = {}          # traffic file -> (git commit, csrc hash) the PMC pass was taken at
+_STALE_WARNED = set()
 
 
 def stage_traffic(traffic, stage):
@@ -561,7 +632,18 @@ def roofline(stage, traffic=None, src=None):
         if fl / stage["bytes"] > RIDGE_FLOP_PER_BYTE:       # right of the ridge: the vector ALU's roof is the lower one
             r.update({"bound": "valu", "achieved": tf, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_PEAK_TFLOPS})
     if traffic is not None:
+        # `traffic` is a constant of the committed PMC pass, NOT an observation of this run: say where it comes from, which build it
+        # was taken on, and whether that build is this one
         r["traffic_source"] = "profiles/" + src
+        builds = [TRAFFIC_BUILD.get(n.strip(), (None, None)) for n in src.split(",")]
+        here = csrc_sha256()
+        r["traffic_commit"] = builds[0][0]
+        r["traffic_csrc_sha256"] = builds[0][1]
+        r["traffic_matches_this_build"] = all(b[1] == here for b in builds)
+        if not r["traffic_matches_this_build"] and src not in _STALE_WARNED:
+            _STALE_WARNED.add(src)
+            print("bench.py: WARNING: profiles/%s was taken on csrc %s (commit %s), this build is %s: roofline.traffic may be stale -- "
+                  "re-run tools/profile_round.sh" % (src, builds[0][1], builds[0][0], here), file=sys.stderr, flush=True)
     return r
 
 
@@ -698,9 +780,10 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": m["ms_per_step"],
         "higher_is_better": True, "scaling": "strong" if args.workload == "million" else "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": WORKLOAD_TEXT[args.workload],
+        "config": {"workload": WORKLOAD_TEXT[args.workload], "workload_key": args.workload,
                    "channels_per_gpu": channels, "superframes_per_step": sframes, "averaging_n": n_avg, "wf_hop": args.hop,
                    "audio_paths": {PATH_TEXT[p]: m["paths"][p] for p in range(3) if m["paths"][p]} if do_audio else {},
+                   "audio_path": (" + ".join(PATH_SHORT[p] for p in range(3) if m["paths"][p]) if do_audio else "none"),
                    "input_decimation": m["decim"], "wf_exact_bins": bool(args.exact),
                    "chain": ("ssdr_run_chain: one fused kernel for both stages (one read of the input; bit-identical to the two per-stage "
                              "kernels, which extra.full_two_kernels times)" if "fused" in m["stages"] else
@@ -712,6 +795,8 @@ def main():
                    "rendezvous": ("none" if world == 1 else rdv.backend if not rdv.fallback_reason else
                                   "gloo (RCCL FAILED: %s)" % rdv.fallback_reason)},
         "parity": parity,
+        "build": {"csrc_sha256": csrc_sha256(), "git_commit": open(os.path.join(ROOT, ".ssdr_head")).read().strip()
+                  if os.path.exists(os.path.join(ROOT, ".ssdr_head")) else None},
         "per_rank": {"value_min": min(per_rank), "value_max": max(per_rank), "values": per_rank,
                      "note": "each rank's own channel-superframes / its own wall time; `value` uses the max wall over ranks"},
         "roofline": roofline(stages[dom], stage_traffic(traffic, stages[dom]), src),
@@ -791,6 +876,7 @@ def main():
         e = run_extra("wf_hop512", "wf", nst, ", hop 512 (23.4 lines/s)", hop=512)
         if e is not None:
             extra["wf_hop512"]["lines_per_s"] = e["stages"]["wf"]["lines_per_launch"] / e["ms_per_step"] * 1e3
+        run_extra("full_am_narrow", "am_narrow", nst, ": what an AM listener who narrows the passband gets -- the general audio path beside the waterfall kernel")
         run_extra("full_hop512", "full", nst, ", waterfall at hop 512 (23.4 lines/s, the reference's line rate), the two stages side by side", hop=512)
         # configs[4] at N = 1 (2^20 channels on this one GPU, 16 superframes per call) and the decimating front end
         run_extra("million", "million", 5, warm=1, spin=0.3)
@@ -834,18 +920,20 @@ def compact_line(full):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     out = {k: full[k] for k in keep}
     c = full["config"]
-    out["config"] = {k: c[k] for k in ("workload", "channels_per_gpu", "superframes_per_step", "averaging_n", "wf_hop", "wf_exact_bins",
-                                        "input", "sharding", "rendezvous")}
+    out["config"] = {k: c[k] for k in ("workload", "workload_key", "channels_per_gpu", "superframes_per_step", "averaging_n", "wf_hop", "wf_exact_bins",
+                                        "audio_path", "input", "sharding", "rendezvous")}
     out["config"]["chain"] = "fused kernel (ssdr_run_chain)" if c["chain"].startswith("ssdr_run_chain") else c["chain"]
     p = full["parity"]
     out["parity"] = {k: p[k] for k in ("ranks_agree", "checksums", "skipped") if k in p}
     out["per_rank"] = {k: full["per_rank"][k] for k in ("value_min", "value_max")}
     r = full["roofline"]
-    out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_hbm", "traffic", "avg_kernel_ms",
+    out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_hbm", "traffic", "traffic_source",
+                                          "traffic_commit", "traffic_csrc_sha256", "traffic_matches_this_build", "avg_kernel_ms",
                                           "algorithmic_bytes_per_launch", "stages") if k in r}
+    out["build"] = full.get("build")
     if "cpu_baseline" in full:
         cb = full["cpu_baseline"]
-        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
+        out["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "sample", "scaling_efficiency", "scaling_note", "host") if k in cb}
         for k in ("c_twin", "one_process"):
             if k in cb:
                 out["cpu_baseline"][k + "_value"] = cb[k]["value"]

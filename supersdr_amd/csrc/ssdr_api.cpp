@@ -774,16 +774,27 @@ int ssdr_read_input(ssdr_ctx *c, uint32_t first, uint32_t count, int16_t *iq_out
     return SSDR_OK;
 }
 
+// The shape rules of a waterfall batch, checked before ANY stage of a call is launched (ssdr_run_chain runs its audio stage first
+// when the stages go side by side: a batch the waterfall stage would refuse must not have advanced the audio state by then).
+static int validate_wf_batch(const ssdr_ctx *c)
+{
+    const bool hop512 = c->hop == SSDR_NFFT / 2;
+    const bool zoomed = c->zoom > 1;
+    if (zoomed && (c->fuse_next || (c->in_frames * c->decim) % c->zoom)) return SSDR_EINVAL;
+    const uint32_t halves = c->in_frames * c->decim / c->zoom;       // 512-sample half-lines the batch yields (of the zoomed stream)
+    if (!hop512 && (halves & 1u)) return SSDR_EINVAL;                // a batch must hold a whole number of lines
+    if (zoomed && halves == 0) return SSDR_EINVAL;
+    return SSDR_OK;
+}
+
 int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out_is_device)
 {
     if (!c) return SSDR_EINVAL;
     if (!c->have_input) return SSDR_ESTATE;
     const bool hop512 = c->hop == SSDR_NFFT / 2;
     const bool zoomed = c->zoom > 1;
-    if (zoomed && (c->fuse_next || (c->in_frames * c->decim) % c->zoom)) return SSDR_EINVAL;
-    const uint32_t halves = c->in_frames * c->decim / c->zoom;       // 512-sample half-lines the batch yields (of the zoomed stream)
-    if (!hop512 && (halves & 1u)) return SSDR_EINVAL;
-    if (zoomed && halves == 0) return SSDR_EINVAL;                   // a batch must hold a whole number of lines
+    { const int rcv = validate_wf_batch(c); if (rcv != SSDR_OK) return rcv; }
+    const uint32_t halves = c->in_frames * c->decim / c->zoom;
     HIP_TRY(hipSetDevice(c->device));
     const uint32_t *wf_src = c->d_iq;                                // what the waterfall kernel reads: the input, or the zoomed stream
     uint64_t wf_stride = (uint64_t)in_len(c, c->in_frames);
@@ -1024,6 +1035,14 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
                           (!c->exact_bins || (!hop512 && c->n_avg == 1));
     if (fused) *fused = eligible ? 1 : 0;
     c->fuse_next = eligible;
+    {   // both stages or neither: what ssdr_run_wf and ssdr_run_audio would refuse is refused before either is launched
+        int rcv = validate_wf_batch(c);
+        if (rcv == SSDR_OK && c->decim > 1) {
+            chan_summary(c);
+            if (c->sum_paths[SSDR_PATH_DELAY4] || c->sum_paths[SSDR_PATH_AM_RAW]) rcv = SSDR_ESTATE;
+        }
+        if (rcv != SSDR_OK) { c->fuse_next = false; if (fused) *fused = 0; return rcv; }
+    }
     // Everything else: the two stages side by side -- the audio stage on a second stream beside the waterfall kernel (one workgroup
     // per CU then), each filling the issue slots the other leaves: +2.7 % on configs[3], +9 % on the full chain at hop 512
     // (profiles/r04_ab_overlap.txt; there it beats the one-read kernel too, which is why that one is opt-in at hop 512)

@@ -1349,6 +1349,32 @@ def test_run_chain_side_by_side_stages_are_bit_identical_and_joined_before_what_
         assert (a == b) if isinstance(a, (bytes, tuple)) else np.array_equal(a, b)
 
 
+def test_a_refused_run_chain_leaves_every_stream_untouched(S, twin):
+    """Round 5 (advisor): with the stages side by side ssdr_run_chain launches the audio stage FIRST, so the waterfall stage's
+    shape rules (a whole number of lines at hop 1024) are checked before either is launched: a refused batch advances nothing,
+    and the caller who fixes the batch and retries gets the stream it would have got without the mistake."""
+    n_ch = 9
+    iq = O.synth_iq(n_ch, 7 * 512, seed=515)
+    ps, _ = mixed_params(S, n_ch)
+    with S.SsdrEngine(n_ch) as eng, S.SsdrEngine(n_ch) as ref:
+        for e in (eng, ref):
+            e.set_params(0, ps)
+            e.set_averaging(2)
+            e.push_iq(iq[:, :4 * 512])
+            e.run_chain()
+        before = (eng.get_state()[0].tobytes(), eng.get_state()[1].tobytes(), eng.output_checksum())
+        eng.push_iq(iq[:, 4 * 512:7 * 512])                  # three frames: one and a half lines
+        with pytest.raises(S.SsdrError):
+            eng.run_chain()
+        assert (eng.get_state()[0].tobytes(), eng.get_state()[1].tobytes(), eng.output_checksum()) == before
+        for e in (eng, ref):                                 # the retry with a well-formed batch continues where the stream stood
+            e.push_iq(iq[:, 4 * 512:6 * 512])
+            lines, _ = e.run_chain()
+        assert np.array_equal(eng.fetch_wf(lines), ref.fetch_wf(lines))
+        assert np.array_equal(eng.fetch_audio()[0], ref.fetch_audio()[0])
+        assert eng.get_state()[0].tobytes() == ref.get_state()[0].tobytes()
+
+
 def test_run_chain_on_a_callers_stream_leaves_both_stages_ordered_behind_it(S):
     """ssdr_set_stream: a caller that orders its own work behind its own stream (and never calls ssdr_sync) must see the audio
     stage too, although that one ran on the ctx's second stream: ssdr_run_chain joins it before returning.  The results are read

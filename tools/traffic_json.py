@@ -13,6 +13,7 @@ The bench line of the traced run names the workload shape; kernels are keyed the
 """
 import csv
 import json
+import os
 import re
 import sys
 from collections import defaultdict
@@ -35,9 +36,12 @@ def main():
     cfg = line["config"]
     fetch = mean_per_kernel(d + "/fetch_counter_collection.csv", "FETCH_SIZE")
     write = mean_per_kernel(d + "/write_counter_collection.csv", "WRITE_SIZE")
-    wl = [k for k in ("full", "wf", "mixed", "million", "decim4") if {"full": "configs[2]", "wf": "configs[1]", "mixed": "configs[3]",
+    wl = cfg["workload_key"] if "workload_key" in cfg else [k for k in ("full", "wf", "mixed", "million", "decim4") if {"full": "configs[2]", "wf": "configs[1]", "mixed": "configs[3]",
                                                                      "million": "configs[4]", "decim4": "ssdr_set_decimation(4)"}[k] in cfg["workload"]][0]
-    out = {"workload": wl, "channels_per_gpu": cfg["channels_per_gpu"], "superframes_per_step": cfg["superframes_per_step"],
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    head = os.path.join(bench.ROOT, ".ssdr_head")          # written by tools/stamp_head.sh before the snapshot goes to the GPU box
+    out = {"workload": wl, "git_commit": open(head).read().strip() if os.path.exists(head) else None, "csrc_sha256": bench.csrc_sha256(), "channels_per_gpu": cfg["channels_per_gpu"], "superframes_per_step": cfg["superframes_per_step"],
            "wf_hop": cfg.get("wf_hop", 1024),
            "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; bytes = 2*FETCH_KB*1024 + WRITE_KB*1024",
            "kernels": {}}
