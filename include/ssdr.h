@@ -184,7 +184,10 @@ int ssdr_audio_iq(ssdr_ctx *ctx, int16_t *iq_out, int out_is_device);
  * runs its batches through this call. */
 int ssdr_run_chain(ssdr_ctx *ctx, uint32_t *lines_ready, int *fused);
 /* 0: never the fused kernel; 1 (default): at hop 1024 with N = 1; 2: at hop 512 and with N > 1 as well (there the two stages side
- * by side are as fast or faster: ssdr_set_overlap) */
+ * by side are as fast or faster: ssdr_set_overlap); 3: also the general-mode kernel (ssdr_fused_gen_kernel, round 5): ANY mix of audio
+ * paths (AM / SSB / CW / NBFM, narrowed passbands) and any N at hop 1024 on one read of the input -- channel filters of up to 33 taps,
+ * no SSDR_MODE_IQ channel, fp32 bins, an even number of at least 4 frames; bit-identical to the two kernels.  *fused of ssdr_run_chain
+ * is then 2. */
 int ssdr_set_fused(ssdr_ctx *ctx, int on);
 /* Batches ssdr_run_chain does not fuse (mixed modes, N > 1, hop 512, float64 bins, ...) run their two stages SIDE BY SIDE: the audio
  * stage on a second HIP stream beside the waterfall kernel, both reading the same input batch (default on; results are those of

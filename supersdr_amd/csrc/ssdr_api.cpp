@@ -60,9 +60,12 @@ struct ssdr_ctx {
     bool summary_dirty = true;                          // path counts / any channel in IQ mode: recounted after the constants change
     uint32_t sum_paths[SSDR_PATH_COUNT] = {0, 0, 0};
     bool sum_any_iq = false;
+    uint32_t sum_gen_ntap = 0;                          // the longest channel filter among the general-path channels
     hipStream_t path_stream[SSDR_PATH_COUNT - 1] = {};  // the audio kernels of different paths run side by side
     hipEvent_t ev_fork = nullptr, ev_path[SSDR_PATH_COUNT - 1] = {};
-    int fused_enabled = 1;                              // ssdr_set_fused: 0 never, 1 at hop 1024 (default), 2 at hop 512 as well
+    int fused_enabled = 1;                              // ssdr_set_fused: 0 never, 1 at hop 1024 (default), 2 at hop 512 as well, 3 + the general-mode kernel
+    bool fuse_gen_next = false;                         // ... and that kernel is ssdr_fused_gen_kernel (any mix of audio paths)
+    uint32_t gen_grid = 0;
     bool overlap_enabled = true;                        // ssdr_set_overlap: un-fused ssdr_run_chain batches run the audio stage beside the waterfall kernel
     bool fuse_next = false;                             // ssdr_run_chain: run_wf parks its arguments, run_audio launches the fused kernel
     SsdrWfArgs fused_wf;
@@ -441,6 +444,9 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         int fused_per_cu = 0;
         HIP_TRY(ssdr_fused_blocks_per_cu(&fused_per_cu));
         c->fused_grid = (uint32_t)prop.multiProcessorCount * (uint32_t)(fused_per_cu < 1 ? 1 : fused_per_cu);
+        int gen_per_cu = 0;
+        HIP_TRY(ssdr_fused_gen_blocks_per_cu(&gen_per_cu));
+        c->gen_grid = (uint32_t)prop.multiProcessorCount * (uint32_t)(gen_per_cu < 1 ? 1 : gen_per_cu);
         return SSDR_OK;
     }();
     if (rc == SSDR_OK) {
@@ -699,9 +705,12 @@ static void chan_summary(ssdr_ctx *c)
     if (!c->summary_dirty) return;
     for (int p = 0; p < SSDR_PATH_COUNT; p++) c->sum_paths[p] = 0;
     c->sum_any_iq = false;
+    c->sum_gen_ntap = 0;
     for (uint32_t ch = 0; ch < c->n_ch; ch++) {
-        c->sum_paths[ssdr_audio_path(c->h_consts[ch])]++;
+        const int path = ssdr_audio_path(c->h_consts[ch]);
+        c->sum_paths[path]++;
         c->sum_any_iq = c->sum_any_iq || c->h_consts[ch].mode == SSDR_MODE_IQ;
+        if (path == SSDR_PATH_GENERAL) c->sum_gen_ntap = std::max(c->sum_gen_ntap, c->h_consts[ch].ntap);
     }
     c->summary_dirty = false;
 }
@@ -965,7 +974,11 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         const uint64_t need = (pairs + SSDR_WF_BLOCK / 64 - 1) / (SSDR_WF_BLOCK / 64);
         const uint32_t grid = (uint32_t)(need < c->fused_grid ? need : c->fused_grid);
         if ((rc = timed_begin(c, s)) != SSDR_OK) return rc;
-        if (c->exact_bins) HIP_TRY(ssdr_launch_fused_exact_am(fa, c->d_tw64, s));
+        if (c->fuse_gen_next) {
+            const uint64_t need_g = (pairs + SSDR_GEN_BLOCK / 64 - 1) / (SSDR_GEN_BLOCK / 64);
+            const uint32_t grid_g = (uint32_t)(need_g < c->gen_grid ? need_g : c->gen_grid);
+            HIP_TRY(ssdr_launch_fused_gen(fa, grid_g ? grid_g : 1, s));
+        } else if (c->exact_bins) HIP_TRY(ssdr_launch_fused_exact_am(fa, c->d_tw64, s));
         else HIP_TRY(ssdr_launch_fused_am(fa, grid ? grid : 1, s));
         if ((rc = timed_end(c, SSDR_K_FUSED, s)) != SSDR_OK) return rc;
         if (fa.wf.tail)          // hop 512: only now may the carried half-line (the kernel's line 0 read it) become this batch's last one
@@ -1033,22 +1046,28 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
                           c->in_frames >= 8 &&
                           !c->concurrent && c->fused_grid != 0 && c->fused_enabled >= ((hop512 || c->n_avg > 1) ? 2 : 1) && c->zoom == 1 &&
                           (!c->exact_bins || (!hop512 && c->n_avg == 1));
-    if (fused) *fused = eligible ? 1 : 0;
-    c->fuse_next = eligible;
+    // the general-mode kernel (ssdr_fused_gen.hip; ssdr_set_fused(ctx, 3)): any mix of audio paths and any N at hop 1024, channel filters of
+    // up to 33 taps, no SSDR_MODE_IQ channel (its second output row), fp32 bins
+    const bool eligible_gen = !eligible && c->fused_enabled >= 3 && c->gen_grid != 0 && c->decim == 1 && !hop512 && !(c->in_frames & 1u) &&
+                              c->in_frames >= 4 && !c->concurrent && c->zoom == 1 && !c->exact_bins && !c->sum_any_iq &&
+                              c->sum_gen_ntap <= SSDR_GEN_NTAP_MAX;
+    if (fused) *fused = eligible ? 1 : (eligible_gen ? 2 : 0);
+    c->fuse_next = eligible || eligible_gen;
+    c->fuse_gen_next = eligible_gen;
     {   // both stages or neither: what ssdr_run_wf and ssdr_run_audio would refuse is refused before either is launched
         int rcv = validate_wf_batch(c);
         if (rcv == SSDR_OK && c->decim > 1) {
             chan_summary(c);
             if (c->sum_paths[SSDR_PATH_DELAY4] || c->sum_paths[SSDR_PATH_AM_RAW]) rcv = SSDR_ESTATE;
         }
-        if (rcv != SSDR_OK) { c->fuse_next = false; if (fused) *fused = 0; return rcv; }
+        if (rcv != SSDR_OK) { c->fuse_next = false; c->fuse_gen_next = false; if (fused) *fused = 0; return rcv; }
     }
     // Everything else: the two stages side by side -- the audio stage on a second stream beside the waterfall kernel (one workgroup
     // per CU then), each filling the issue slots the other leaves: +2.7 % on configs[3], +9 % on the full chain at hop 512
     // (profiles/r04_ab_overlap.txt; there it beats the one-read kernel too, which is why that one is opt-in at hop 512)
     // (not with the float64 waterfall kernel: it fills the CUs' LDS by itself, and beside it the audio stage only gets in the way:
     //  3.61 ms one after the other, 3.75 ms side by side)
-    const bool overlap = !eligible && c->overlap_enabled && !c->concurrent && !c->exact_bins;
+    const bool overlap = !c->fuse_next && c->overlap_enabled && !c->concurrent && !c->exact_bins;
     int rc;
     if (overlap) {
         // the audio stage first: its stream waits for what is queued so far (the input), not for the waterfall kernel that follows
@@ -1062,12 +1081,13 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
         if (rc == SSDR_OK) rc = ssdr_run_audio(c, nullptr, nullptr, 0);
     }
     c->fuse_next = false;
+    c->fuse_gen_next = false;
     return rc;
 }
 
 int ssdr_set_fused(ssdr_ctx *c, int on)
 {
-    if (!c || on < 0 || on > 2) return SSDR_EINVAL;
+    if (!c || on < 0 || on > 3) return SSDR_EINVAL;
     c->fused_enabled = on;
     return SSDR_OK;
 }

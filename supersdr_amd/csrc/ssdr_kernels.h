@@ -150,6 +150,14 @@ struct SsdrZoomArgs {
 };
 hipError_t ssdr_launch_zoom(const SsdrZoomArgs &a, hipStream_t stream);
 struct SsdrFusedArgs { SsdrWfArgs wf; SsdrAudioArgs au; };
+// the general-mode fused kernel (ssdr_fused_gen.hip): one 1024-thread workgroup per CU; channel filters of up to 33 taps (4 history octets)
+#ifndef SSDR_GEN_BLOCK
+#define SSDR_GEN_BLOCK 1024
+#endif
+#define SSDR_GEN_HIST_OCT 4
+#define SSDR_GEN_NTAP_MAX 33
+hipError_t ssdr_launch_fused_gen(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream);
+hipError_t ssdr_fused_gen_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_fused_am(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream);
 hipError_t ssdr_fused_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_fused_exact_am(const SsdrFusedArgs &a, const double2 *tw, hipStream_t stream);   // ssdr_wf_exact.hip: float64 bins; chooses its grid

@@ -178,7 +178,8 @@ class SsdrEngine:
         return pcm, rssi
 
     def set_fused(self, on):
-        """0 / False: never the fused superframe kernel; 1 / True (default): at hop 1024; 2: at hop 512 as well"""
+        """0 / False: never the fused superframe kernel; 1 / True (default): at hop 1024; 2: at hop 512 as well; 3: and the general-mode
+        fused kernel for batches of mixed audio paths (run_chain then reports fused == 2)"""
         check(lib.ssdr_set_fused(self._ctx, int(on)), "ssdr_set_fused")
 
     def set_overlap(self, on):
@@ -190,7 +191,7 @@ class SsdrEngine:
         n, fused = C.c_uint32(0), C.c_int(0)
         self.audio_frames = self.in_frames
         check(lib.ssdr_run_chain(self._ctx, C.byref(n), C.byref(fused)), "ssdr_run_chain")
-        return n.value, bool(fused.value)
+        return n.value, fused.value
 
     def fetch_wf(self, lines):
         """device results of the last waterfall run -> int16 [lines, n_ch, 1024]"""
