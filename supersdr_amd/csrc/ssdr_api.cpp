@@ -66,6 +66,7 @@ struct ssdr_ctx {
     int fused_enabled = 1;                              // ssdr_set_fused: 0 never, 1 at hop 1024 (default), 2 at hop 512 as well, 3 + the general-mode kernel
     bool fuse_gen_next = false;                         // ... and that kernel is ssdr_fused_gen_kernel (any mix of audio paths)
     uint32_t gen_grid = 0;
+    uint32_t *d_gen_park = nullptr;                     // [gen_grid * waves][16][64]: the N-line sums of ssdr_fused_gen_kernel<AVG> while its audio phases run
     bool overlap_enabled = true;                        // ssdr_set_overlap: un-fused ssdr_run_chain batches run the audio stage beside the waterfall kernel
     bool fuse_next = false;                             // ssdr_run_chain: run_wf parks its arguments, run_audio launches the fused kernel
     SsdrWfArgs fused_wf;
@@ -245,7 +246,7 @@ void ssdr_destroy(ssdr_ctx *c)
     void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_wf_tail, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_flags, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
                     c->d_play_taps, c->d_play_hist, c->d_play_hist_alt, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
-                    c->d_smeter_in, c->d_post_sel, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64, c->d_wire_gps, c->d_iq_out, c->d_zoom_taps, c->d_zoom_dphi, c->d_zoom_phase, c->d_zoom_hist, c->d_zoom_out};
+                    c->d_smeter_in, c->d_post_sel, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64, c->d_wire_gps, c->d_iq_out, c->d_zoom_taps, c->d_zoom_dphi, c->d_zoom_phase, c->d_zoom_hist, c->d_zoom_out, c->d_gen_park};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -970,6 +971,11 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         SsdrFusedArgs fa;
         fa.wf = c->fused_wf;
         fa.au = a;
+        fa.park = nullptr;
+        if (c->fuse_gen_next) {
+            if (!c->d_gen_park) HIP_TRY(hipMalloc(&c->d_gen_park, (size_t)c->gen_grid * (SSDR_GEN_BLOCK / 64) * 16 * 64 * 4));
+            fa.park = c->d_gen_park;
+        }
         const uint64_t pairs = (c->n_ch + 1) / 2;
         const uint64_t need = (pairs + SSDR_WF_BLOCK / 64 - 1) / (SSDR_WF_BLOCK / 64);
         const uint32_t grid = (uint32_t)(need < c->fused_grid ? need : c->fused_grid);

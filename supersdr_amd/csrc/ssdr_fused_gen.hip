@@ -58,9 +58,12 @@ enum { PATH_GENERAL = SSDR_PATH_GENERAL, PATH_DELAY4 = SSDR_PATH_DELAY4, PATH_AM
 
 // the FIR's work area: octet q (0 .. SOCT-1; q < HMAX is history) at 64 q + 16 (q >> 2)
 SSDR_DEV int s_addr(int q) { return (q << 6) + ((q >> 2) << 4); }
+template <typename T> SSDR_DEV T *al16(const void *p) { return reinterpret_cast<T *>(__builtin_assume_aligned(const_cast<void *>(p), 16)); }
+// ... and the 16 bytes of padding behind octets 4 j .. 4 j + 3 hold the channel's taps 4 j .. 4 j + 3 (staged per line: audio_line)
+SSDR_DEV int s_tap_addr(int j) { return 272 * j + 256; }
 SSDR_DEV void s_load_oct(const unsigned char *S, int q, float2 (&v)[8])
 {
-    const float4 *p = reinterpret_cast<const float4 *>(S + s_addr(q));
+    const float4 *p = al16<const float4>(S + s_addr(q));
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const float4 t = p[i];
@@ -70,7 +73,7 @@ SSDR_DEV void s_load_oct(const unsigned char *S, int q, float2 (&v)[8])
 }
 SSDR_DEV void s_store_oct(unsigned char *S, int q, const float2 (&v)[8])
 {
-    float4 *p = reinterpret_cast<float4 *>(S + s_addr(q));
+    float4 *p = al16<float4>(S + s_addr(q));
 #pragma unroll
     for (int i = 0; i < 4; i++) p[i] = make_float4(v[2 * i].x, v[2 * i].y, v[2 * i + 1].x, v[2 * i + 1].y);
 }
@@ -148,16 +151,38 @@ struct LineCtx {                                // what the audio phase of one s
 
 // The audio chain of one channel for the two frames of a line.  PATH as in ssdr_audio.hip:channel_frames, whose per-frame code this
 // is, statement for statement, with the carried state handed in and out.
+// Per-frame RSSI and ADC-overflow flag without a per-lane keeper that would have to live across the FFT: lane 0 leaves the frame's power
+// sum (the same scan, the same order) and the flag in the output rows; the conversion to dBm runs once per call (rssi_finish).
+SSDR_DEV void rssi_flag_raw(const float (&p)[8], bool clip, uint32_t f, int l, float *rssi_row, uint8_t *flag_row)
+{
+    float ps = p[0];
+#pragma unroll
+    for (int j = 1; j < 8; j++) ps = ps + p[j];
+    const float tot = lane63(scan_sum(ps));
+    if (l == 0) { rssi_row[f] = tot; flag_row[f] = clip ? (uint8_t)1 : (uint8_t)0; }
+}
+SSDR_DEV void rssi_finish(float *rssi_row, uint32_t n_frames, float cal, int l)
+{
+    // lane 0's stores of the call have left the wave (written through to this XCD's L2; no agent-scope release: that would write the
+    // whole L2 back, once per channel) ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += 64) {
+        const uint32_t f = f0 + (uint32_t)l;
+        if (f < n_frames) {
+            const float sum = __hip_atomic_load(rssi_row + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ... and are read from there, past the L1
+            rssi_row[f] = fmaf(ssdr_log2p(fmaxf(sum, 1e-20f)) - 39.0f, SSDR_DB_PER_LOG2, cal);
+        }
+    }
+}
+
 template <int PATH>
-SSDR_DEV void audio_line(const SsdrAudioArgs &u, const LineCtx &x, Slot &s, const ssdr_chan_consts &kc, const int l,
-                         float &rssi_sum, uint32_t &flag_keep)
+SSDR_DEV void audio_line(const SsdrAudioArgs &u, const LineCtx &x, Slot &s, const ssdr_chan_consts &kc, const int l)
 {
     const uint32_t mode = kc.mode;
     const uint32_t tap_groups = kc.tap_groups;
     const uint32_t nblk = (kc.ntap + 7) >> 3;
     const uint32_t dphi1 = kc.dphi1, dphi2 = kc.dphi2;
     const AgcK agc = {kc.agc_c0, kc.agc_c1, kc.agc_knee, kc.agc_delta8, kc.hang_frames};
-    const float cal = kc.smeter_cal_db;
     const bool ssb = mode >= SSDR_MODE_LSB && mode <= SSDR_MODE_CW;
     const bool untuned = dphi1 == 0 && s.phi1 == 0;         // stays what it is for the whole call (phi1 += 512 * 0)
     Nco n1, n2;
@@ -166,12 +191,15 @@ SSDR_DEV void audio_line(const SsdrAudioArgs &u, const LineCtx &x, Slot &s, cons
         if (!untuned) nco_line(n1, dphi1, s.phi1, s.cs1, s.ss1, l);
         if (ssb) nco_line(n2, dphi2, s.phi2, s.cs2, s.ss2, l);
     }
-    const float4 *taps4 = reinterpret_cast<const float4 *>(u.taps + (size_t)x.cc * SSDR_NTAP_MAX);
-    if (PATH == PATH_GENERAL) {                 // the previous line's last HMAX octets in front of the frame
+    if (PATH == PATH_GENERAL) {
+        // the channel's taps into the work area's padding (lane k: tap k; 4 (HMAX + 1) = 40 >= ntap + 7 of them), the FIR reads them back as
+        // broadcasts; and the previous line's last HMAX octets in front of the frame
+        if (l < 8 * (HMAX + 1)) *reinterpret_cast<float *>(x.S + s_tap_addr(l >> 2) + 4 * (l & 3)) = u.taps[(size_t)x.cc * SSDR_NTAP_MAX + l];
         if (l < HMAX) {
-            float4 *d = reinterpret_cast<float4 *>(x.S + s_addr(l));
+            float4 *d = al16<float4>(x.S + s_addr(l));
+            const float4 *hs = al16<const float4>(x.hist + 4 * l);
 #pragma unroll
-            for (int i = 0; i < 4; i++) d[i] = x.hist[4 * l + i];
+            for (int i = 0; i < 4; i++) d[i] = hs[i];
         }
     }
     int16_t *dst = u.pcm + ((uint64_t)x.cc * x.n_frames + 2 * x.line) * SSDR_FRAME + 8 * l;
@@ -183,7 +211,7 @@ SSDR_DEV void audio_line(const SsdrAudioArgs &u, const LineCtx &x, Slot &s, cons
     for (int f = 0; f < 2; f++, dst += SSDR_FRAME) {
         const uint32_t frame = 2 * x.line + f;
         if (x.raw_lds) {
-            const u32x4 *qp = reinterpret_cast<const u32x4 *>(x.raw_lds + SSDR_FRAME * f) + 2 * l;
+            const u32x4 *qp = al16<const u32x4>(x.raw_lds + SSDR_FRAME * f) + 2 * l;
             raw0 = qp[0]; raw1 = qp[1];
         } else {                                // plain loads: the line is read once more when it is filed for the FFT (the L2 has it)
             const u32x4 *gp = reinterpret_cast<const u32x4 *>(x.raw_glb + SSDR_FRAME * f + 8 * l);
@@ -248,11 +276,11 @@ SSDR_DEV void audio_line(const SsdrAudioArgs &u, const LineCtx &x, Slot &s, cons
                 for (uint32_t b = 0; b < nblk; b += 2) {
                     const uint32_t m4 = (tap_groups >> (2 * b)) & 15u;
                     if (m4 == 0) continue;
-                    const float4 *hq = taps4 + 2 * b;
+                    const unsigned char *hq = x.S + s_tap_addr(2 * (int)b);        // taps 8 b .. : padding chunks 2 b, 2 b + 1 (, + 2, + 3)
                     if (m4 & 3u) {
                         if (a_oct != b) s_load_oct(x.S, HMAX + l - (int)b, A);
                         s_load_oct(x.S, max(HMAX + l - 1 - (int)b, 0), B);
-                        const float4 h0 = hq[0], h1 = hq[1];
+                        const float4 h0 = *al16<const float4>(hq), h1 = *al16<const float4>(hq + 272);
                         const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
                         if (m4 & 1u) fir_taps<0, 4>(h, A, B, yr, yi);
                         if (m4 & 2u) fir_taps<4, 4>(h, A, B, yr, yi);
@@ -260,7 +288,7 @@ SSDR_DEV void audio_line(const SsdrAudioArgs &u, const LineCtx &x, Slot &s, cons
                     if (m4 & 12u) {
                         if (!(m4 & 3u)) s_load_oct(x.S, max(HMAX + l - 1 - (int)b, 0), B);
                         s_load_oct(x.S, max(HMAX + l - 2 - (int)b, 0), A);
-                        const float4 h0 = hq[2], h1 = hq[3];
+                        const float4 h0 = *al16<const float4>(hq + 544), h1 = *al16<const float4>(hq + 816);
                         const float h[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
                         if (m4 & 4u) fir_taps<0, 4>(h, B, A, yr, yi);
                         if (m4 & 8u) fir_taps<4, 4>(h, B, A, yr, yi);
@@ -282,18 +310,19 @@ SSDR_DEV void audio_line(const SsdrAudioArgs &u, const LineCtx &x, Slot &s, cons
         }
 
         agc_pack_store(p, aud, l, agc, s.agc_d, s.agc_m, dst, pm_am);
-        rssi_flag_step(p, clip, frame, x.n_frames, l, cal, rssi_sum, flag_keep, rssi_row, flag_row);
+        rssi_flag_raw(p, clip, frame, l, rssi_row, flag_row);
         s.phi1 += (uint32_t)SSDR_FRAME * dphi1;
         s.phi2 += (uint32_t)SSDR_FRAME * dphi2;
         if constexpr (PATH == PATH_GENERAL) {   // the frame's tail: the next frame's history (frame 1's waits in `hist` for the next line)
             lds_sync();
             if (l < HMAX) {
-                const float4 *t = reinterpret_cast<const float4 *>(x.S + s_addr(64 + l));
-                float4 *d = reinterpret_cast<float4 *>(x.S + s_addr(l));
+                const float4 *t = al16<const float4>(x.S + s_addr(64 + l));
+                float4 *d = al16<float4>(x.S + s_addr(l));
+                float4 *hd = al16<float4>(x.hist + 4 * l);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const float4 v = t[i];
-                    if (f == 0) d[i] = v; else x.hist[4 * l + i] = v;
+                    if (f == 0) d[i] = v; else hd[i] = v;
                 }
             }
             lds_sync();
@@ -336,7 +365,7 @@ SSDR_DEV void slot_begin(const SsdrAudioArgs &u, uint32_t cc, const ssdr_chan_co
             phasor_mul(fc, fs, qc, qs, bc, bs);
             mix8<false>(rw, bc, bs, cs1, ss1, H, unused);
 #pragma unroll
-            for (int i = 0; i < 4; i++) hist[4 * l + i] = make_float4(H[2 * i].x, H[2 * i].y, H[2 * i + 1].x, H[2 * i + 1].y);
+            for (int i = 0; i < 4; i++) al16<float4>(hist + 4 * l)[i] = make_float4(H[2 * i].x, H[2 * i].y, H[2 * i + 1].x, H[2 * i + 1].y);
         }
     }
     float tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -382,17 +411,36 @@ SSDR_DEV void file_line(const uint32_t *row, unsigned char *dst, int lane)
     }
     SCHED_FENCE();
 #pragma unroll
-    for (int i = 0; i < 4; i++) reinterpret_cast<u32x4 *>(dst)[64 * i + lane] = t[i];
+    for (int i = 0; i < 4; i++) al16<u32x4>(dst)[64 * i + lane] = t[i];
     SCHED_FENCE();
 }
 
-template <bool AVG>
-__global__ __launch_bounds__(SSDR_GEN_BLOCK, 4) void ssdr_fused_gen_kernel(SsdrFusedArgs fa)
+// The kernel's arguments are ~45 scalar registers' worth of pointers and counts; held for the whole kernel they, the carried state of a slot
+// and the channel constants do not fit the scalar file, and what spills goes through vector registers.  Each phase therefore reads what it
+// needs from the kernarg segment again (scalar loads, cached) through a laundered pointer, and nothing of it lives across the other phase.
+typedef const __attribute__((address_space(4))) SsdrFusedArgs *KArgs;
+#ifndef SSDR_GEN_KARGS
+#define SSDR_GEN_KARGS 1
+#endif
+SSDR_DEV KArgs args_now()
 {
+    KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    if (SSDR_GEN_KARGS) asm volatile("" : "+s"(p));         // (0: A/B -- the arguments are loaded once and kept)
+    return p;
+}
+
+template <bool AVG>
+__global__ __launch_bounds__(SSDR_GEN_BLOCK, SSDR_GEN_WAVES_PER_EU) void ssdr_fused_gen_kernel(SsdrFusedArgs fa_unused)
+{
+#if defined(__HIP_DEVICE_COMPILE__)             // (the host pass only needs the kernel's symbol; address space 4 exists on the device side)
     __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];
-    const SsdrWfArgs &a = fa.wf;
-    const SsdrAudioArgs &u = fa.au;
-    load_tables(smem, a.win, a.tw_stage, a.lut);
+    (void)fa_unused;
+    {
+        const SsdrWfArgs a0 = args_now()->wf;
+        load_tables(smem, a0.win, a0.tw_stage, a0.lut);
+    }
+    const SsdrWfArgs a = args_now()->wf;                // (what the loop bounds and the call-start / call-end code use)
+    const SsdrAudioArgs u = args_now()->au;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, l = lane & 31;
@@ -425,11 +473,15 @@ __global__ __launch_bounds__(SSDR_GEN_BLOCK, 4) void ssdr_fused_gen_kernel(SsdrF
         wave_lds_sync();
         // a pair with one general-path channel runs it FIRST: its work area lies where the other slot's line will be filed
         const uint32_t first = (n_sub == 2 && path1 == PATH_GENERAL && path0 != PATH_GENERAL) ? 1u : 0u;
-        float rssi_k0 = 0.0f, rssi_k1 = 0.0f;
-        uint32_t flag_k0 = 0u, flag_k1 = 0u;
+        // AVG: the N-line sums rest in global memory (16 dwords per lane, the wave's own 4 KB: L2-resident) while the audio chain has the registers
+        uint32_t *park = args_now()->park + ((size_t)(blockIdx.x * WAVES + wave) * 16) * 64 + lane;
         uint32_t acc[AVG ? 16 : 1];
 #pragma unroll
         for (int j = 0; j < (AVG ? 16 : 1); j++) acc[j] = 0;
+        if (AVG) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) park[64 * j] = 0u;
+        }
 
         for (uint32_t line = 0; line < a.n_lines; line++) {
             prio_latency_phase();
@@ -439,34 +491,34 @@ __global__ __launch_bounds__(SSDR_GEN_BLOCK, 4) void ssdr_fused_gen_kernel(SsdrF
                 const uint32_t sidx = first ^ k;
                 if (sidx >= n_sub) continue;                                      // wave-uniform
                 uint32_t pair_now = __builtin_amdgcn_readfirstlane(pair);
-                asm volatile("" : "+s"(pair_now));
+                asm volatile("" : "+s"(pair_now));      // everything derived from the pair and from the lane id is recomputed per phase (a few
+                const int ln = opaque(lane);            // fast ops) rather than hoisted out of the line loop into registers that live across the FFT
                 const uint32_t cc = 2 * pair_now + sidx;
+                const KArgs kp = args_now();
+                const SsdrAudioArgs u = kp->au;                                  // (shadows the outer copy: this phase's own scalar loads)
                 const ssdr_chan_consts &kc = u.consts[cc];
                 const int path = sidx ? path1 : path0;
-                const uint32_t *row = a.iq + (uint64_t)cc * a.ch_stride + (uint64_t)line * SSDR_NFFT;
+                const uint32_t *row = kp->wf.iq + (uint64_t)cc * kp->wf.ch_stride + (uint64_t)line * SSDR_NFFT;
                 unsigned char *R = work + (sidx ? R1_OFF : 0);
                 // two general channels: slot 1's work area is where its own line belongs -- frames straight from memory, the line filed afterwards
                 const bool late = sidx == 1 && path == PATH_GENERAL && path0 == PATH_GENERAL;
-                if (!late) { file_line<true>(row, R, lane); wave_lds_sync(); }
+                if (!late) { file_line<true>(row, R, ln); wave_lds_sync(); }
                 LineCtx x;
-                x.cc = cc; x.line = line; x.n_frames = n_frames;
+                x.cc = cc; x.line = line; x.n_frames = u.n_frames;
                 x.raw_lds = late ? nullptr : reinterpret_cast<const uint32_t *>(R);
                 x.raw_glb = row;
                 x.S = work + ((sidx == 1 && path0 != PATH_GENERAL) ? 0 : R_BYTES);
                 x.hist = hist_lds + sidx * (HIST_BYTES / 16);
-                x.last_line = line + 1 == a.n_lines;
+                x.last_line = line + 1 == kp->wf.n_lines;
                 float *sp = state_lds + sidx * STATE_WORDS;
                 Slot s;
                 slot_load(sp, s, path);
-                float rk = sidx ? rssi_k1 : rssi_k0;
-                uint32_t fk = sidx ? flag_k1 : flag_k0;
-                if (path == PATH_GENERAL) audio_line<PATH_GENERAL>(u, x, s, kc, lane, rk, fk);
-                else if (path == PATH_DELAY4) audio_line<PATH_DELAY4>(u, x, s, kc, lane, rk, fk);
-                else audio_line<PATH_AM_RAW>(u, x, s, kc, lane, rk, fk);
-                if (sidx) { rssi_k1 = rk; flag_k1 = fk; } else { rssi_k0 = rk; flag_k0 = fk; }
-                slot_store(sp, s, path, lane);
+                if (path == PATH_GENERAL) audio_line<PATH_GENERAL>(u, x, s, kc, ln);
+                else if (path == PATH_DELAY4) audio_line<PATH_DELAY4>(u, x, s, kc, ln);
+                else audio_line<PATH_AM_RAW>(u, x, s, kc, ln);
+                slot_store(sp, s, path, ln);
                 wave_lds_sync();
-                if (late) { file_line<true>(row, R, lane); wave_lds_sync(); }
+                if (late) { file_line<true>(row, R, ln); wave_lds_sync(); }
             }
 #if SSDR_GEN_ABLATE == 2
             for (uint32_t sidx = 0; sidx < n_sub; sidx++)
@@ -475,6 +527,8 @@ __global__ __launch_bounds__(SSDR_GEN_BLOCK, 4) void ssdr_fused_gen_kernel(SsdrF
 #endif
             prio_compute_phase();
             // ---- waterfall: both lines out of the work area, then exactly ssdr_wf_kernel<AVG, false>
+            const SsdrWfArgs a = args_now()->wf;                                  // (this phase's own scalar loads)
+            uint32_t *hist_out = args_now()->au.hist;
             uint32_t raw[32];
             {
                 const uint32_t *q = reinterpret_cast<const uint32_t *>(work + opaque(h) * R1_OFF) + opaque(l);
@@ -486,9 +540,15 @@ __global__ __launch_bounds__(SSDR_GEN_BLOCK, 4) void ssdr_fused_gen_kernel(SsdrF
             // the raw tail of the call's last frame (its samples 384..511 = this line's 896..1023) is the next call's history
             if (line + 1 == a.n_lines && ch_ok) {
 #pragma unroll
-                for (int r = 28; r < 32; r++) u.hist[(size_t)ch * SSDR_HIST + 32 * (r - 28) + l] = raw[r];
+                for (int r = 28; r < 32; r++) hist_out[(size_t)ch * SSDR_HIST + 32 * (r - 28) + l] = raw[r];
             }
             uint32_t qn[16];
+            if (AVG) {
+                uint32_t *pk = park;
+                asm volatile("" : "+v"(pk));                 // (a laundered pointer: the 16 loads go out together and are not forwarded from the stores)
+#pragma unroll
+                for (int j = 0; j < 16; j++) acc[j] = pk[64 * j];
+            }
 #if SSDR_GEN_ABLATE == 1
 #pragma unroll
             for (int j = 0; j < 16; j++) qn[j] = raw[j] ^ raw[j + 16];
@@ -535,6 +595,12 @@ __global__ __launch_bounds__(SSDR_GEN_BLOCK, 4) void ssdr_fused_gen_kernel(SsdrF
                     for (int j = 0; j < 16; j++) acc[j] = 0;
                 }
             }
+            if (AVG) {
+                uint32_t *pk = park;
+                asm volatile("" : "+v"(pk));
+#pragma unroll
+                for (int j = 0; j < 16; j++) pk[64 * j] = acc[j];
+            }
         }
 
         // ---- state back to HBM
@@ -550,10 +616,12 @@ __global__ __launch_bounds__(SSDR_GEN_BLOCK, 4) void ssdr_fused_gen_kernel(SsdrF
                 for (int i = 0; i < 8; i++) st.agc_m[i] = sp[4 + i];
                 st.prev_re = sp[12]; st.prev_im = sp[13];
                 if (lane == 0) u.state[cc] = st;
+                rssi_finish(u.rssi + (uint64_t)cc * n_frames, n_frames, u.consts[cc].smeter_cal_db, lane);
             }
         }
         wave_lds_sync();
     }
+#endif
 }
 
 } // namespace

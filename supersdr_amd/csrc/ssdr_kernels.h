@@ -149,10 +149,13 @@ struct SsdrZoomArgs {
     uint32_t *out;                           // [n_ch][n_in / zoom] I | Q << 16
 };
 hipError_t ssdr_launch_zoom(const SsdrZoomArgs &a, hipStream_t stream);
-struct SsdrFusedArgs { SsdrWfArgs wf; SsdrAudioArgs au; };
+struct SsdrFusedArgs { SsdrWfArgs wf; SsdrAudioArgs au; uint32_t *park; };      // park: ssdr_fused_gen_kernel<AVG>, [waves of the grid][16][64] dwords
 // the general-mode fused kernel (ssdr_fused_gen.hip): one 1024-thread workgroup per CU; channel filters of up to 33 taps (4 history octets)
 #ifndef SSDR_GEN_BLOCK
 #define SSDR_GEN_BLOCK 1024
+#endif
+#ifndef SSDR_GEN_WAVES_PER_EU
+#define SSDR_GEN_WAVES_PER_EU (SSDR_GEN_BLOCK / 256)
 #endif
 #define SSDR_GEN_HIST_OCT 4
 #define SSDR_GEN_NTAP_MAX 33
