@@ -501,7 +501,43 @@ def measure_post(S, L, local_rank, channels=65536, sframes=16, steps=10, spinup=
     return stages
 
 
-def measure_hub(S, L, torch, local_rank, channels, sframes, steps, in_place, batch_superframes=4, copy_threads=0):
+def gpu_numa_node(torch, local_rank):
+    """NUMA node of the GPU this rank drives (sysfs, through its PCI address), or None"""
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        addr = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % addr).read())
+        return node if node >= 0 else None
+    except Exception:                                            # noqa: BLE001
+        return None
+
+
+def parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if part:
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+    return cpus
+
+
+def bind_to_numa_node(node):
+    """this process (and the threads it starts, and the pages it touches first: the hub's pinned ring) onto the CPUs of `node`.
+    -> dict for the JSON line"""
+    info = {"gpu_numa_node": node, "bound": False}
+    if node is None or not hasattr(os, "sched_setaffinity"):
+        return info
+    try:
+        cpus = parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read()) & os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+            info.update(bound=True, cpus=len(cpus))
+    except Exception as ex:                                      # noqa: BLE001
+        info["error"] = "%s: %s" % (type(ex).__name__, ex)
+    return info
+
+
+def measure_hub(S, L, torch, local_rank, channels, sframes, steps, in_place, batch_superframes=4, copy_threads=0, lazy_out=False, rdv=None):
     """The pipelined feed driven through the product's own ingest API (supersdr_amd/workers.py:IQHub, the thing
     KiwiSDRStream._process_iq_samples fills, kiwi/client.py:493-494): `channels` receivers, one block call per superframe.
     in_place=False: IQHub.feed_block (one copy of the block into the hub's pinned slot -- the hub's whole host cost);
@@ -514,10 +550,11 @@ def measure_hub(S, L, torch, local_rank, channels, sframes, steps, in_place, bat
     eng.synth_iq(2 * batch_superframes)
     block = eng.read_input()                                     # [channels, K * 1024, 2]: K superframes of synthetic IQ, replayed
     hub = IQHub(channels, engine=eng, gpu_post=False, pipeline=True, depth=3, lazy=True, batch_superframes=batch_superframes,
-                backlog_superframes=2 * batch_superframes, stall_superframes=batch_superframes, copy_threads=copy_threads)
+                backlog_superframes=2 * batch_superframes, stall_superframes=batch_superframes, copy_threads=copy_threads, lazy_out=lazy_out)
     hub.attach(channels // 2, wf=True, snd=True)
-    seen = [0]
+    seen, rows = [0], [0]
     hub.subscribe(lambda r: seen.__setitem__(0, seen[0] + r.pcm.shape[1] // 1024))
+    hub.subscribe(lambda r: rows.__setitem__(0, r.pcm.shape[0]))
     U = 1024 * batch_superframes
 
     def one_batch():
@@ -532,6 +569,8 @@ def measure_hub(S, L, torch, local_rank, channels, sframes, steps, in_place, bat
     hub.flush()
     n_batches = max(1, steps * sframes // batch_superframes)
     seen[0] = 0
+    if rdv is not None:
+        rdv.barrier()                                            # every rank's feed primed: the timed region starts together
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n_batches):
@@ -539,14 +578,22 @@ def measure_hub(S, L, torch, local_rank, channels, sframes, steps, in_place, bat
     hub.flush()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
+    if rdv is not None:
+        rdv.barrier()
+    wall_all = rdv.max_over_ranks(time.perf_counter() - t0) if rdv is not None else wall
     assert seen[0] == n_batches * batch_superframes, (seen, n_batches)
     q = hub.snd_queue[channels // 2].qsize()
     hub.close()
     units = channels * n_batches * batch_superframes
+    # bytes per channel-superframe that cross PCIe: 4096 in; back either every channel's line + PCM + RSSI + flags, or the listeners' rows only
+    d2h = (2048.0 + 2048.0 + 8.0 + 2.0) * (rows[0] / channels)
     return {"value": units / wall / RT_SUPERFRAMES_PER_S, "unit": "rt_channels", "ms_per_superframe": wall / (n_batches * batch_superframes) * 1e3,
             "channels": channels, "superframes_per_gpu_run": batch_superframes, "superframes": n_batches * batch_superframes,
             "ingest": "IQHub.reserve/commit (in place)" if in_place else "IQHub.feed_block (one host copy%s)" % (", %d threads" % copy_threads if copy_threads > 1 else ""),
-            "host_GBps": units * 4096.0 / wall / 1e9, "frames_queued_for_the_one_listener": q}
+            "results": "rows of the %d attached channel(s) only (SSDR_FEED_LAZY_OUT), the rest stays on the device" % rows[0] if lazy_out else "every channel's rows copied back",
+            "h2d_bytes_per_channel_superframe": 4096.0, "d2h_bytes_per_channel_superframe": round(d2h, 3),
+            "host_GBps": units * (4096.0 + d2h) / wall / 1e9, "frames_queued_for_the_one_listener": q,
+            "units": units, "wall_s": wall, "wall_all_ranks_s": wall_all}
 
 
 def csrc_sha256():
@@ -676,6 +723,11 @@ def main():
                     help="1: inputs come from (pinned) host memory (2: as SND wire bodies, unpacked on the device) and results go back to it through the pipelined feed "
                          "(ssdr_feed_*): the PCIe-inclusive rate of DESIGN.md, never the headline value; 3: the same through the product's ingest API, "
                          "IQHub.feed_block (one host copy per block); 4: IQHub.reserve / commit (in place)")
+    ap.add_argument("--hub-lazy-out", type=int, default=0,
+                    help="--host-feed 3 / 4: 1 = only the attached channels' results are copied back (IQHub(lazy_out=True), SSDR_FEED_LAZY_OUT)")
+    ap.add_argument("--hub-copy-threads", type=int, default=0, help="--host-feed 3: threads of IQHub.feed_block's copy")
+    ap.add_argument("--numa-bind", type=int, default=1,
+                    help="--host-feed 3 / 4: bind each rank (and its pinned ring, by first touch) to the CPUs of its GPU's NUMA node (default on)")
     ap.add_argument("--concurrent", type=int, default=0, help="bit 0: audio stage on a second stream beside the waterfall kernel; bit 1: the audio stage's per-path kernels one after the other")
     ap.add_argument("--fused", type=int, default=1,
                     help="1 (the library's default): ssdr_run_chain uses the fused superframe kernel where the configuration allows it "
@@ -723,6 +775,16 @@ def main():
         nxt = firsts[(rank + 1) % world]
         own, cross = fake(first_id), fake(nxt if os.environ.get("SSDR_DRYRUN_BREAK_RANK") != str(rank) else nxt + 1)
         parity = parity_report(rdv, world, firsts, own, cross, "dry run: stand-in checksums")
+        if args.host_feed in (3, 4):                              # the multi-rank hub line's control flow: barrier, sum over ranks, max wall, per-rank values
+            units = float(channels * sframes * args.steps)
+            own_wall = 1e-3 * (rank + 1)
+            line = hub_line(rdv, rank, world, args, {"value": units / own_wall / RT_SUPERFRAMES_PER_S, "units": units, "wall_s": own_wall,
+                                                     "wall_all_ranks_s": rdv.max_over_ranks(own_wall), "host_GBps": 0.0, "channels": channels},
+                            {"gpu_numa_node": None, "bound": False})
+            if rank == 0:
+                print(json.dumps(dict(line, dry_run=True)), flush=True)
+            rdv.close()
+            return
         if rank == 0:
             print(json.dumps({"metric": "real-time IQ channels sustained (WF+demod)", "value": None, "unit": "rt_channels",
                               "n_gpus": world, "dry_run": True, "channels_total": int(total), "max_wall": wall, "parity": parity,
@@ -750,10 +812,14 @@ def main():
     from supersdr_amd import _lib as L
 
     if args.host_feed in (3, 4):         # the pipelined feed behind the product's own ingest API (IQHub); PCIe-inclusive, its own short line
-        h = measure_hub(S, L, torch, local_rank, channels, sframes, args.steps, in_place=(args.host_feed == 4))
+        # every rank: its process, its copy threads and (by first touch) its pinned ring on the NUMA node of ITS GPU; a barrier on both sides of
+        # the timed region; value = the channel-superframes of ALL ranks over the slowest rank's time
+        numa = bind_to_numa_node(gpu_numa_node(torch, local_rank)) if args.numa_bind else {"gpu_numa_node": gpu_numa_node(torch, local_rank), "bound": False}
+        h = measure_hub(S, L, torch, local_rank, channels, sframes, args.steps, in_place=(args.host_feed == 4),
+                        copy_threads=args.hub_copy_threads, lazy_out=bool(args.hub_lazy_out), rdv=rdv)
+        line = hub_line(rdv, rank, world, args, h, numa)
         if rank == 0:
-            print(json.dumps(dict(h, metric="real-time IQ channels sustained (WF+demod), inputs and results in host memory, through IQHub",
-                                  n_gpus=world, steps=args.steps, note="PCIe- and host-copy-inclusive: never the headline value")), flush=True)
+            print(json.dumps(line), flush=True)
         rdv.close()
         return
     m = measure(S, L, torch, rdv, rank, world, local_rank, args.workload, channels, sframes, args.steps, args.warmup,
@@ -891,8 +957,9 @@ def main():
         # the product's own ingest API in front of the pipelined feed (PCIe-inclusive, never `value`)
         if args.host_feed_extra:
             def hub_extra():
-                extra["hub_feed"] = {k: measure_hub(S, L, torch, local_rank, 65536, 16, 2, in_place=ip, copy_threads=ct)
-                                     for k, ip, ct in (("feed_block", False, 0), ("feed_block_8_threads", False, 8), ("in_place", True, 0))}
+                extra["hub_feed"] = {k: measure_hub(S, L, torch, local_rank, 65536, 16, 2, in_place=ip, copy_threads=ct, lazy_out=lo)
+                                     for k, ip, ct, lo in (("feed_block", False, 0, False), ("feed_block_8_threads", False, 8, False), ("in_place", True, 0, False),
+                                                           ("feed_block_8_threads_lazy_out", False, 8, True), ("in_place_lazy_out", True, 0, True))}
             guarded("hub_feed", hub_extra)
         full["extra"] = extra
     full["roofline"]["stages"] = summary
@@ -911,6 +978,24 @@ def main():
     rdv.close()
     if not parity["ranks_agree"]:
         raise SystemExit("bench.py: PARITY HASH MISMATCH between ranks: %r" % (parity,))
+
+
+def hub_line(rdv, rank, world, args, h, numa):
+    """the --host-feed 3 / 4 line over all ranks: sum of the ranks' channel-superframes over the slowest rank's wall (barrier on both sides
+    of the timed region), every rank's own rate and NUMA placement, the host-memory traffic of the whole job"""
+    units_all = rdv.sum_over_ranks(h["units"])
+    per_rank = [v[0] for v in rdv.gather_floats([h["value"]])]
+    gbps = rdv.sum_over_ranks(h["host_GBps"])
+    nodes = [int(v[0]) - 1 for v in rdv.gather_ints([(numa.get("gpu_numa_node") if numa.get("gpu_numa_node") is not None else -1) + 1])]
+    bound = [bool(v[0]) for v in rdv.gather_ints([1 if numa.get("bound") else 0])]
+    out = {k: v for k, v in h.items() if k not in ("units", "wall_s", "wall_all_ranks_s", "value", "host_GBps")}
+    out.update(metric="real-time IQ channels sustained (WF+demod), inputs and results in host memory, through IQHub",
+               value=units_all / h["wall_all_ranks_s"] / RT_SUPERFRAMES_PER_S, unit="rt_channels", n_gpus=world, steps=args.steps,
+               per_rank={"values": per_rank, "value_min": min(per_rank), "value_max": max(per_rank),
+                         "gpu_numa_node": [n if n >= 0 else None for n in nodes], "numa_bound": bound},
+               host_GBps_all_ranks=gbps, wall_s=h["wall_all_ranks_s"], scaling="weak",
+               note="PCIe- and host-copy-inclusive: never the headline value; value = all ranks' channel-superframes / the slowest rank's time")
+    return out
 
 
 def compact_line(full):
@@ -947,7 +1032,8 @@ def compact_line(full):
             elif "value" in v:
                 out["extra"][k] = {kk: (round(v[kk], 4) if isinstance(v[kk], float) else v[kk]) for kk in ("value", "ms_per_step", "chain_frac") if kk in v}
             elif k == "hub_feed":
-                out["extra"][k] = {kk: {"value": vv["value"], "ms_per_superframe": round(vv["ms_per_superframe"], 3)} for kk, vv in v.items()}
+                out["extra"][k] = {kk: {"value": vv["value"], "ms_per_superframe": round(vv["ms_per_superframe"], 3),
+                                        "d2h_bytes_per_channel_superframe": vv.get("d2h_bytes_per_channel_superframe")} for kk, vv in v.items()}
     return out
 
 

@@ -333,6 +333,17 @@ int ssdr_adpcm_decode(ssdr_ctx *ctx, const uint8_t *data, uint32_t n_streams, ui
  * Without SSDR_FEED_POST the post-processing entry points keep referring to the last ssdr_run_* batch, not to fed ones. */
 #define SSDR_FEED_WIRE 1u
 #define SSDR_FEED_POST 2u
+/* flags = SSDR_FEED_LAZY_OUT (round 5): a hub of 10^5 receivers has a handful of listeners (README.md:8 "dozens of instances"; one
+ * kiwi_waterfall / kiwi_sound pair each, utils_supersdr.py:780-785, 1044-1076), and copying every channel's line, PCM, RSSI and flags
+ * back -- 4 KB per channel-superframe of PCIe and host DRAM writes nobody reads -- is what the feed spent its return path on.  With this
+ * flag only the channels of ssdr_set_post_channels (at most SSDR_FEED_LAZY_MAX; no selection: all channels, if they are that few) come
+ * back: ssdr_feed_collect's arrays are then COMPACT -- wf [lines][n_sel][1024], pcm [n_sel][n_frames*512], rssi / wire_rssi / flags
+ * [n_sel][n_frames], rows in the order of the selection in force at the batch's submit (ssdr_feed_collect_lazy tells n_sel) -- and the
+ * whole-batch results stay on the device, in the slot's buffers, for device-side consumers (ssdr_feed_collect_lazy: valid until
+ * depth - 1 further batches have been submitted). */
+#define SSDR_FEED_LAZY_OUT 4u
+#define SSDR_FEED_LAZY_MAX 4096u
+int ssdr_feed_collect_lazy(ssdr_ctx *ctx, uint32_t *n_sel, int16_t **d_wf_sum, int16_t **d_pcm, float **d_rssi, uint8_t **d_flags);
 int ssdr_feed_open(ssdr_ctx *ctx, uint32_t n_frames, uint32_t depth, uint32_t flags);
 int ssdr_feed_slot(ssdr_ctx *ctx, void **host_in);
 int ssdr_feed_submit(ssdr_ctx *ctx);

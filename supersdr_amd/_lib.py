@@ -137,6 +137,7 @@ _SIGS = {
     "ssdr_checkpoint_load": (C.c_int, [_P, _P, C.c_uint64]),
     "ssdr_get_config": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ssdr_db2col_line": (C.c_int, [_P, _P, C.c_uint32, C.POINTER(Db2colChan), _P]),
+    "ssdr_feed_collect_lazy": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "ssdr_output_checksum": (C.c_int, [_P, C.POINTER(C.c_uint64 * 3)]),
     "ssdr_set_wf_lines": (C.c_int, [_P, _P, C.c_uint32]),
     "ssdr_set_pcm": (C.c_int, [_P, _P, C.c_uint32]),

@@ -116,12 +116,19 @@ struct ssdr_ctx {
         int16_t *d_play = nullptr, *h_play = nullptr, *d_mono = nullptr, *h_mono = nullptr;
         bool has_mono = false;
         uint32_t n_post = 0;                             // channels the batch was post-processed for (ssdr_set_post_channels at submit)
+        // SSDR_FEED_LAZY_OUT: compact rows of the selected channels (what is copied back); the whole-batch d_wf / d_pcm / ... stay on the device
+        int16_t *d_sel_wf = nullptr, *d_sel_pcm = nullptr;
+        float *d_sel_rssi = nullptr, *d_sel_wire_rssi = nullptr;
+        uint8_t *d_sel_flags = nullptr;
+        uint32_t n_sel = 0;
     };
     std::vector<FeedSlot> feed;
     uint32_t feed_frames = 0, feed_head = 0, feed_tail = 0, feed_inflight = 0;
     bool feed_taken = false;                             // slot at feed_head handed to the caller, not yet submitted
     bool feed_wire = false;                              // slots hold SND bodies (kiwi/client.py:443-454), unpacked on the device
     bool feed_post = false;                              // SSDR_FEED_POST: db2col + play_buffer in the slot pipeline
+    bool feed_lazy = false;                              // SSDR_FEED_LAZY_OUT: only the selected channels' results are copied back
+    uint32_t feed_lazy_max = 0;                          // rows the compact buffers hold
     std::vector<ssdr_db2col_chan> feed_dbchan;           // display state for the next submits (ssdr_feed_post)
     std::vector<ssdr_play_chan> feed_playchan;
     int feed_last = -1;                                  // slot ssdr_feed_collect returned last
@@ -1180,7 +1187,8 @@ int ssdr_feed_close(ssdr_ctx *c)
     for (auto &s : c->feed) {
         void *hp[] = {s.h_in, s.h_wf, s.h_pcm, s.h_rssi, s.h_wire_rssi, s.h_flags, s.h_color, s.h_dbchan, s.h_playchan, s.h_play, s.h_mono};
         for (void *p : hp) if (p) (void)hipHostFree(p);
-        void *dp[] = {s.d_in, s.d_wf, s.d_pcm, s.d_rssi, s.d_wire, s.d_wire_rssi, s.d_flags, s.d_color, s.d_dbchan, s.d_play, s.d_mono};
+        void *dp[] = {s.d_in, s.d_wf, s.d_pcm, s.d_rssi, s.d_wire, s.d_wire_rssi, s.d_flags, s.d_color, s.d_dbchan, s.d_play, s.d_mono,
+                      s.d_sel_wf, s.d_sel_pcm, s.d_sel_rssi, s.d_sel_wire_rssi, s.d_sel_flags};
         for (void *p : dp) if (p) (void)hipFree(p);
         hipEvent_t ev[] = {s.ev_in, s.ev_run, s.ev_out};
         for (hipEvent_t e : ev) if (e) (void)hipEventDestroy(e);
@@ -1191,13 +1199,14 @@ int ssdr_feed_close(ssdr_ctx *c)
     c->feed_frames = c->feed_head = c->feed_tail = c->feed_inflight = 0;
     c->feed_taken = false;
     c->feed_post = false;
+    c->feed_lazy = false;
     c->feed_last = -1;
     return SSDR_OK;
 }
 
 int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth, uint32_t flags)
 {
-    if (!c || n_frames == 0 || (n_frames & 1u) || depth < 2 || depth > 16 || (flags & ~(uint32_t)(SSDR_FEED_WIRE | SSDR_FEED_POST))) return SSDR_EINVAL;
+    if (!c || n_frames == 0 || (n_frames & 1u) || depth < 2 || depth > 16 || (flags & ~(uint32_t)(SSDR_FEED_WIRE | SSDR_FEED_POST | SSDR_FEED_LAZY_OUT))) return SSDR_EINVAL;
     if (!c->feed.empty() || c->concurrent || c->decim != 1 || c->zoom != 1) return SSDR_ESTATE;      // the feed's slots are sized for un-zoomed 12 kHz IQ
     HIP_TRY(hipSetDevice(c->device));
     const bool post = (flags & SSDR_FEED_POST) != 0;
@@ -1218,22 +1227,33 @@ int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth, uint32_t flag
     const size_t wf_b = (size_t)(c->hop == SSDR_NFFT / 2 ? n_frames : n_frames / 2) * c->n_ch * SSDR_NFFT * 2;
     const size_t pcm_b = (size_t)c->n_ch * n_frames * SSDR_FRAME * 2;
     const size_t rssi_b = (size_t)c->n_ch * n_frames * sizeof(float);
+    // SSDR_FEED_LAZY_OUT: what comes back to the host is sized for the listeners, not for the receivers
+    const bool lazy = (flags & SSDR_FEED_LAZY_OUT) != 0;
+    c->feed_lazy = lazy;
+    c->feed_lazy_max = c->n_ch < SSDR_FEED_LAZY_MAX ? c->n_ch : SSDR_FEED_LAZY_MAX;
+    const size_t out_ch = lazy ? c->feed_lazy_max : c->n_ch;
+    const size_t h_wf_b = wf_b / c->n_ch * out_ch, h_pcm_b = pcm_b / c->n_ch * out_ch, h_rssi_b = rssi_b / c->n_ch * out_ch, h_flags_b = out_ch * n_frames;
     c->feed.resize(depth);
     bool ok = hipStreamCreateWithFlags(&c->feed_s_in, hipStreamNonBlocking) == hipSuccess &&
               hipStreamCreateWithFlags(&c->feed_s_out, hipStreamNonBlocking) == hipSuccess;
     for (auto &s : c->feed) {
         ok = ok && hipHostMalloc(&s.h_in, wire ? wire_b : in_b, hipHostMallocDefault) == hipSuccess;
         if (wire) {
-            ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_wire_rssi), rssi_b, hipHostMallocDefault) == hipSuccess;
+            ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_wire_rssi), h_rssi_b, hipHostMallocDefault) == hipSuccess;
             ok = ok && hipMalloc(&s.d_wire, wire_b + 16) == hipSuccess /* the unpack kernel reads whole dwords */ && hipMalloc(&s.d_wire_rssi, rssi_b) == hipSuccess;
         }
-        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_wf), wf_b, hipHostMallocDefault) == hipSuccess;
-        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_pcm), pcm_b, hipHostMallocDefault) == hipSuccess;
-        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_rssi), rssi_b, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_wf), h_wf_b, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_pcm), h_pcm_b, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_rssi), h_rssi_b, hipHostMallocDefault) == hipSuccess;
+        if (lazy) {
+            ok = ok && hipMalloc(&s.d_sel_wf, h_wf_b) == hipSuccess && hipMalloc(&s.d_sel_pcm, h_pcm_b) == hipSuccess;
+            ok = ok && hipMalloc(&s.d_sel_rssi, h_rssi_b) == hipSuccess && hipMalloc(&s.d_sel_flags, h_flags_b) == hipSuccess;
+            if (wire) ok = ok && hipMalloc(&s.d_sel_wire_rssi, h_rssi_b) == hipSuccess;
+        }
         ok = ok && hipMalloc(&s.d_in, in_b) == hipSuccess && hipMalloc(&s.d_wf, wf_b) == hipSuccess;
         ok = ok && hipMalloc(&s.d_pcm, pcm_b) == hipSuccess && hipMalloc(&s.d_rssi, rssi_b) == hipSuccess;
         ok = ok && hipMalloc(&s.d_flags, (size_t)c->n_ch * n_frames) == hipSuccess;
-        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_flags), (size_t)c->n_ch * n_frames, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&s.h_flags), h_flags_b, hipHostMallocDefault) == hipSuccess;
         if (post) {
             const size_t color_b = wf_b * 2, db_b = (size_t)c->n_ch * sizeof(ssdr_db2col_chan);
             const size_t play_b = (size_t)c->n_ch * n_frames * 2048 * 2 * sizeof(int16_t);       // sized for the x4 form, either rate fits
@@ -1270,6 +1290,7 @@ static int feed_submit_impl(ssdr_ctx *c, const void *host_in)
     HIP_TRY(hipSetDevice(c->device));
     auto &s = c->feed[c->feed_head];
     const uint32_t nf = c->feed_frames;
+    if (c->feed_lazy && (c->d_post_sel ? c->n_post : c->n_ch) > c->feed_lazy_max) return SSDR_ESTATE;     // more listeners than the compact rows hold
     if (c->feed_wire)
         HIP_TRY(hipMemcpyAsync(s.d_wire, host_in, (size_t)c->n_ch * nf * SSDR_WIRE_BODY, hipMemcpyHostToDevice, c->feed_s_in));
     else
@@ -1343,15 +1364,33 @@ static int feed_submit_impl(ssdr_ctx *c, const void *host_in)
     c->d_flags = k_flags; c->flags_frames = k_ff;
     if (rc != SSDR_OK) return rc;
     s.lines = lines;
+    // what goes back: every channel's rows, or (SSDR_FEED_LAZY_OUT) the selected channels' rows gathered into compact ones
+    const int16_t *o_wf = s.d_wf, *o_pcm = s.d_pcm;
+    const float *o_rssi = s.d_rssi, *o_wire_rssi = s.d_wire_rssi;
+    const uint8_t *o_flags = s.d_flags;
+    size_t o_ch = c->n_ch;
+    s.n_sel = c->n_ch;
+    if (c->feed_lazy) {
+        SsdrGatherArgs g;
+        g.wf = s.d_wf; g.pcm = s.d_pcm; g.rssi = s.d_rssi; g.flags = s.d_flags; g.wire_rssi = c->feed_wire ? s.d_wire_rssi : nullptr;
+        g.wf_out = s.d_sel_wf; g.pcm_out = s.d_sel_pcm; g.rssi_out = s.d_sel_rssi; g.flags_out = s.d_sel_flags; g.wire_rssi_out = s.d_sel_wire_rssi;
+        g.sel = c->d_post_sel; g.n_sel = c->d_post_sel ? c->n_post : c->n_ch; g.n_ch = c->n_ch; g.n_lines = lines; g.n_frames = nf;
+        HIP_TRY(ssdr_launch_gather(g, c->stream));
+        o_wf = s.d_sel_wf; o_pcm = s.d_sel_pcm; o_rssi = s.d_sel_rssi; o_wire_rssi = s.d_sel_wire_rssi; o_flags = s.d_sel_flags;
+        o_ch = g.n_sel;
+        s.n_sel = g.n_sel;
+    }
     HIP_TRY(hipEventRecord(s.ev_run, c->stream));
     HIP_TRY(hipStreamWaitEvent(c->feed_s_out, s.ev_run, 0));
-    if (lines)
-        HIP_TRY(hipMemcpyAsync(s.h_wf, s.d_wf, (size_t)lines * c->n_ch * SSDR_NFFT * 2, hipMemcpyDeviceToHost, c->feed_s_out));
-    HIP_TRY(hipMemcpyAsync(s.h_pcm, s.d_pcm, (size_t)c->n_ch * nf * SSDR_FRAME * 2, hipMemcpyDeviceToHost, c->feed_s_out));
-    HIP_TRY(hipMemcpyAsync(s.h_rssi, s.d_rssi, (size_t)c->n_ch * nf * sizeof(float), hipMemcpyDeviceToHost, c->feed_s_out));
-    if (c->feed_wire)
-        HIP_TRY(hipMemcpyAsync(s.h_wire_rssi, s.d_wire_rssi, (size_t)c->n_ch * nf * sizeof(float), hipMemcpyDeviceToHost, c->feed_s_out));
-    HIP_TRY(hipMemcpyAsync(s.h_flags, s.d_flags, (size_t)c->n_ch * nf, hipMemcpyDeviceToHost, c->feed_s_out));
+    if (lines && o_ch)
+        HIP_TRY(hipMemcpyAsync(s.h_wf, o_wf, (size_t)lines * o_ch * SSDR_NFFT * 2, hipMemcpyDeviceToHost, c->feed_s_out));
+    if (o_ch) {
+        HIP_TRY(hipMemcpyAsync(s.h_pcm, o_pcm, o_ch * nf * SSDR_FRAME * 2, hipMemcpyDeviceToHost, c->feed_s_out));
+        HIP_TRY(hipMemcpyAsync(s.h_rssi, o_rssi, o_ch * nf * sizeof(float), hipMemcpyDeviceToHost, c->feed_s_out));
+        if (c->feed_wire)
+            HIP_TRY(hipMemcpyAsync(s.h_wire_rssi, o_wire_rssi, o_ch * nf * sizeof(float), hipMemcpyDeviceToHost, c->feed_s_out));
+        HIP_TRY(hipMemcpyAsync(s.h_flags, o_flags, o_ch * nf, hipMemcpyDeviceToHost, c->feed_s_out));
+    }
     if (c->feed_post) {
         const size_t per_frame = c->kiwi_rate != SSDR_RATE ? (size_t)SSDR_RS_OUT_PER_FRAME : 2048;
         if (lines && c->n_post) {
@@ -1443,6 +1482,19 @@ int ssdr_feed_collect(ssdr_ctx *c, int16_t **wf_sum, uint32_t *lines, int16_t **
     c->feed_last = (int)c->feed_tail;
     c->feed_tail = (c->feed_tail + 1) % (uint32_t)c->feed.size();
     c->feed_inflight--;
+    return SSDR_OK;
+}
+
+int ssdr_feed_collect_lazy(ssdr_ctx *c, uint32_t *n_sel, int16_t **d_wf_sum, int16_t **d_pcm, float **d_rssi, uint8_t **d_flags)
+{
+    if (!c) return SSDR_EINVAL;
+    if (c->feed.empty() || c->feed_last < 0) return SSDR_ESTATE;
+    auto &s = c->feed[c->feed_last];
+    if (n_sel) *n_sel = s.n_sel;
+    if (d_wf_sum) *d_wf_sum = s.d_wf;
+    if (d_pcm) *d_pcm = s.d_pcm;
+    if (d_rssi) *d_rssi = s.d_rssi;
+    if (d_flags) *d_flags = s.d_flags;
     return SSDR_OK;
 }
 

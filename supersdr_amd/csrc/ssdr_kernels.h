@@ -127,6 +127,13 @@ struct SsdrWireArgs {
                                              // last_gps_solution, dummy, gpssec, gpsnsec; and the header's flags / seq ride along: see ssdr.h
 };
 
+struct SsdrGatherArgs {                      // SSDR_FEED_LAZY_OUT: rows of the selected channels -> compact rows
+    const int16_t *wf; const int16_t *pcm; const float *rssi; const uint8_t *flags; const float *wire_rssi;     // whole-batch results (wire_rssi may be null)
+    int16_t *wf_out; int16_t *pcm_out; float *rssi_out; uint8_t *flags_out; float *wire_rssi_out;                // [..][n_sel]..
+    const uint32_t *sel;                     // [n_sel] channel of every position, or null (position == channel)
+    uint32_t n_sel, n_ch, n_lines, n_frames;
+};
+hipError_t ssdr_launch_gather(const SsdrGatherArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_db2col(const SsdrDb2colArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_play(const SsdrPlayArgs &a, hipStream_t stream);
 hipError_t ssdr_launch_play_rs(const SsdrPlayArgs &a, hipStream_t stream);

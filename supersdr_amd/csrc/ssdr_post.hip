@@ -531,7 +531,38 @@ __global__ __launch_bounds__(256) void ssdr_checksum_kernel(const uint32_t *data
     if (threadIdx.x == 0) atomicAdd(out, part[0]);
 }
 
+// SSDR_FEED_LAZY_OUT: the results of the channels somebody listens to, gathered into compact rows (position in the selection) for the
+// copy back to the host; everything else stays on the device.  One workgroup per selected channel; 16 bytes per lane where the rows allow it.
+__global__ __launch_bounds__(256) void ssdr_gather_kernel(SsdrGatherArgs a)
+{
+    const uint32_t pos = blockIdx.x;
+    const uint32_t ch = a.sel ? a.sel[pos] : pos;
+    typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+    for (uint32_t line = 0; line < a.n_lines; line++) {                        // [line][ch][1024] int16 -> [line][pos][1024]
+        const u4 *src = reinterpret_cast<const u4 *>(a.wf + ((uint64_t)line * a.n_ch + ch) * SSDR_NFFT);
+        u4 *dst = reinterpret_cast<u4 *>(a.wf_out + ((uint64_t)line * a.n_sel + pos) * SSDR_NFFT);
+        for (uint32_t i = threadIdx.x; i < SSDR_NFFT * 2 / 16; i += blockDim.x) dst[i] = src[i];
+    }
+    {                                                                          // [ch][n_frames * 512] int16 -> [pos][...]
+        const u4 *src = reinterpret_cast<const u4 *>(a.pcm + (uint64_t)ch * a.n_frames * SSDR_FRAME);
+        u4 *dst = reinterpret_cast<u4 *>(a.pcm_out + (uint64_t)pos * a.n_frames * SSDR_FRAME);
+        for (uint32_t i = threadIdx.x; i < a.n_frames * (SSDR_FRAME * 2 / 16); i += blockDim.x) dst[i] = src[i];
+    }
+    for (uint32_t f = threadIdx.x; f < a.n_frames; f += blockDim.x) {
+        a.rssi_out[(uint64_t)pos * a.n_frames + f] = a.rssi[(uint64_t)ch * a.n_frames + f];
+        a.flags_out[(uint64_t)pos * a.n_frames + f] = a.flags[(uint64_t)ch * a.n_frames + f];
+        if (a.wire_rssi) a.wire_rssi_out[(uint64_t)pos * a.n_frames + f] = a.wire_rssi[(uint64_t)ch * a.n_frames + f];
+    }
+}
+
 } // namespace
+
+hipError_t ssdr_launch_gather(const SsdrGatherArgs &a, hipStream_t stream)
+{
+    if (!a.n_sel) return hipSuccess;
+    hipLaunchKernelGGL(ssdr_gather_kernel, dim3(a.n_sel), dim3(256), 0, stream, a);
+    return hipGetLastError();
+}
 
 hipError_t ssdr_launch_checksum(const void *data, uint64_t n_words, unsigned long long *out, hipStream_t stream)
 {

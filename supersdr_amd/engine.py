@@ -254,11 +254,15 @@ class SsdrEngine:
         return out
 
     # ---- pipelined host feed (copy-in / kernels / copy-out of consecutive batches overlap)
-    def feed_open(self, n_frames, depth=3, wire=False, post=False):
+    def feed_open(self, n_frames, depth=3, wire=False, post=False, lazy_out=False):
         """wire=True: slots take SND bodies uint8 [n_ch, n_frames, 2065] (kiwi/client.py:443-454), unpacked on the device.
-        post=True: every batch also goes through spectrum_db2col / play_buffer on the device (feed_post, feed_collect_post)."""
-        check(lib.ssdr_feed_open(self._ctx, int(n_frames), int(depth), (1 if wire else 0) | (2 if post else 0)), "ssdr_feed_open")
+        post=True: every batch also goes through spectrum_db2col / play_buffer on the device (feed_post, feed_collect_post).
+        lazy_out=True (SSDR_FEED_LAZY_OUT): only the channels of set_post_channels come back to the host -- feed_collect's arrays then
+        have one row per SELECTED channel (the selection in force at the batch's submit); every channel's results stay on the
+        device (feed_device)."""
+        check(lib.ssdr_feed_open(self._ctx, int(n_frames), int(depth), (1 if wire else 0) | (2 if post else 0) | (4 if lazy_out else 0)), "ssdr_feed_open")
         self._feed_frames, self._feed_wire, self._feed_post = int(n_frames), bool(wire), bool(post)
+        self._feed_lazy = bool(lazy_out)
         self._feed_lines = 0
         self._feed_n_post, self._feed_last_n_post = [], self.n_post
 
@@ -339,15 +343,33 @@ class SsdrEngine:
         nf, nl = self._feed_frames, int(lines.value)
         self._feed_lines = nl
         self._feed_last_n_post = self._feed_n_post.pop(0) if self._feed_n_post else self.n_post
-        self.feed_flags = np.ctypeslib.as_array(C.cast(fl, C.POINTER(C.c_uint8)), shape=(self.n_ch * nf,)).reshape(self.n_ch, nf)
+        rows = self.n_ch                           # rows of the arrays: every channel, or (lazy_out) the channels selected at the batch's submit
+        if getattr(self, "_feed_lazy", False):
+            n_sel = C.c_uint32()
+            check(lib.ssdr_feed_collect_lazy(self._ctx, C.byref(n_sel), None, None, None, None), "ssdr_feed_collect_lazy")
+            rows = int(n_sel.value)
+        self.feed_rows = rows
+
+        def view(ptr, ctype, dtype, shape):
+            n = int(np.prod(shape))
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(n,)).reshape(shape) if n else np.zeros(shape, dtype)
+
+        self.feed_flags = view(fl, C.c_uint8, np.uint8, (rows, nf))
         self.feed_n_avg = int(navg.value)          # the N in force when this batch was submitted
-        w = (np.ctypeslib.as_array(C.cast(wf, C.POINTER(C.c_int16)), shape=(nl * self.n_ch * L.NFFT,)).reshape(nl, self.n_ch, L.NFFT)
-             if nl else np.zeros((0, self.n_ch, L.NFFT), np.int16))
-        p = np.ctypeslib.as_array(C.cast(pcm, C.POINTER(C.c_int16)), shape=(self.n_ch * nf * L.FRAME,)).reshape(self.n_ch, -1)
-        r = np.ctypeslib.as_array(C.cast(rssi, C.POINTER(C.c_float)), shape=(self.n_ch * nf,)).reshape(self.n_ch, nf)
+        w = view(wf, C.c_int16, np.int16, (nl, rows, L.NFFT))
+        p = view(pcm, C.c_int16, np.int16, (rows, nf * L.FRAME))
+        r = view(rssi, C.c_float, np.float32, (rows, nf))
         if self._feed_wire:
-            return w, p, r, np.ctypeslib.as_array(C.cast(wr, C.POINTER(C.c_float)), shape=(self.n_ch * nf,)).reshape(self.n_ch, nf)
+            return w, p, r, view(wr, C.c_float, np.float32, (rows, nf))
         return w, p, r
+
+    def feed_device(self):
+        """device pointers (ints) of EVERY channel's results of the batch feed_collect returned last -> dict(wf, pcm, rssi, flags, rows):
+        wf int16 [lines][n_ch][1024], pcm int16 [n_ch][n_frames*512], rssi float32 / flags uint8 [n_ch][n_frames]; valid until
+        depth - 1 further batches have been submitted.  For device-side consumers of a lazy_out feed."""
+        n_sel, a, b, c, d = C.c_uint32(), C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        check(lib.ssdr_feed_collect_lazy(self._ctx, C.byref(n_sel), C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "ssdr_feed_collect_lazy")
+        return {"wf": a.value, "pcm": b.value, "rssi": c.value, "flags": d.value, "rows": int(n_sel.value), "lines": self._feed_lines}
 
     def feed_close(self):
         check(lib.ssdr_feed_close(self._ctx), "ssdr_feed_close")

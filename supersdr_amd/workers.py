@@ -73,9 +73,11 @@ class SuperframeResult:
     spectrum_db2col left them), play int16 [n_ch, frames*L, 2], mono (recording) -- or None where that stage did not run.
     On a lazy hub the post-processing runs for the channels with a worker only: post_channels lists them, and color / chans /
     play / mono have one entry per listed channel, in that order (post_channels None: one per channel).
+    On a lazy_out hub (SSDR_FEED_LAZY_OUT) wf / pcm / rssi / flags / wire_rssi too have one row per channel of out_channels (the attached
+    channels at the batch's submit) instead of one per channel; out_channels None: one per channel.
     In pipeline mode the arrays are views of the feed's pinned slots: valid until `depth - 1` further superframes have
     been collected (copy what must live longer)."""
-    __slots__ = ("seq", "wf", "n_avg", "color", "chans", "pcm", "rssi", "flags", "play", "mono", "iq", "wire_rssi", "post_channels")
+    __slots__ = ("seq", "wf", "n_avg", "color", "chans", "pcm", "rssi", "flags", "play", "mono", "iq", "wire_rssi", "post_channels", "out_channels")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -155,7 +157,7 @@ class IQHub:
 
     def __init__(self, n_channels, device=0, engine=None, max_queue=64, gpu_post=True, kiwi_rate=12000, trace_rows=0,
                  backlog_superframes=8, stall_superframes=4, pipeline=False, depth=3, hop=1024, zoom=1, lazy=None,
-                 batch_superframes=1, wire=False, copy_threads=None, exact_bins=False):
+                 batch_superframes=1, wire=False, copy_threads=None, exact_bins=False, lazy_out=False):
         self.n_ch = int(n_channels)
         self.engine = engine if engine is not None else SsdrEngine(self.n_ch, device)
         # waterfall zoom ("SET zoom=", utils_supersdr.py:741, 839): the lines then span 1/zoom of the IQ band around each
@@ -237,6 +239,12 @@ class IQHub:
         # spectrum_db2col / play_buffer are per viewer: a lazy hub runs them for the channels with a worker only
         # (ssdr_set_post_channels); a hub that attaches everybody keeps them on every channel
         self._post_select = self._lazy and hasattr(self.engine, "set_post_channels")
+        # lazy_out (round 5, SSDR_FEED_LAZY_OUT): only the ATTACHED channels' lines / PCM / RSSI / flags are copied back from the GPU
+        # (a hub of 10^5 receivers has a handful of listeners); the result arrays then have one row per attached channel
+        # (SuperframeResult.out_channels) and every channel's results stay on the device (engine.feed_device())
+        self._lazy_out = bool(lazy_out)
+        if self._lazy_out and not (self.pipeline and self._post_select):
+            raise ValueError("lazy_out needs the pipelined feed and a lazy hub (pipeline=True, lazy=True)")
         self._post_sel, self._post_pos, self._post_dirty = None, None, self._post_select
         self._inflight_sel = deque()                 # pipelined: the selection each batch in flight was submitted with
         self._alloc_post_arrays(self.n_ch)
@@ -251,7 +259,8 @@ class IQHub:
         self._lock = threading.RLock()
         self.superframes = 0
         if self.pipeline:
-            self.engine.feed_open(2 * self.zoom * self.batch_superframes, self._depth, post=self.gpu_post, **({"wire": True} if self.wire else {}))
+            self.engine.feed_open(2 * self.zoom * self.batch_superframes, self._depth, post=self.gpu_post, **({"wire": True} if self.wire else {}),
+                                  **({"lazy_out": True} if self._lazy_out else {}))
         if not self._lazy:
             for c in range(self.n_ch):
                 self.attach(c, wf=True, snd=True)
@@ -270,6 +279,7 @@ class IQHub:
             if snd and c not in self.snd_queue._q:
                 self.snd_queue._q[c] = queue.Queue(2 * self._max_queue)
                 bisect.insort(self._snd_att, c)
+            self._post_dirty = self._post_select            # the selection follows who is attached (re-derived before the next superframe)
         return {"wf": self.wf_queue._q.get(c), "snd": self.snd_queue._q.get(c)}
 
     def detach(self, channel, wf=True, snd=True):
@@ -279,6 +289,7 @@ class IQHub:
                 self._wf_att.remove(c)
             if snd and self.snd_queue._q.pop(c, None) is not None:
                 self._snd_att.remove(c)
+            self._post_dirty = self._post_select
 
     def subscribe(self, fn):
         """fn(SuperframeResult) after every GPU run, on the feeding thread, with the hub's lock held: the bulk consumer's
@@ -299,7 +310,10 @@ class IQHub:
     def _apply_post_selection(self):
         """lazy hub: the post kernels' channel list follows the workers that are attached"""
         self._post_dirty = False
-        sel = sorted({c for c in self._wf_att if self.wf_clients[c] is not None} | {c for c in self._snd_att if self.snd_clients[c] is not None})
+        if self._lazy_out:                               # what comes back from the GPU: every attached channel (worker or bare queue)
+            sel = sorted(set(self._wf_att) | set(self._snd_att))
+        else:
+            sel = sorted({c for c in self._wf_att if self.wf_clients[c] is not None} | {c for c in self._snd_att if self.snd_clients[c] is not None})
         if sel == self._post_sel:
             return
         self.engine.set_post_channels(sel)
@@ -525,12 +539,14 @@ class IQHub:
         pos = self._post_pos
         for c in self._wf_att:
             w = self.wf_clients[c]
-            if w is not None:
-                self._db_arr[c if pos is None else pos[c]] = self._db2col_chan(w)
+            pc = c if pos is None else pos.get(c)
+            if w is not None and pc is not None:
+                self._db_arr[pc] = self._db2col_chan(w)
         for c in self._snd_att:
             s = self.snd_clients[c]
-            if s is not None:
-                self._play_arr[c if pos is None else pos[c]] = PlayChan(float(s.volume), float(s.audio_balance))
+            pc = c if pos is None else pos.get(c)
+            if s is not None and pc is not None:
+                self._play_arr[pc] = PlayChan(float(s.volume), float(s.audio_balance))
 
     def _sync_recording(self):
         rec = any(self.snd_clients[c] is not None and self.snd_clients[c].audio_rec.recording_flag for c in self._snd_att)
@@ -569,26 +585,33 @@ class IQHub:
             fn(r)
         P, wf, pcm = self.play_len, r.wf, r.pcm
         pos = None if r.post_channels is None else {c: i for i, c in enumerate(r.post_channels)}      # row of a channel in the post results
+        opos = None if r.out_channels is None else (pos if r.out_channels is r.post_channels else {c: i for i, c in enumerate(r.out_channels)})
         for c in self._wf_att:
             q = self.wf_queue._q[c]
             pc = c if pos is None else pos.get(c)
+            oc = c if opos is None else opos.get(c)          # row of the channel's line (lazy_out: attached after the batch left -> not in it)
+            if oc is None:
+                continue
             has_post = r.color is not None and self.wf_clients[c] is not None and pc is not None
             for i in range(len(wf)):
                 post = None
                 if has_post:
                     k = r.chans[pc]
                     post = (r.color[i, pc].copy(), k.low_clip_db, k.high_clip_db, k.dynamic_range, k.wf_min_db, k.wf_max_db)
-                _put_drop_oldest(q, (wf[i, c].copy(), r.n_avg, post))
+                _put_drop_oldest(q, (wf[i, oc].copy(), r.n_avg, post))
         for c in self._snd_att:
             q = self.snd_queue._q[c]
             iq_mode = r.iq is not None and self.params(c).mode == L.MODE_IQ
             pc = c if pos is None else pos.get(c)
+            oc = c if opos is None else opos.get(c)
+            if oc is None:
+                continue
             has_play = r.play is not None and pc is not None
             for f in range(pcm.shape[1] // L.FRAME):
                 _put_drop_oldest(q, Frame.make(
-                    pcm[c, f * L.FRAME:(f + 1) * L.FRAME], r.rssi[c, f],
+                    pcm[oc, f * L.FRAME:(f + 1) * L.FRAME], r.rssi[oc, f],
                     r.play[pc, f * P:(f + 1) * P].copy() if has_play else None,
-                    r.mono[pc, f * P:(f + 1) * P].copy() if has_play and r.mono is not None else None, r.flags[c, f],
+                    r.mono[pc, f * P:(f + 1) * P].copy() if has_play and r.mono is not None else None, r.flags[oc, f],
                     r.iq[c, f * L.FRAME:(f + 1) * L.FRAME].copy() if iq_mode else None))
 
     def _run_pipelined(self, batch):
@@ -597,6 +620,8 @@ class IQHub:
             self._sync_recording()
             self._sync_display_state()
             eng.feed_post(self._db_arr, self._play_arr)
+        if self._post_dirty:                          # (without gpu_post nobody else re-derives it: lazy_out's rows follow the attached channels)
+            self._apply_post_selection()
         self._inflight_sel.append(self._post_sel)
         if hasattr(eng, "feed_submit_from"):
             eng.feed_submit_from(batch)               # the H2D copy reads the hub's slot itself
@@ -624,7 +649,7 @@ class IQHub:
                 play = mono = None
         self._hand_out(SuperframeResult(seq=self.superframes - self._inflight, wf=wf, n_avg=n_avg, color=color, chans=chans, pcm=pcm,
                                         rssi=rssi, flags=flags, play=play, mono=mono, wire_rssi=got[3] if len(got) > 3 else None,
-                                        post_channels=sel))
+                                        post_channels=sel, out_channels=sel if self._lazy_out else None))
 
     def flush(self):
         """pipeline mode: wait for the superframes still in flight and hand their results out"""

@@ -129,3 +129,26 @@ def test_eight_ranks_meet_over_gloo_shard_a_million_channels_and_close_the_parit
     assert d["config"]["rendezvous"] == "gloo" and d["parity"]["ranks_agree"]
     assert d["parity"]["first_channel_ids"] == [r * 131072 for r in range(8)] and len({tuple(c) for c in d["parity"]["checksums"]}) == 8
     assert abs(d["max_wall"] - 8e-3) < 1e-9
+
+
+def test_hub_feed_line_sums_over_the_ranks():
+    """Round 5: bench.py --gpus N --host-feed 3|4 (the PCIe-inclusive rate through IQHub) is a multi-rank measurement: a barrier on both
+    sides of the timed region, the ranks' channel-superframes summed, over the slowest rank's time -- not rank 0's own line."""
+    p = run(["--gpus", "3", "--dry-run", "--host-feed", "4", "--channels", "1000", "--superframes", "4", "--steps", "5"])
+    assert p.returncode == 0, p.stderr
+    d = last_json(p)
+    assert d["n_gpus"] == 3 and d["dry_run"] and d["scaling"] == "weak"
+    units = 3 * 1000 * 4 * 5
+    assert abs(d["value"] - units / 3e-3 / 11.71875) < 1e-6 * d["value"]          # all ranks' units / the slowest rank's wall (3 ms)
+    assert len(d["per_rank"]["values"]) == 3 and d["per_rank"]["value_max"] == d["per_rank"]["values"][0]
+    assert abs(d["per_rank"]["values"][2] - 1000 * 4 * 5 / 3e-3 / 11.71875) < 1e-3
+    assert d["per_rank"]["numa_bound"] == [False] * 3 and d["per_rank"]["gpu_numa_node"] == [None] * 3
+
+
+def test_numa_cpulist_parser():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", BENCH)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and b.parse_cpulist("") == set()
+    assert b.bind_to_numa_node(None) == {"gpu_numa_node": None, "bound": False}

@@ -630,13 +630,16 @@ def test_post_processing_for_the_listeners_only(S):
     N, who = 600, (41, 500)
     big = O.synth_iq(N, 5 * 1024, seed=53)
     seen = {}
-    for name, kw in (("everybody", dict(lazy=False)), ("listeners", dict(lazy=True)), ("listeners, pipelined", dict(lazy=True, pipeline=True, depth=3))):
+    whole = {}
+    for name, kw in (("everybody", dict(lazy=False)), ("listeners", dict(lazy=True)), ("listeners, pipelined", dict(lazy=True, pipeline=True, depth=3)),
+                     ("listeners, pipelined, lazy out", dict(lazy=True, pipeline=True, depth=3, lazy_out=True))):
         hub = IQHub(N, **kw)
         wfs = [kiwi_waterfall("gpu", 0, "", 4 + i, 7100.0, None, Disp(), hub=hub, channel=c, timeout=1.0) for i, c in enumerate(who)]
         snds = [kiwi_sound(7100.0 + i, "AM", -6000, 6000, "", w, 8) for i, w in enumerate(wfs)]
         snds[1].volume, snds[1].audio_balance = 130, 0.5
-        rows = []
+        rows, outs = [], []
         hub.subscribe(lambda r: rows.append((r.post_channels, None if r.color is None else r.color.shape, None if r.play is None else r.play.shape)))
+        hub.subscribe(lambda r: outs.append((r.out_channels, r.wf.shape, r.pcm.shape, r.rssi.shape, r.flags.shape)))
         for k in range(5):
             hub.feed_block(0, big[:, k * 1024:(k + 1) * 1024])
         hub.flush()
@@ -653,8 +656,25 @@ def test_post_processing_for_the_listeners_only(S):
             assert hub.post_channels == list(who) and all(r == (list(who), (1, 2, 1024), (2, 2 * 2048, 2)) for r in rows)
         else:
             assert hub.post_channels is None and rows[0][1] == (1, N, 1024)
+        if kw.get("lazy_out"):
+            # round 5 (SSDR_FEED_LAZY_OUT): two rows come back per superframe instead of 600 -- and every channel's results are still there, on the device
+            assert all(o == (list(who), (1, 2, 1024), (2, 1024), (2, 2), (2, 2)) for o in outs), outs[:2]
+            import ctypes as C
+            from supersdr_amd._lib import lib, check
+            dev = hub.engine.feed_device()
+            assert dev["rows"] == 2 and dev["lines"] == 1
+            pcm_all, wf_all = np.empty((N, 1024), np.int16), np.empty((1, N, 1024), np.int16)
+            check(lib.ssdr_copy_from_device(hub.engine._ctx, pcm_all.ctypes.data, C.c_void_p(dev["pcm"]), pcm_all.nbytes), "copy")
+            check(lib.ssdr_copy_from_device(hub.engine._ctx, wf_all.ctypes.data, C.c_void_p(dev["wf"]), wf_all.nbytes), "copy")
+            assert np.array_equal(pcm_all, whole["pcm"]) and np.array_equal(wf_all, whole["wf"])
+        else:
+            assert all(o[0] is None and o[1] == (1, N, 1024) and o[2] == (N, 1024) for o in outs)
+            if kw.get("pipeline"):
+                whole = {"pcm": hub.last.pcm.copy(), "wf": hub.last.wf.copy()}
         hub.close()
-    for name in ("listeners", "listeners, pipelined"):
+    with pytest.raises(ValueError):
+        IQHub(8, lazy=True, lazy_out=True)                     # (needs the pipelined feed)
+    for name in ("listeners", "listeners, pipelined", "listeners, pipelined, lazy out"):
         for a, b in zip(seen["everybody"], seen[name]):
             assert all(np.array_equal(x, y) for x, y in zip(a, b)), name
 

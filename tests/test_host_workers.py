@@ -1017,6 +1017,28 @@ def test_lazy_hub_post_processes_its_listeners_only_and_they_see_what_they_alway
         assert all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
+def test_lazy_hub_selection_follows_manual_attach_and_detach(gpu):
+    """Round 5 (advisor): on a lazy hub the post selection was re-derived on client changes only.  A worker is set on a channel,
+    the channel is detached before the next superframe (the selection is computed without it) and attached again by hand:
+    _sync_display_state then looked the channel up in a selection that did not hold it (KeyError on the feeding thread).  The
+    selection now follows attach() / detach() as well, and a channel outside it is skipped."""
+    from supersdr_amd.workers import IQHub
+    n_ch = 6
+    iq = O.synth_iq(n_ch, 4 * 1024, seed=92)
+    hub = IQHub(n_ch, engine=TwinEngine(n_ch), lazy=True)
+    wf = gpu.kiwi_waterfall("gpu", 0, "", 5, 7100.0, Eibi(), Disp(), hub=hub, channel=3, timeout=0.2)
+    snd = gpu.kiwi_sound(7100.0, "AM", -6000, 6000, "", wf, 8)
+    hub.detach(3)                                              # gone before the first superframe: the selection is derived without it
+    hub.feed_block(0, iq[:, :1024])
+    assert hub.post_channels == []
+    hub.attach(3, wf=True, snd=True)                           # back by hand: its workers are still the channel's clients
+    hub.feed_block(0, iq[:, 1024:2048])                        # (used to raise KeyError: 3)
+    assert hub.post_channels == [3] and hub.last.color.shape[1] == 1
+    wf.step()
+    assert wf.wf_color.shape == (1024,) and snd.process_audio_stream().play_block.shape[0] == 2048
+    hub.close()
+
+
 def test_hub_fed_from_many_threads_delivers_every_stream_in_order():
     """the reference's ingest is one thread per receiver (supersdr.py:121, utils_supersdr.py:1198): eight feeder threads, each with
     its own block of receivers and its own chunking, push into one hub at once; every receiver's samples come out of the
