@@ -184,7 +184,12 @@ __global__ __launch_bounds__(256) void ssdr_db2col_kernel(SsdrDb2colArgs a)
             __builtin_nontemporal_store(o, dst0 + 64 * q);
         }
     }
-    // the display state as the LAST line leaves it (utils_supersdr.py:795-808); only the fields spectrum_db2col writes
+    // the display state as the LAST line leaves it (utils_supersdr.py:795-808); only the fields spectrum_db2col writes.
+    // INVARIANT (the waves of a channel's other lines read a.chans[pos] at their start, unordered against this store): every field
+    // written here is either recomputed by each wave from its own line (auto_scale: low / high / dynamic_range, wf_min / wf_max) or
+    // -- without auto_scale -- written back with the value it was read with; the fields a wave reads and does not recompute (zoom,
+    // auto_scale, the deltas) are never written.  So a wave sees the same inputs whichever side of the store it starts on.  State
+    // that is CARRIED from line to line would break this: it needs a second array (as ssdr_play_kernel's hist / hist_out).
     if (l == 0 && line + 1 == a.n_lines) {
         ssdr_db2col_chan *o = a.chans + pos;
         o->low_clip_db = st.low_clip_db; o->high_clip_db = st.high_clip_db; o->dynamic_range = st.dynamic_range;

@@ -22,6 +22,9 @@
 //     count table (ssdr_wf.hip:quantise, exhaustively verified) gives the exact count;
 //   * the int16 line is staged through the transpose buffer so that every lane stores 2 x 16 contiguous bytes.
 // 256-thread workgroups, three per CU (LDS: 4 x 8.1 KB transpose buffers + 16 KB of tables each), persistent grid.
+#include <map>
+#include <mutex>
+#include <utility>
 #include "ssdr_math.h"
 #include "ssdr_kernels.h"
 #include "ssdr_audio_dev.h"
@@ -570,14 +573,32 @@ __global__ __launch_bounds__(SSDR_WFX_BLOCK, SSDR_WFX_WAVES_PER_EU) void ssdr_fu
 
 } // namespace
 
+// The persistent grids' sizes are a property of the DEVICE a launch goes to: cached per device id, under a lock (a process may hold
+// contexts on several GPUs and make its first launches from several threads).  which: 0 the waterfall kernels, 1 the fused kernel.
+static bool resident_cached(int which, int dev, uint32_t *blocks, bool store)
+{
+    static std::mutex m;
+    static std::map<std::pair<int, int>, uint32_t> cache;
+    std::lock_guard<std::mutex> lock(m);
+    if (store) { cache[{which, dev}] = *blocks; return true; }
+    auto it = cache.find({which, dev});
+    if (it == cache.end()) return false;
+    *blocks = it->second;
+    return true;
+}
+
 // resident workgroups of the kernel on the current device (persistent grid)
 static hipError_t wfx_resident(uint32_t *blocks)
 {
-    static uint32_t cached = 0;
-    if (!cached) {
-        int dev = 0, per_cu = 0, b = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
+    int dev = 0;
+    {
+        hipError_t e0 = hipGetDevice(&dev);
+        if (e0 != hipSuccess) return e0;
+    }
+    uint32_t cached = 0;
+    if (!resident_cached(0, dev, &cached, false)) {
+        int per_cu = 0, b = 0;
+        hipError_t e;
         hipDeviceProp_t prop;
         if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
         per_cu = 1 << 30;
@@ -590,6 +611,7 @@ static hipError_t wfx_resident(uint32_t *blocks)
         if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ssdr_wf_exact_kernel<true, true>, SSDR_WFX_BLOCK, 0)) != hipSuccess) return e;
         per_cu = b < per_cu ? b : per_cu;
         cached = (uint32_t)prop.multiProcessorCount * (uint32_t)(per_cu < 1 ? 1 : per_cu);
+        resident_cached(0, dev, &cached, true);
     }
     *blocks = cached;
     return hipSuccess;
@@ -627,15 +649,17 @@ hipError_t ssdr_launch_wf_exact(const SsdrWfArgs &a_in, const double2 *tw, hipSt
 hipError_t ssdr_launch_fused_exact_am(const SsdrFusedArgs &a, const double2 *tw, hipStream_t stream)
 {
     if (a.wf.n_ch == 0 || a.wf.n_lines == 0) return hipSuccess;
-    static uint32_t resident = 0;
-    if (!resident) {
-        int dev = 0, b = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
+    uint32_t resident = 0;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (!resident_cached(1, dev, &resident, false)) {
+        int b = 0;
         hipDeviceProp_t prop;
         if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
         if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ssdr_fused_exact_am_kernel, SSDR_WFX_BLOCK, 0)) != hipSuccess) return e;
         resident = (uint32_t)prop.multiProcessorCount * (uint32_t)(b < 1 ? 1 : b);
+        resident_cached(1, dev, &resident, true);
     }
     constexpr uint32_t waves = SSDR_WFX_BLOCK / 64;
     const uint64_t need = ((uint64_t)a.wf.n_ch + waves - 1) / waves;

@@ -762,6 +762,8 @@ def test_full_size_batch_properties(S, twin):
         eng.set_averaging(n_avg)
         eng.synth_iq(n_frames, seed=99)
         iq_sub = np.stack([eng.read_input(int(c), 1)[0] for c in sub])
+        sub64 = np.arange(3, n_ch, 255)[:256]               # the float64 check's channels: a strided 256, every mode 64 times
+        iq64 = np.stack([eng.read_input(int(c), 1)[0] for c in sub64])
         wf = eng.run_wf()
         pcm, rssi = eng.run_audio()
         csum1 = (int(wf.astype(np.int64).sum()), int(pcm.astype(np.int64).sum()), float(rssi.astype(np.float64).sum()))
@@ -788,17 +790,20 @@ def test_full_size_batch_properties(S, twin):
         p3, r3 = eng.run_audio()
         assert np.array_equal(p3, pcm[sub]) and np.array_equal(r3, rssi[sub])
     assert len(np.unique(k["mode"])) == 4 and pcm.std() > 1000
-    # ... and against the float64 definition at this very shape: eight of the channels (two of each mode):
-    # the N = 10 sums identical outside the guard band, PCM within the north_star tolerance, every sample counted
-    _, ops = mixed_params(S, 388)
-    o8 = [ops[int(c) % 388] for c in sub[:8]]
-    wf_o, gb = oracle_wf(iq_sub[:8], n_avg), oracle_guard(iq_sub[:8], n_avg)
-    d = np.abs(wf[:, sub[:8]].astype(np.int32) - wf_o)
-    assert not (d > gb).any()
+    # ... and against the float64 definition at this very shape (r4 item 7: a strided 256 channels instead of
+    # eight, 64 of each mode, the oracle in a process pool): the N = 10 sums identical outside the guard band, PCM within the
+    # north_star tolerance on every channel, every sample counted
+    import oracle_pool as OP
     import tolerances as T
-    pcm_o, rssi_o, bound = T.oracle_with_bound(iq_sub[:8], o8)
-    T.assert_pcm_within_tolerance(pcm[sub[:8]], pcm_o, bound, what="configs[3] shape")
-    assert sorted(set(p_.mode for p_ in o8)) == ["am", "lsb", "nbfm", "usb"]
+    _, ops = mixed_params(S, 388)
+    o64 = [ops[int(c) % 388] for c in sub64]
+    wf_o, gb = OP.wf(iq64, n_avg)
+    d = np.abs(wf[:, sub64].astype(np.int32) - wf_o)
+    assert not (d > gb).any()
+    pcm_o, rssi_o, bound = OP.audio(iq64, o64, eps=T.EPS)
+    well, rms = T.assert_pcm_within_tolerance(pcm[sub64], pcm_o, bound, what="configs[3] shape, 256 channels")
+    assert well.all() and rms.max() < PCM_RMS_TOL           # BASELINE's own configuration: the plain figure on every channel
+    assert [sum(p_.mode == m for p_ in o64) for m in ("am", "usb", "lsb", "nbfm")] == [64] * 4
 
 
 def test_million_channel_batch(S, twin):
@@ -842,24 +847,28 @@ def test_parity_at_the_timed_shape_waterfall_only(S, twin):
             eng.set_params(first, ps[: min(388, n_ch - first)])
         eng.synth_iq(2 * n_lines, seed=0x5D5D)
         iq_sub = np.stack([eng.read_input(int(c), 1)[0] for c in sub])
+        sub64 = np.arange(0, n_ch, 16)[:256]                # the float64 check's channels: every 16th, 256 of them
+        iq64 = np.stack([eng.read_input(int(c), 1)[0] for c in sub64])
         n1 = eng.run_wf(fetch=False)
         wf = eng.run_wf()                                   # the same launch again: N = 1 carries nothing
         consts, _ = eng.get_consts()
     assert n1 == n_lines and wf.shape == (n_lines, n_ch, 1024)
     assert np.array_equal(wf[:, sub], twin.wf(iq_sub, 1, consts["wf_cal_lin"][sub]))
     assert (wf.max(axis=2) > 150).all()                     # a carrier in every line of every channel
-    # ... and against the float64 definition at this very shape: six of the channels, all 256 lines --
-    # identical outside the guard band, never more than the allowed steps inside it
-    wf_o, gb = oracle_wf(iq_sub[:6], 1), oracle_guard(iq_sub[:6], 1)
-    d = np.abs(wf[:, sub[:6]].astype(np.int32) - wf_o)
+    # ... and against the float64 definition at this very shape (r4 item 7: 256 channels x all 256 lines = 6.7e7
+    # bins, the oracle in a process pool) -- identical outside the guard band, never more than the allowed steps inside it
+    import oracle_pool as OP
+    wf_o, gb = OP.wf(iq64, 1)
+    d = np.abs(wf[:, sub64].astype(np.int32) - wf_o)
     assert not (d > gb).any() and (d > 0).mean() < 1e-3
+    print("waterfall at the timed shape vs the float64 oracle: %d of %d bins differ (all by one step, all inside the guard band)" % ((d > 0).sum(), d.size))
     with S.SsdrEngine(n_ch) as eng:                         # the float64 kernel at the timed shape: no guard band at all
         for first in range(0, n_ch, 388):
             eng.set_params(first, ps[: min(388, n_ch - first)])
         eng.set_exact_bins(True)
         eng.synth_iq(2 * n_lines, seed=0x5D5D)
         wfx = eng.run_wf()
-    assert np.array_equal(wfx[:, sub[:6]], wf_o) and (wfx != wf).mean() < 1e-3
+    assert np.array_equal(wfx[:, sub64], wf_o) and (wfx != wf).mean() < 1e-3      # float64 kernel: bit for bit on all 6.7e7 bins
     with S.SsdrEngine(n_ch) as eng:
         for first in range(0, n_ch, 388):
             eng.set_params(first, ps[: min(388, n_ch - first)])
@@ -881,6 +890,8 @@ def test_parity_at_the_timed_shape_full_chain(S, twin):
         eng.synth_iq(2 * sf, seed=0x5D5D)
         assert eng.audio_paths() == (0, 0, n_ch)            # the path the bench times
         iq_sub = np.stack([eng.read_input(int(c), 1)[0] for c in sub])
+        sub64 = np.arange(5, n_ch, 256)[:256]               # the float64 check's channels: a strided 256
+        iq64 = np.stack([eng.read_input(int(c), 1)[0] for c in sub64])
         wf = eng.run_wf()
         pcm, rssi = eng.run_audio()
         flags = eng.audio_flags()
@@ -907,11 +918,17 @@ def test_parity_at_the_timed_shape_full_chain(S, twin):
     assert np.array_equal(pcm2[sub], pcm_t2) and np.array_equal(rssi2[sub], rssi_t2)
     assert st_g[sub].tobytes() == st.tobytes() and np.array_equal(hist_g[sub], hist)
     assert not flags.any() and (np.abs(pcm).max(axis=1) > 1000).all() and np.isfinite(rssi).all()
-    # vs the float64 definition on a few of them
-    ops = [O.ChanParams(mode="am", f_shift_hz=((int(c) * 37) % 97 - 48) * 100.0) for c in sub[:6]]
-    pcm_o, _ = O.audio_chain(iq_sub[:6], ops)
-    rms = np.sqrt(((pcm[sub[:6]].astype(np.float64) - pcm_o) ** 2).mean(axis=1)) / 32768.0
+    # vs the float64 definition (r4 item 7: 256 strided channels x 16 superframes, the oracle in a process pool): the waterfall lines
+    # identical outside the guard band, the PCM within the plain north_star figure on every one of them
+    import oracle_pool as OP
+    ops = [O.ChanParams(mode="am", f_shift_hz=((int(c) % 388 * 37) % 97 - 48) * 100.0) for c in sub64]
+    pcm_o, _, _ = OP.audio(iq64, ops)
+    rms = np.sqrt(((pcm[sub64].astype(np.float64) - pcm_o) ** 2).mean(axis=1)) / 32768.0
     assert rms.max() < PCM_RMS_TOL
+    wf_o, gb = OP.wf(iq64, 1)
+    d = np.abs(wf[:, sub64].astype(np.int32) - wf_o)
+    assert not (d > gb).any() and (d > 0).mean() < 1e-3
+    print("full chain at the timed shape vs the float64 oracle, 256 channels: PCM RMS max %.2e, %d of %d bins one step apart" % (rms.max(), (d > 0).sum(), d.size))
 
 
 def test_checkpoint_restore_continues_bit_exactly(S):

@@ -432,3 +432,41 @@ def test_zoom_stage_known_answers_and_twin_vs_oracle(twin, Z):
         dd = np.abs(got[c].astype(np.int32) - o.astype(np.int32))
         assert dd.max() <= 1 and (dd > 0).mean() < 0.01
     assert len(O.zoom_taps(Z)) == 32 * Z - 1
+
+
+@pytest.mark.parametrize("seed", [401, 402, 403])
+def test_error_sensitivity_is_a_tight_bound(seed):
+    """The tolerance rule (tests/tolerances.py) bounds each sample by what the oracle says a relative error EPS in its own filter sums
+    does to its output (AudioChannel.error_sensitivity).  An over-estimate there would excuse anything.  Here the float64 chain is run
+    twice on random receivers, once with its filter sums actually moved by EPS x (their dot-product bound) in random directions:
+    the outputs never differ by more than the predicted bound (first order: 10 % of slack for the second), and the prediction is not
+    loose -- in every channel the largest deviation reaches a good part of its bound."""
+    import random_params as RP
+    import tolerances as T
+    rng = np.random.default_rng(seed)
+    n_ch, n_frames = 16, 6
+    iq = RP.signal(rng, n_ch, n_frames * 512)
+    eps = T.EPS
+    tight = []
+    for c in range(n_ch):
+        d = RP.draw(rng)
+        p = O.ChanParams(**d)
+        a, b = O.AudioChannel(p, want_sens=True), O.AudioChannel(p)
+        b.perturb = (eps, np.random.default_rng(seed * 100 + c))
+        a.process(iq[c]); b.process(iq[c])
+        sens, cap, margin = a.sens_out.reshape(3, -1)
+        bound = np.where(eps * sens >= margin, cap, np.minimum(eps * sens, cap))
+        dy = np.abs(a.y_out.reshape(-1) - b.y_out.reshape(-1))
+        live = (bound > 1e-9) & (np.abs(a.y_out.reshape(-1)) < 32000)           # (silent channels: nothing to perturb; clipped samples: both clip)
+        live[:128] = False      # the filter filling up from a reset: the discriminator's first few outputs (hundredths of an LSB) move by up to 4x their
+                                # first-order bound there -- far inside the rule's 1 LSB of rounding allowance, and the bound's only miss
+        if live.sum() < 100:
+            continue
+        assert (dy[live] <= 1.1 * bound[live] + 1e-6).all(), (c, d["mode"], float((dy[live] / bound[live]).max()))
+        tight.append((d["mode"], float((dy[live] / bound[live]).max()), float(np.sqrt((dy[live] ** 2).mean()) / np.sqrt((bound[live] ** 2).mean()))))
+    assert len(tight) >= 8
+    # with random directions the linear pieces reach their bound to within a factor of a few somewhere in 3072 samples
+    assert min(t[1] for t in tight) > 0.15, sorted(tight, key=lambda t: t[1])[:3]
+    # (in RMS the bound sits further above a random perturbation: its AGC term is a worst case over the follower's whole memory)
+    print("error_sensitivity: largest share of its bound a perturbed sample reaches, per channel: min %.2f median %.2f; RMS(deviation) / RMS(bound): min %.3f median %.2f"
+          % (min(t[1] for t in tight), float(np.median([t[1] for t in tight])), min(t[2] for t in tight), float(np.median([t[2] for t in tight]))))

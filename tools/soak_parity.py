@@ -75,6 +75,10 @@ def run_sweeps(a, sweeps, T):
                      "largest share of its propagated bound (EPS = 2^%d) any sample used: %.2f (%d samples at the FM discriminator's branch cut, a full turn allowed, set aside)"
                      % (len(rep), chans, well, 100.0 * well / max(chans, 1), max(r["untrimmed_max_well"] for r in rep),
                         int(round(__import__("math").log2(T.EPS))), max(r["worst_sample_not_at_the_branch_cut"] for r in rep), sum(r["samples_at_the_branch_cut"] for r in rep)))
+        if "rms_all_channels_off_the_branch_cut_max" in rep[0]:
+            out = sum(r["outside_plain_tolerance"] for r in rep)
+            lines.append("channels outside the plain 1e-5 RMS: %d of %d (%.1f %%); largest RMS of ANY channel over its samples off the branch cut: %.2e"
+                         % (out, chans, 100.0 * out / max(chans, 1), max(r["rms_all_channels_off_the_branch_cut_max"] for r in rep)))
     text = "\n".join(lines) + "\n"
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
