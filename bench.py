@@ -957,7 +957,8 @@ def main():
         # the product's own ingest API in front of the pipelined feed (PCIe-inclusive, never `value`)
         if args.host_feed_extra:
             def hub_extra():
-                extra["hub_feed"] = {k: measure_hub(S, L, torch, local_rank, 65536, 16, 2, in_place=ip, copy_threads=ct, lazy_out=lo)
+                # (6 "steps" = 24 GPU runs of 4 superframes each: the 8 runs of rounds 3-4 were mostly the copy pool's first touches)
+                extra["hub_feed"] = {k: measure_hub(S, L, torch, local_rank, 65536, 16, 6, in_place=ip, copy_threads=ct, lazy_out=lo)
                                      for k, ip, ct, lo in (("feed_block", False, 0, False), ("feed_block_8_threads", False, 8, False), ("in_place", True, 0, False),
                                                            ("feed_block_8_threads_lazy_out", False, 8, True), ("in_place_lazy_out", True, 0, True))}
             guarded("hub_feed", hub_extra)
