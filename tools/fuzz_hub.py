@@ -39,7 +39,8 @@ def one_sequence(S, IQHub, seed, steps):
     lazy = bool(rng.random() < 0.5)
     K = int(rng.choice([1, 1, 2]))
     kw = dict(gpu_post=post, lazy=lazy, max_queue=1 << 14, backlog_superframes=8 * K, stall_superframes=3 * K, batch_superframes=K)
-    hubs = [IQHub(n, **kw), IQHub(n, pipeline=True, depth=int(rng.choice([2, 3, 4])), **kw)]
+    # (round 5: on a lazy hub the pipelined side copies back the listeners' rows only, every other time -- SSDR_FEED_LAZY_OUT)
+    hubs = [IQHub(n, **kw), IQHub(n, pipeline=True, depth=int(rng.choice([2, 3, 4])), lazy_out=bool(lazy and rng.random() < 0.5), **kw)]
     listeners = sorted(set(int(c) for c in rng.integers(0, n, max(1, n // 3))))
     compared = 0
     try:
