@@ -8,6 +8,11 @@
 // KIND 3: v_fma_f32, ONE dependent chain                            1 wave  / SIMD  -> latency-bound, ALU mostly idle
 // KIND 4: v_fma_f32 only                                            1 wave  / SIMD
 // KIND 5: 1 v_fma_f32 per 3 s_nop 0                                 4 waves / SIMD  -> a quarter of the issue slots
+// KIND 6: v_pk_fma_f32 only (slow class, two lane-operations)        4 waves / SIMD
+// KIND 7: alternating v_pk_fma_f32 / v_fma_f32                       4 waves / SIMD  -> do packed and scalar FMAs share quad-cycles?
+// KIND 8: alternating v_max_f32_dpp row_shr:1 (+ s_nop 1) / v_fma_f32
+// KIND 9: alternating v_cvt_f32_i32 / v_perm_b32 (slow / slow)
+// KIND 10: alternating v_sqrt_f32 / v_fma_f32 (transcendental / fast)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define REP 64
@@ -16,8 +21,10 @@
 template <int KIND>
 __global__ void calib(float *out, int iters)
 {
+    typedef float f2 __attribute__((ext_vector_type(2)));
     float a[8], b = 1.0001f, c = 0.5f;
-    for (int i = 0; i < 8; i++) a[i] = (float)threadIdx.x + i;
+    f2 pk[8], pb = {1.0001f, 0.9999f}, pc = {0.5f, 0.25f};
+    for (int i = 0; i < 8; i++) { a[i] = (float)threadIdx.x + i; pk[i] = f2{(float)i, (float)threadIdx.x}; }
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int r = 0; r < REP / 8; r++) {
@@ -28,11 +35,16 @@ __global__ void calib(float *out, int iters)
                 if (KIND == 2) { if (i & 1) asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(a[i])); else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c)); }
                 if (KIND == 3) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[0]) : "v"(b), "v"(c));
                 if (KIND == 5) asm volatile("v_fma_f32 %0, %1, %2, %0\n s_nop 0\n s_nop 0\n s_nop 0" : "+v"(a[i]) : "v"(b), "v"(c));
+                if (KIND == 6) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(pk[i]) : "v"(pb), "v"(pc));
+                if (KIND == 7) { if (i & 1) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(pk[i]) : "v"(pb), "v"(pc)); else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c)); }
+                if (KIND == 8) { if (i & 1) asm volatile("s_nop 1\n v_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a[i])); else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c)); }
+                if (KIND == 9) { if (i & 1) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c)); else asm volatile("v_cvt_f32_i32 %0, %0" : "+v"(a[i])); }
+                if (KIND == 10) { if (i & 1) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i])); else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(b), "v"(c)); }
             }
         }
     }
     float s = 0;
-    for (int i = 0; i < 8; i++) s += a[i];
+    for (int i = 0; i < 8; i++) s += a[i] + pk[i].x + pk[i].y;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -62,5 +74,10 @@ int main()
     run<3>("v_fma_f32 one dependent chain", d, 1);
     run<4>("v_fma_f32 x8 chains", d, 1);
     run<5>("v_fma_f32 + 3 s_nop", d, 4);
+    run<6>("v_pk_fma_f32", d, 4);
+    run<7>("v_pk_fma_f32 / v_fma_f32 alternating", d, 4);
+    run<8>("v_max_f32_dpp / v_fma_f32 alternating", d, 4);
+    run<9>("v_cvt_f32_i32 / v_perm_b32 alternating", d, 4);
+    run<10>("v_sqrt_f32 / v_fma_f32 alternating", d, 4);
     return 0;
 }
