@@ -21,10 +21,15 @@
 //       The FFT's transposes take the first 8448 B of the work area once both lines are in registers.
 //       Behind the work area: 2 x 256 B filter history (the last 32 mixed samples of each general channel's previous line) and
 //       2 x 28 words of carried state (phases, DC, AGC follower, discriminator memory, the shift paths' 4-sample tails).
-//   * registers: nothing of the audio chain lives across the FFT except one RSSI / flag keeper per slot.  The per-lane NCO constants
+//   * registers: nothing of the audio chain lives across the FFT, and nothing of the FFT across the audio chain.  The per-lane NCO constants
 //     P(8 l dphi) and the line's two frame phasors are re-evaluated per line (two polynomials per oscillator: the same arguments, hence
 //     the same bits, as the stand-alone kernel's per-call / per-64-frames tables); the carried state comes back from the LDS through
-//     v_readfirstlane (wave-uniform, so it sits in scalar registers as in the stand-alone kernels).
+//     v_readfirstlane (wave-uniform, so it sits in scalar registers as in the stand-alone kernels); the per-frame RSSI sums and flags go
+//     straight to their output rows and are converted to dBm once per call; with N > 1 the N-line sums rest in 4 KB of global memory per
+//     wave while the audio chain runs; the kernel's arguments are re-read from the kernarg segment per phase.
+//   * MEASURED (profiles/r05_ab_fused_general.txt): bit-identical to the two kernels and 45 % slower than running them side by side --
+//     the register and LDS squeeze costs +21 % instructions, 31-36 spilled registers and more memory traffic than the second read saves.
+//     Opt-in: ssdr_set_fused(ctx, 3).
 //   * channel filters of up to 33 taps (4 history octets: every passband of the reference's mode table except CW; a ctx with a longer
 //     filter runs the two kernels); SSDR_MODE_IQ channels (a second output row) likewise.
 #include "ssdr_math.h"
@@ -149,8 +154,6 @@ struct LineCtx {                                // what the audio phase of one s
     bool last_line;
 };
 
-// The audio chain of one channel for the two frames of a line.  PATH as in ssdr_audio.hip:channel_frames, whose per-frame code this
-// is, statement for statement, with the carried state handed in and out.
 // Per-frame RSSI and ADC-overflow flag without a per-lane keeper that would have to live across the FFT: lane 0 leaves the frame's power
 // sum (the same scan, the same order) and the flag in the output rows; the conversion to dBm runs once per call (rssi_finish).
 SSDR_DEV void rssi_flag_raw(const float (&p)[8], bool clip, uint32_t f, int l, float *rssi_row, uint8_t *flag_row)
@@ -175,6 +178,8 @@ SSDR_DEV void rssi_finish(float *rssi_row, uint32_t n_frames, float cal, int l)
     }
 }
 
+// The audio chain of one channel for the two frames of a line.  PATH as in ssdr_audio.hip:channel_frames, whose per-frame code this
+// is, statement for statement, with the carried state handed in and out.
 template <int PATH>
 SSDR_DEV void audio_line(const SsdrAudioArgs &u, const LineCtx &x, Slot &s, const ssdr_chan_consts &kc, const int l)
 {
@@ -192,7 +197,7 @@ SSDR_DEV void audio_line(const SsdrAudioArgs &u, const LineCtx &x, Slot &s, cons
         if (ssb) nco_line(n2, dphi2, s.phi2, s.cs2, s.ss2, l);
     }
     if (PATH == PATH_GENERAL) {
-        // the channel's taps into the work area's padding (lane k: tap k; 4 (HMAX + 1) = 40 >= ntap + 7 of them), the FIR reads them back as
+        // the channel's taps into the work area's padding (lane k: tap k; 8 (HMAX + 1) = 40 >= ntap + 7 of them), the FIR reads them back as
         // broadcasts; and the previous line's last HMAX octets in front of the frame
         if (l < 8 * (HMAX + 1)) *reinterpret_cast<float *>(x.S + s_tap_addr(l >> 2) + 4 * (l & 3)) = u.taps[(size_t)x.cc * SSDR_NTAP_MAX + l];
         if (l < HMAX) {
