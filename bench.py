@@ -608,6 +608,38 @@ def csrc_sha256():
     return h.hexdigest()[:16]
 
 
+def measure_ui_hub(S, local_rank, receivers=2, superframes=60):
+    """The reference's own scale (README.md:8 "dozens of instances"; one kiwi_waterfall + kiwi_sound pair per receiver): a synchronous IQHub of a
+    few receivers with spectrum_db2col / play_buffer on the GPU and a bound worker pair on each -- what ONE superframe (85.3 ms of signal) costs
+    from the ingest call to the workers' queues, i.e. the latency this path adds in front of the UI.  Not a throughput figure."""
+    from supersdr_amd.workers import IQHub, bind_headless
+    mod = bind_headless()
+
+    class Disp:
+        DISPLAY_WIDTH, WF_HEIGHT = 1024, 8
+
+    hub = IQHub(receivers, device=local_rank)
+    wfs = [mod.kiwi_waterfall("gpu", 0, "", 8, 7100.0, None, Disp(), hub=hub, channel=c, timeout=1.0) for c in range(receivers)]
+    snds = [mod.kiwi_sound(7100.0, "USB", 30, 3000, "", w, 8) for w in wfs]
+    rng = np.random.default_rng(1)
+    iq = rng.integers(-8000, 8000, (receivers, 1024, 2)).astype(np.int16)
+    for _ in range(5):
+        hub.feed_block(0, iq)
+    ts = []
+    for _ in range(superframes):
+        t0 = time.perf_counter()
+        hub.feed_block(0, iq)                                    # synchronous hub: returns when the results are in the workers' queues
+        for w, s_ in zip(wfs, snds):
+            w.step()                                             # kiwi_waterfall.run's body for one line: receive_spectrum + spectrum_db2col + scroll
+            s_.process_audio_stream(); s_.process_audio_stream()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    hub.close()
+    ts.sort()
+    return {"receivers": receivers, "superframes": superframes, "ms_per_superframe_median": ts[len(ts) // 2], "ms_per_superframe_max": ts[-1],
+            "real_time_ms": 1024 / 12.0, "what": "IQHub.feed_block -> waterfall + db2col + audio + play_buffer kernels -> bound kiwi_waterfall / kiwi_sound "
+            "workers consume the line and both frames (synchronous hub, %d receivers)" % receivers}
+
+
 def pmc_traffic(workload, channels, sframes, hop=1024):
     """HBM bytes per launch from the PMC passes committed under profiles/ (collected with rocprofv3 in separate
     runs, corrected as MI355X_MICROARCH.md prescribes; tools/profile_round.sh + tools/traffic_json.py).
@@ -954,6 +986,8 @@ def main():
                              "rooflines": [note("post." + k, v) for k, v in post.items()],
                              "reference_cpu": {v["kernel"]: v["reference_cpu"] for v in post.values() if "reference_cpu" in v}}
         guarded("post", post_extra)
+        # the reference's own scale: a two-receiver UI hub, latency per superframe
+        guarded("ui_hub", lambda: extra.__setitem__("ui_hub", measure_ui_hub(S, local_rank)))
         # the product's own ingest API in front of the pipelined feed (PCIe-inclusive, never `value`)
         if args.host_feed_extra:
             def hub_extra():
@@ -1037,6 +1071,8 @@ def compact_line(full):
                 out["extra"][k] = {"error": v["error"]}
             elif "value" in v:
                 out["extra"][k] = {kk: (round(v[kk], 4) if isinstance(v[kk], float) else v[kk]) for kk in ("value", "ms_per_step", "chain_frac") if kk in v}
+            elif k == "ui_hub":
+                out["extra"][k] = {kk: (round(v[kk], 3) if isinstance(v[kk], float) else v[kk]) for kk in ("receivers", "ms_per_superframe_median", "ms_per_superframe_max", "real_time_ms")}
             elif k == "hub_feed":
                 out["extra"][k] = {kk: {"value": vv["value"], "ms_per_superframe": round(vv["ms_per_superframe"], 3),
                                         "d2h_bytes_per_channel_superframe": vv.get("d2h_bytes_per_channel_superframe")} for kk, vv in v.items()}
