@@ -64,6 +64,7 @@ class ChanState(C.Structure):
 assert C.sizeof(ChanConsts) == 64 and C.sizeof(ChanState) == 64 and C.sizeof(ChanParams) == 88
 assert C.sizeof(Db2colChan) == 48 and C.sizeof(PlayChan) == 16
 WIRE_BODY = 17 + FRAME * 4
+FEED_LAZY_MAX = 4096        # SSDR_FEED_LAZY_MAX (include/ssdr.h): rows a SSDR_FEED_LAZY_OUT feed copies back per batch
 
 _P = C.c_void_p
 _SIGS = {

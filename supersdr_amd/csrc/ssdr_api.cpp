@@ -1,6 +1,6 @@
 // ssdr_api.cpp -- C-ABI of libssdr.so (see include/ssdr.h).  Host side only: owns the
 // device buffers, the per-channel state and the stream; launches the HIP kernels.
-// Never throws, never aborts: every failure is a negative return code.
+// Never throws, never aborts: every failure is a negative return code (SSDR_GUARD / SSDR_UNGUARD below).
 #include "ssdr_kernels.h"
 #include "ssdr_resample_taps.h"
 #include <algorithm>
@@ -22,6 +22,19 @@ static thread_local char g_hip_err[256] = "";
             return e_ == hipErrorOutOfMemory ? SSDR_ENOMEM : SSDR_EHIP;                 \
         }                                                                               \
     } while (0)
+
+// "Never throws": every `int` entry point is a function-try-block.  A host allocation that fails (std::vector, std::bad_alloc)
+// or anything else thrown below the C boundary comes back as a return code, like the reference's own policy of turning errors into
+// a flag the caller polls (utils_supersdr.py:1031-1036) -- the maintainer's process is never terminated from inside the library.
+static int ssdr_caught(bool nomem) noexcept
+{
+    snprintf(g_hip_err, sizeof g_hip_err, nomem ? "host allocation failed (std::bad_alloc)" : "C++ exception below the C boundary");
+    return nomem ? SSDR_ENOMEM : SSDR_EHIP;
+}
+#define SSDR_GUARD try
+#define SSDR_UNGUARD                                               \
+    catch (const std::bad_alloc &) { return ssdr_caught(true); }   \
+    catch (...) { return ssdr_caught(false); }
 
 struct ssdr_ctx {
     int device = 0;
@@ -272,7 +285,7 @@ void ssdr_destroy(ssdr_ctx *c)
     delete c;
 }
 
-int ssdr_default_params(int mode, ssdr_chan_params *p)
+int ssdr_default_params(int mode, ssdr_chan_params *p) SSDR_GUARD
 {
     if (!p || mode < SSDR_MODE_AM || mode > SSDR_MODE_IQ) return SSDR_EINVAL;
     memset(p, 0, sizeof *p);
@@ -294,14 +307,14 @@ int ssdr_default_params(int mode, ssdr_chan_params *p)
     default: p->low_cut = -6000.0; p->high_cut = 6000.0; break;
     }
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_compile_params(const ssdr_chan_params *p, ssdr_chan_consts *consts, float *taps)
+int ssdr_compile_params(const ssdr_chan_params *p, ssdr_chan_consts *consts, float *taps) SSDR_GUARD
 {
     return ssdr_compile_params_host(p, consts, taps, 1);
-}
+} SSDR_UNGUARD
 
-int ssdr_table(int which, float *out, uint32_t n)
+int ssdr_table(int which, float *out, uint32_t n) SSDR_GUARD
 {
     if (!out) return SSDR_EINVAL;
     float wr[512], wi[512];
@@ -322,13 +335,13 @@ int ssdr_table(int which, float *out, uint32_t n)
         return SSDR_OK;
     default: return SSDR_EINVAL;
     }
-}
+} SSDR_UNGUARD
 
 static int zoom_restart(ssdr_ctx *c, uint32_t first, uint32_t count, bool restart_group = true);
 static int join_audio(ssdr_ctx *c);
 static int drain_audio(ssdr_ctx *c);
 
-int ssdr_reset_state(ssdr_ctx *c, uint32_t first, uint32_t count)
+int ssdr_reset_state(ssdr_ctx *c, uint32_t first, uint32_t count) SSDR_GUARD
 {
     if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     if (!count) return SSDR_OK;
@@ -352,9 +365,9 @@ int ssdr_reset_state(ssdr_ctx *c, uint32_t first, uint32_t count)
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (first == 0 && count == c->n_ch) { c->wf_phase = 0; c->synth_sample0 = 0; c->audio_started = false; }
     return zoom_restart(c, first, count, false);         // the zoomed streams of these channels start over as well
-}
+} SSDR_UNGUARD
 
-int ssdr_set_params(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan_params *p)
+int ssdr_set_params(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan_params *p) SSDR_GUARD
 {
     if (!c || !p || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     if (!count) return SSDR_OK;
@@ -385,9 +398,9 @@ int ssdr_set_params(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan
     }
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t frame, ssdr_ctx **out)
+int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t frame, ssdr_ctx **out) SSDR_GUARD
 {
     if (!out) return SSDR_EINVAL;
     *out = nullptr;
@@ -402,6 +415,7 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
     c->device = device_id;
     c->n_ch = n_channels;
     c->n_post = n_channels;
+    struct Owner { ssdr_ctx *c; ~Owner() { if (c) ssdr_destroy(c); } } owner{c};     // an error return or an exception below frees the half-built ctx
     int rc = [&]() -> int {
         HIP_TRY(hipSetDevice(device_id));
         HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -465,12 +479,13 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         rc = ssdr_set_params(c, 0, n_channels, all.data());
     }
     if (rc == SSDR_OK) rc = ssdr_reset_state(c, 0, n_channels);
-    if (rc != SSDR_OK) { ssdr_destroy(c); return rc; }
+    if (rc != SSDR_OK) return rc;
+    owner.c = nullptr;
     *out = c;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_averaging(ssdr_ctx *c, uint32_t n)
+int ssdr_set_averaging(ssdr_ctx *c, uint32_t n) SSDR_GUARD
 {
     if (!c || n < 1 || n > 100) return SSDR_EINVAL;      // supersdr.py:376-385: averaging_n in 1..100
     if (n != c->n_avg) {
@@ -481,36 +496,42 @@ int ssdr_set_averaging(ssdr_ctx *c, uint32_t n)
         c->n_avg = n;
     }
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_compile_params_decim(const ssdr_chan_params *p, uint32_t decim, ssdr_chan_consts *consts, float *taps)
+int ssdr_compile_params_decim(const ssdr_chan_params *p, uint32_t decim, ssdr_chan_consts *consts, float *taps) SSDR_GUARD
 {
     return ssdr_compile_params_host(p, consts, taps, decim);
-}
+} SSDR_UNGUARD
 
-int ssdr_compile_params_rate(const ssdr_chan_params *p, uint32_t decim, uint32_t rate, ssdr_chan_consts *consts, float *taps)
+int ssdr_compile_params_rate(const ssdr_chan_params *p, uint32_t decim, uint32_t rate, ssdr_chan_consts *consts, float *taps) SSDR_GUARD
 {
     return ssdr_compile_params_host(p, consts, taps, decim, rate);
-}
+} SSDR_UNGUARD
 
-int ssdr_set_decimation(ssdr_ctx *c, uint32_t decim)
+int ssdr_set_decimation(ssdr_ctx *c, uint32_t decim) SSDR_GUARD
 {
     if (!c || (decim != 1 && decim != 2 && decim != 4)) return SSDR_EINVAL;
     if (!c->feed.empty()) return SSDR_ESTATE;
     if (decim == c->decim) return SSDR_OK;
     HIP_TRY(hipSetDevice(c->device));
+    std::vector<ssdr_chan_params> all = c->h_params;              // recompile every channel for the new input rate
     const uint32_t keep = c->decim;
     c->decim = decim;
-    std::vector<ssdr_chan_params> all = c->h_params;              // recompile every channel for the new input rate
     int rc = ssdr_set_params(c, 0, c->n_ch, all.data());
-    if (rc != SSDR_OK) { c->decim = keep; (void)ssdr_set_params(c, 0, c->n_ch, all.data()); return rc; }
-    c->have_input = false;                                        // a batch pushed at the old rate has the wrong extent
-    rc = ssdr_reset_state(c, 0, c->n_ch);                         // phases and histories of the old rate mean nothing now
-    if (rc == SSDR_OK) rc = zoom_restart(c, 0, c->n_ch);
+    if (rc == SSDR_OK) {
+        c->have_input = false;                                    // a batch pushed at the old rate has the wrong extent
+        rc = ssdr_reset_state(c, 0, c->n_ch);                     // phases and histories of the old rate mean nothing now
+        if (rc == SSDR_OK) rc = zoom_restart(c, 0, c->n_ch);
+    }
+    if (rc != SSDR_OK) {                                          // all or nothing: back to the old rate, streams restarted
+        c->decim = keep;
+        (void)ssdr_set_params(c, 0, c->n_ch, all.data());
+        (void)ssdr_reset_state(c, 0, c->n_ch);
+    }
     return rc;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_hop(ssdr_ctx *c, uint32_t hop)
+int ssdr_set_hop(ssdr_ctx *c, uint32_t hop) SSDR_GUARD
 {
     if (!c || (hop != SSDR_NFFT && hop != SSDR_NFFT / 2)) return SSDR_EINVAL;
     if (!c->feed.empty()) return SSDR_ESTATE;                 // the feed's slots are sized for the hop they were opened with
@@ -524,7 +545,7 @@ int ssdr_set_hop(ssdr_ctx *c, uint32_t hop)
     c->hop = hop;
     c->wf_phase = 0;                                          // a change of framing restarts the averaging group
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
 // the zoom centres as NCO steps at the current input rate; the zoom streams restart (phase, history, averaging group)
 static int zoom_restart(ssdr_ctx *c, uint32_t first, uint32_t count, bool restart_group)
@@ -548,7 +569,7 @@ static int zoom_restart(ssdr_ctx *c, uint32_t first, uint32_t count, bool restar
     return SSDR_OK;
 }
 
-int ssdr_set_wf_zoom(ssdr_ctx *c, uint32_t zoom)
+int ssdr_set_wf_zoom(ssdr_ctx *c, uint32_t zoom) SSDR_GUARD
 {
     if (!c || (zoom != 1 && zoom != 2 && zoom != 4 && zoom != 8)) return SSDR_EINVAL;
     if (!c->feed.empty()) return SSDR_ESTATE;              // the feed's slots are sized for un-zoomed lines
@@ -580,9 +601,9 @@ int ssdr_set_wf_zoom(ssdr_ctx *c, uint32_t zoom)
         return zoom_restart(c, 0, c->n_ch);
     }
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_wf_center(ssdr_ctx *c, uint32_t first, uint32_t count, const double *offset_hz)
+int ssdr_set_wf_center(ssdr_ctx *c, uint32_t first, uint32_t count, const double *offset_hz) SSDR_GUARD
 {
     if (!c || !offset_hz || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     const double half = 0.5 * (double)c->kiwi_rate * c->decim;
@@ -592,9 +613,9 @@ int ssdr_set_wf_center(ssdr_ctx *c, uint32_t first, uint32_t count, const double
     if (c->h_zoom_offset.size() != c->n_ch) c->h_zoom_offset.assign(c->n_ch, 0.0);
     for (uint32_t i = 0; i < count; i++) c->h_zoom_offset[first + i] = offset_hz[i];
     return zoom_restart(c, first, count);
-}
+} SSDR_UNGUARD
 
-int ssdr_read_zoom(ssdr_ctx *c, uint32_t first, uint32_t count, int16_t *iq_out, uint32_t *samples_per_channel)
+int ssdr_read_zoom(ssdr_ctx *c, uint32_t first, uint32_t count, int16_t *iq_out, uint32_t *samples_per_channel) SSDR_GUARD
 {
     if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     if (c->zoom <= 1 || !c->d_zoom_out || c->zoom_run_samples == 0) return SSDR_ESTATE;
@@ -605,9 +626,9 @@ int ssdr_read_zoom(ssdr_ctx *c, uint32_t first, uint32_t count, int16_t *iq_out,
                            hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_exact_bins(ssdr_ctx *c, int on)
+int ssdr_set_exact_bins(ssdr_ctx *c, int on) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -619,9 +640,9 @@ int ssdr_set_exact_bins(ssdr_ctx *c, int on)
     }
     c->exact_bins = on != 0;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_get_config(ssdr_ctx *c, uint32_t *hop, uint32_t *decim, uint32_t *averaging, uint32_t *kiwi_rate)
+int ssdr_get_config(ssdr_ctx *c, uint32_t *hop, uint32_t *decim, uint32_t *averaging, uint32_t *kiwi_rate) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     if (hop) *hop = c->hop;
@@ -629,16 +650,16 @@ int ssdr_get_config(ssdr_ctx *c, uint32_t *hop, uint32_t *decim, uint32_t *avera
     if (averaging) *averaging = c->n_avg;
     if (kiwi_rate) *kiwi_rate = c->kiwi_rate;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_stream(ssdr_ctx *c, void *hip_stream)
+int ssdr_set_stream(ssdr_ctx *c, void *hip_stream) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_concurrent(ssdr_ctx *c, int on)
+int ssdr_set_concurrent(ssdr_ctx *c, int on) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -648,16 +669,16 @@ int ssdr_set_concurrent(ssdr_ctx *c, int on)
     c->audio_serial = (on & 2) != 0;
     c->audio_pending = false;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_profiling(ssdr_ctx *c, int on)
+int ssdr_set_profiling(ssdr_ctx *c, int on) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     c->profiling = on != 0;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_kernel_stats(ssdr_ctx *c, int which, float *total_ms, uint32_t *launches, int reset)
+int ssdr_kernel_stats(ssdr_ctx *c, int which, float *total_ms, uint32_t *launches, int reset) SSDR_GUARD
 {
     if (!c || which < 0 || which >= SSDR_K_COUNT) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -667,9 +688,9 @@ int ssdr_kernel_stats(ssdr_ctx *c, int which, float *total_ms, uint32_t *launche
     if (launches) *launches = c->k_n[which];
     if (reset) { c->k_ms[which] = 0.0f; c->k_n[which] = 0; }
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_elapsed_ms(ssdr_ctx *c, float *ms)
+int ssdr_elapsed_ms(ssdr_ctx *c, float *ms) SSDR_GUARD
 {
     if (!c || !ms) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -682,16 +703,16 @@ int ssdr_elapsed_ms(ssdr_ctx *c, float *ms)
     HIP_TRY(hipEventSynchronize(c->ev1));
     HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_sync(ssdr_ctx *c)
+int ssdr_sync(ssdr_ctx *c) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (c->concurrent || c->audio_pending) HIP_TRY(hipStreamSynchronize(c->stream2));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
 // An audio stage that ran beside the waterfall kernel (stream2) and has not been joined yet: everything that follows on the
 // main stream and touches what it reads or writes (input, constants, state, PCM, RSSI, flags) waits for it first.
@@ -723,6 +744,26 @@ static void chan_summary(ssdr_ctx *c)
     c->summary_dirty = false;
 }
 
+// channels sorted by audio frame path; rebuilt after ssdr_set_params.  The only host allocation of a run: made before a stage
+// of the call has been launched or any bookkeeping advanced (ssdr_run_chain calls it first), so a failure leaves the streams untouched.
+static int ensure_chan_list(ssdr_ctx *c, hipStream_t s)
+{
+    if (!c->chan_list_dirty) return SSDR_OK;
+    std::vector<uint32_t> list(c->n_ch);
+    uint32_t pos = 0, off[SSDR_PATH_COUNT], cnt[SSDR_PATH_COUNT];
+    for (int p = 0; p < SSDR_PATH_COUNT; p++) {
+        off[p] = pos;
+        for (uint32_t ch = 0; ch < c->n_ch; ch++)
+            if (ssdr_audio_path(c->h_consts[ch]) == p) list[pos++] = ch;
+        cnt[p] = pos - off[p];
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_chan_list, list.data(), (size_t)c->n_ch * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));    // `list` goes out of scope
+    for (int p = 0; p < SSDR_PATH_COUNT; p++) { c->path_off[p] = off[p]; c->path_n[p] = cnt[p]; }
+    c->chan_list_dirty = false;
+    return SSDR_OK;
+}
+
 // input samples (dwords) per channel of a batch of n_frames frames: a frame yields 512 PCM samples and takes 512 * D of IQ
 static inline size_t in_len(const ssdr_ctx *c, uint32_t n_frames) { return (size_t)n_frames * SSDR_FRAME * c->decim; }
 
@@ -738,7 +779,7 @@ static int ensure_input(ssdr_ctx *c, uint32_t n_frames)
     return SSDR_OK;
 }
 
-int ssdr_push_iq(ssdr_ctx *c, const int16_t *iq, uint32_t n_frames, int is_device)
+int ssdr_push_iq(ssdr_ctx *c, const int16_t *iq, uint32_t n_frames, int is_device) SSDR_GUARD
 {
     if (!c || !iq || n_frames == 0) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -754,9 +795,9 @@ int ssdr_push_iq(ssdr_ctx *c, const int16_t *iq, uint32_t n_frames, int is_devic
     c->in_frames = n_frames;
     c->have_input = true;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_synth_iq(ssdr_ctx *c, uint32_t n_frames, uint32_t seed, uint32_t first_channel_id)
+int ssdr_synth_iq(ssdr_ctx *c, uint32_t n_frames, uint32_t seed, uint32_t first_channel_id) SSDR_GUARD
 {
     if (!c || n_frames == 0) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -778,9 +819,9 @@ int ssdr_synth_iq(ssdr_ctx *c, uint32_t n_frames, uint32_t seed, uint32_t first_
     c->in_frames = n_frames;
     c->have_input = true;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_read_input(ssdr_ctx *c, uint32_t first, uint32_t count, int16_t *iq_out)
+int ssdr_read_input(ssdr_ctx *c, uint32_t first, uint32_t count, int16_t *iq_out) SSDR_GUARD
 {
     if (!c || !iq_out || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     if (!c->have_input) return SSDR_ESTATE;
@@ -789,7 +830,7 @@ int ssdr_read_input(ssdr_ctx *c, uint32_t first, uint32_t count, int16_t *iq_out
     HIP_TRY(hipMemcpyAsync(iq_out, c->d_iq + (size_t)first * per_ch, (size_t)count * per_ch * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
 // The shape rules of a waterfall batch, checked before ANY stage of a call is launched (ssdr_run_chain runs its audio stage first
 // when the stages go side by side: a batch the waterfall stage would refuse must not have advanced the audio state by then).
@@ -804,7 +845,7 @@ static int validate_wf_batch(const ssdr_ctx *c)
     return SSDR_OK;
 }
 
-int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out_is_device)
+int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out_is_device) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     if (!c->have_input) return SSDR_ESTATE;
@@ -894,9 +935,9 @@ int ssdr_run_wf(ssdr_ctx *c, int16_t *wf_sum_out, uint32_t *lines_ready, int out
         if (!out_is_device) HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_device)
+int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_device) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     if (!c->have_input) return SSDR_ESTATE;
@@ -959,21 +1000,9 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         HIP_TRY(hipEventRecord(c->ev_in, c->stream));          // everything queued so far, incl. the input copy/synth
         HIP_TRY(hipStreamWaitEvent(s, c->ev_in, 0));
     }
+    { int rcl = ensure_chan_list(c, s); if (rcl != SSDR_OK) return rcl; }
     c->audio_started = true;
     c->audio_run_frames = c->in_frames;
-    if (c->chan_list_dirty) {                // channels sorted by frame path; rebuilt after ssdr_set_params
-        std::vector<uint32_t> list(c->n_ch);
-        uint32_t pos = 0;
-        for (int p = 0; p < SSDR_PATH_COUNT; p++) {
-            c->path_off[p] = pos;
-            for (uint32_t ch = 0; ch < c->n_ch; ch++)
-                if (ssdr_audio_path(c->h_consts[ch]) == p) list[pos++] = ch;
-            c->path_n[p] = pos - c->path_off[p];
-        }
-        HIP_TRY(hipMemcpyAsync(c->d_chan_list, list.data(), (size_t)c->n_ch * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-        HIP_TRY(hipStreamSynchronize(s));    // `list` goes out of scope
-        c->chan_list_dirty = false;
-    }
     if (c->fuse_next) {                      // waterfall + full-band AM audio in one kernel: one read of the input
         SsdrFusedArgs fa;
         fa.wf = c->fused_wf;
@@ -1041,9 +1070,9 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         c->audio_pending = true;
     }
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
+int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     if (!c->have_input) return SSDR_ESTATE;
@@ -1073,6 +1102,10 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
             chan_summary(c);
             if (c->sum_paths[SSDR_PATH_DELAY4] || c->sum_paths[SSDR_PATH_AM_RAW]) rcv = SSDR_ESTATE;
         }
+        if (rcv == SSDR_OK && c->chan_list_dirty) {      // (the previous call's audio stage may still be reading the list)
+            rcv = [&]() -> int { HIP_TRY(hipSetDevice(c->device)); return join_audio(c); }();
+            if (rcv == SSDR_OK) rcv = ensure_chan_list(c, c->stream);
+        }
         if (rcv != SSDR_OK) { c->fuse_next = false; c->fuse_gen_next = false; if (fused) *fused = 0; return rcv; }
     }
     // Everything else: the two stages side by side -- the audio stage on a second stream beside the waterfall kernel (one workgroup
@@ -1096,31 +1129,31 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused)
     c->fuse_next = false;
     c->fuse_gen_next = false;
     return rc;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_fused(ssdr_ctx *c, int on)
+int ssdr_set_fused(ssdr_ctx *c, int on) SSDR_GUARD
 {
     if (!c || on < 0 || on > 3) return SSDR_EINVAL;
     c->fused_enabled = on;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_overlap(ssdr_ctx *c, int on)
+int ssdr_set_overlap(ssdr_ctx *c, int on) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     c->overlap_enabled = on != 0;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_audio_paths(ssdr_ctx *c, uint32_t counts[3])
+int ssdr_audio_paths(ssdr_ctx *c, uint32_t counts[3]) SSDR_GUARD
 {
     if (!c || !counts) return SSDR_EINVAL;
     chan_summary(c);
     for (int p = 0; p < SSDR_PATH_COUNT; p++) counts[p] = c->sum_paths[p];
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_audio_iq(ssdr_ctx *c, int16_t *iq_out, int out_is_device)
+int ssdr_audio_iq(ssdr_ctx *c, int16_t *iq_out, int out_is_device) SSDR_GUARD
 {
     if (!c || !iq_out) return SSDR_EINVAL;
     if (!c->iq_out_valid || !c->d_iq_out || c->audio_run_frames == 0) return SSDR_ESTATE;
@@ -1130,9 +1163,9 @@ int ssdr_audio_iq(ssdr_ctx *c, int16_t *iq_out, int out_is_device)
                            out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     if (!out_is_device) HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_audio_flags(ssdr_ctx *c, uint8_t *flags_out, int out_is_device)
+int ssdr_audio_flags(ssdr_ctx *c, uint8_t *flags_out, int out_is_device) SSDR_GUARD
 {
     if (!c || !flags_out) return SSDR_EINVAL;
     if (!c->d_flags || c->audio_run_frames == 0 || c->flags_frames < c->audio_run_frames) return SSDR_ESTATE;
@@ -1142,7 +1175,7 @@ int ssdr_audio_flags(ssdr_ctx *c, uint8_t *flags_out, int out_is_device)
                            out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     if (!out_is_device) HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
 // play_buffer's constant tables and carried history (utils_supersdr.py:999-1005), created at first use
 static int ensure_play(ssdr_ctx *c)
@@ -1175,7 +1208,7 @@ static int wfdata_feed(ssdr_ctx *c, const float *color, uint32_t lines);
 // Three streams: host->device copy of batch k+1, the two kernels of batch k, device->host copy of batch k-1.
 // The kernels stay on the ctx stream, in batch order, so the per-channel state and the waterfall's partial sums
 // carry from batch to batch exactly as with ssdr_push_iq / ssdr_run_*.
-int ssdr_feed_close(ssdr_ctx *c)
+int ssdr_feed_close(ssdr_ctx *c) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     if (c->feed.empty()) return SSDR_OK;
@@ -1202,15 +1235,16 @@ int ssdr_feed_close(ssdr_ctx *c)
     c->feed_lazy = false;
     c->feed_last = -1;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth, uint32_t flags)
+int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth, uint32_t flags) SSDR_GUARD
 {
     if (!c || n_frames == 0 || (n_frames & 1u) || depth < 2 || depth > 16 || (flags & ~(uint32_t)(SSDR_FEED_WIRE | SSDR_FEED_POST | SSDR_FEED_LAZY_OUT))) return SSDR_EINVAL;
     if (!c->feed.empty() || c->concurrent || c->decim != 1 || c->zoom != 1) return SSDR_ESTATE;      // the feed's slots are sized for un-zoomed 12 kHz IQ
     HIP_TRY(hipSetDevice(c->device));
     const bool post = (flags & SSDR_FEED_POST) != 0;
     if (post) { int rcp = ensure_play(c); if (rcp != SSDR_OK) return rcp; }
+    struct Undo { ssdr_ctx *c; bool armed; ~Undo() { if (armed) (void)ssdr_feed_close(c); } } undo{c, true};   // an error or an exception below: no half-open feed
     c->feed_post = post;
     if (post && c->feed_dbchan.size() != c->n_ch) {          // the reference's initial display state (utils_supersdr.py:599-603, 921, 945)
         ssdr_db2col_chan d;
@@ -1270,11 +1304,12 @@ int ssdr_feed_open(ssdr_ctx *c, uint32_t n_frames, uint32_t depth, uint32_t flag
         ok = ok && hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming) == hipSuccess;
     }
     c->feed_frames = n_frames;
-    if (!ok) { (void)hipGetLastError(); (void)ssdr_feed_close(c); return SSDR_ENOMEM; }
+    if (!ok) { (void)hipGetLastError(); return SSDR_ENOMEM; }
+    undo.armed = false;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_feed_slot(ssdr_ctx *c, void **host_iq)
+int ssdr_feed_slot(ssdr_ctx *c, void **host_iq) SSDR_GUARD
 {
     if (!c || !host_iq) return SSDR_EINVAL;
     if (c->feed.empty() || c->feed_taken) return SSDR_ESTATE;
@@ -1282,7 +1317,7 @@ int ssdr_feed_slot(ssdr_ctx *c, void **host_iq)
     *host_iq = c->feed[c->feed_head].h_in;
     c->feed_taken = true;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
 // host_in: where the batch lies (the slot's own pinned buffer, or the caller's -- ssdr_feed_submit_from)
 static int feed_submit_impl(ssdr_ctx *c, const void *host_in)
@@ -1410,49 +1445,49 @@ static int feed_submit_impl(ssdr_ctx *c, const void *host_in)
     return SSDR_OK;
 }
 
-int ssdr_feed_submit(ssdr_ctx *c)
+int ssdr_feed_submit(ssdr_ctx *c) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     if (c->feed.empty() || !c->feed_taken) return SSDR_ESTATE;
     return feed_submit_impl(c, c->feed[c->feed_head].h_in);
-}
+} SSDR_UNGUARD
 
-int ssdr_feed_submit_from(ssdr_ctx *c, const void *host_in)
+int ssdr_feed_submit_from(ssdr_ctx *c, const void *host_in) SSDR_GUARD
 {
     if (!c || !host_in) return SSDR_EINVAL;
     if (c->feed.empty() || c->feed_taken) return SSDR_ESTATE;
     if (c->feed_inflight == c->feed.size()) return SSDR_ESTATE;      // collect first: every slot is in flight
     return feed_submit_impl(c, host_in);
-}
+} SSDR_UNGUARD
 
-int ssdr_host_alloc(ssdr_ctx *c, uint64_t bytes, void **out)
+int ssdr_host_alloc(ssdr_ctx *c, uint64_t bytes, void **out) SSDR_GUARD
 {
     if (!c || !out || bytes == 0) return SSDR_EINVAL;
     *out = nullptr;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_host_free(ssdr_ctx *c, void *ptr)
+int ssdr_host_free(ssdr_ctx *c, void *ptr) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     if (!ptr) return SSDR_OK;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipHostFree(ptr));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_feed_post(ssdr_ctx *c, const ssdr_db2col_chan *chans, const ssdr_play_chan *play)
+int ssdr_feed_post(ssdr_ctx *c, const ssdr_db2col_chan *chans, const ssdr_play_chan *play) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     if (c->feed.empty() || !c->feed_post) return SSDR_ESTATE;
     if (chans) std::copy(chans, chans + c->n_post, c->feed_dbchan.begin());        // (n_post entries, in the order of the selection)
     if (play) std::copy(play, play + c->n_post, c->feed_playchan.begin());
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_feed_collect_post(ssdr_ctx *c, float **color, ssdr_db2col_chan **chans, int16_t **play, int16_t **mono)
+int ssdr_feed_collect_post(ssdr_ctx *c, float **color, ssdr_db2col_chan **chans, int16_t **play, int16_t **mono) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     if (c->feed.empty() || !c->feed_post || c->feed_last < 0) return SSDR_ESTATE;
@@ -1462,10 +1497,10 @@ int ssdr_feed_collect_post(ssdr_ctx *c, float **color, ssdr_db2col_chan **chans,
     if (play) *play = s.h_play;
     if (mono) *mono = s.has_mono ? s.h_mono : nullptr;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
 int ssdr_feed_collect(ssdr_ctx *c, int16_t **wf_sum, uint32_t *lines, int16_t **pcm, float **rssi, float **wire_rssi,
-                      uint8_t **flags, uint32_t *n_avg)
+                      uint8_t **flags, uint32_t *n_avg) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     if (c->feed.empty() || c->feed_inflight == 0) return SSDR_ESTATE;
@@ -1483,9 +1518,9 @@ int ssdr_feed_collect(ssdr_ctx *c, int16_t **wf_sum, uint32_t *lines, int16_t **
     c->feed_tail = (c->feed_tail + 1) % (uint32_t)c->feed.size();
     c->feed_inflight--;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_feed_collect_lazy(ssdr_ctx *c, uint32_t *n_sel, int16_t **d_wf_sum, int16_t **d_pcm, float **d_rssi, uint8_t **d_flags)
+int ssdr_feed_collect_lazy(ssdr_ctx *c, uint32_t *n_sel, int16_t **d_wf_sum, int16_t **d_pcm, float **d_rssi, uint8_t **d_flags) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     if (c->feed.empty() || c->feed_last < 0) return SSDR_ESTATE;
@@ -1496,17 +1531,17 @@ int ssdr_feed_collect_lazy(ssdr_ctx *c, uint32_t *n_sel, int16_t **d_wf_sum, int
     if (d_rssi) *d_rssi = s.d_rssi;
     if (d_flags) *d_flags = s.d_flags;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_wf_device(ssdr_ctx *c, int16_t **ptr, uint32_t *lines)
+int ssdr_wf_device(ssdr_ctx *c, int16_t **ptr, uint32_t *lines) SSDR_GUARD
 {
     if (!c || !ptr) return SSDR_EINVAL;
     *ptr = c->d_wf_out;
     if (lines) *lines = c->wf_lines_ready;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_copy_from_device(ssdr_ctx *c, void *host_dst, const void *device_src, uint64_t bytes)
+int ssdr_copy_from_device(ssdr_ctx *c, void *host_dst, const void *device_src, uint64_t bytes) SSDR_GUARD
 {
     if (!c || !host_dst || !device_src) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -1514,9 +1549,9 @@ int ssdr_copy_from_device(ssdr_ctx *c, void *host_dst, const void *device_src, u
     HIP_TRY(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_audio_device(ssdr_ctx *c, int16_t **pcm, float **rssi)
+int ssdr_audio_device(ssdr_ctx *c, int16_t **pcm, float **rssi) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -1524,9 +1559,9 @@ int ssdr_audio_device(ssdr_ctx *c, int16_t **pcm, float **rssi)
     if (pcm) *pcm = c->d_pcm;
     if (rssi) *rssi = c->d_rssi;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_get_consts(ssdr_ctx *c, uint32_t first, uint32_t count, ssdr_chan_consts *consts, float *taps)
+int ssdr_get_consts(ssdr_ctx *c, uint32_t first, uint32_t count, ssdr_chan_consts *consts, float *taps) SSDR_GUARD
 {
     if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -1535,9 +1570,9 @@ int ssdr_get_consts(ssdr_ctx *c, uint32_t first, uint32_t count, ssdr_chan_const
     if (taps) HIP_TRY(hipMemcpyAsync(taps, c->d_taps + (size_t)first * SSDR_NTAP_MAX, (size_t)count * SSDR_NTAP_MAX * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_get_state(ssdr_ctx *c, uint32_t first, uint32_t count, ssdr_chan_state *state, int16_t *hist)
+int ssdr_get_state(ssdr_ctx *c, uint32_t first, uint32_t count, ssdr_chan_state *state, int16_t *hist) SSDR_GUARD
 {
     if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -1546,9 +1581,9 @@ int ssdr_get_state(ssdr_ctx *c, uint32_t first, uint32_t count, ssdr_chan_state 
     if (hist) HIP_TRY(hipMemcpyAsync(hist, c->d_hist + (size_t)first * SSDR_HIST, (size_t)count * SSDR_HIST * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_state(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan_state *state, const int16_t *hist)
+int ssdr_set_state(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan_state *state, const int16_t *hist) SSDR_GUARD
 {
     if (!c || (uint64_t)first + count > c->n_ch) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -1560,7 +1595,7 @@ int ssdr_set_state(ssdr_ctx *c, uint32_t first, uint32_t count, const ssdr_chan_
     if (hist) HIP_TRY(hipMemcpyAsync(c->d_hist + (size_t)first * SSDR_HIST, hist, (size_t)count * SSDR_HIST * 4, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
 // ---- checkpoint: everything a stream carries from one call to the next, as one blob -------------------------
 // header | consts | taps | state | hist | waterfall partial sums | play_buffer history (zeros if never used)
@@ -1575,7 +1610,7 @@ static const uint32_t kCkptMagic = 0x52445353u;          // "SSDR"
 // kernels (version 3 blobs, whose `kfm` word meant padding, are refused)
 static const uint32_t kCkptVersion = 4;
 
-int ssdr_checkpoint_size(ssdr_ctx *c, uint64_t *bytes)
+int ssdr_checkpoint_size(ssdr_ctx *c, uint64_t *bytes) SSDR_GUARD
 {
     if (!c || !bytes) return SSDR_EINVAL;
     const uint64_t n = c->n_ch;
@@ -1583,9 +1618,9 @@ int ssdr_checkpoint_size(ssdr_ctx *c, uint64_t *bytes)
                                            SSDR_HIST * 4 + SSDR_NFFT * 2 + 8 * sizeof(double) + (SSDR_NFFT / 2) * 4 +
                                            sizeof(ssdr_chan_params));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_checkpoint_save(ssdr_ctx *c, void *blob)
+int ssdr_checkpoint_save(ssdr_ctx *c, void *blob) SSDR_GUARD
 {
     if (!c || !blob) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -1611,9 +1646,9 @@ int ssdr_checkpoint_save(ssdr_ctx *c, void *blob)
     memcpy(p, c->h_params.data(), n * sizeof(ssdr_chan_params));          // what the constants were compiled from
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob, uint64_t bytes)
+int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob, uint64_t bytes) SSDR_GUARD
 {
     if (!c || !blob) return SSDR_EINVAL;
     uint64_t want = 0;
@@ -1637,6 +1672,12 @@ int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob, uint64_t bytes)
     for (size_t i = 0; i < n; i++)
         if (ssdr_compile_params_host(&prm[i], &kc[i], ktaps.data() + i * SSDR_NTAP_MAX, h.decim, h.kiwi_rate) != SSDR_OK) return SSDR_EINVAL;
     if (!c->feed.empty() || c->zoom > 1) return SSDR_ESTATE;
+    std::vector<double> play_hist;                          // play_buffer state that arrives before its buffers exist: applied at first use
+    if (h.has_play && !c->d_play_hist) {
+        const double *q = reinterpret_cast<const double *>(static_cast<const char *>(blob) + sizeof h + n * (sizeof(ssdr_chan_consts) +
+                          SSDR_NTAP_MAX * sizeof(float) + sizeof(ssdr_chan_state) + SSDR_HIST * 4 + SSDR_NFFT * 2));
+        play_hist.assign(q, q + n * 8);
+    }
     HIP_TRY(hipSetDevice(c->device));
     { int rch = ssdr_set_hop(c, h.hop); if (rch != SSDR_OK) return rch; }
     { int rcj = join_audio(c); if (rcj != SSDR_OK) return rcj; }
@@ -1662,15 +1703,11 @@ int ssdr_checkpoint_load(ssdr_ctx *c, const void *blob, uint64_t bytes)
     c->synth_sample0 = h.synth_sample0;
     c->summary_dirty = true;
     c->chan_list_dirty = true;
-    c->pending_play_hist.clear();
-    if (h.has_play && !c->d_play_hist) {                    // play_buffer state arrives before its buffers exist: applied at first use
-        const double *q = reinterpret_cast<const double *>(p);
-        c->pending_play_hist.assign(q, q + n * 8);
-    }
+    c->pending_play_hist.swap(play_hist);                   // (every host allocation of the load was made before anything was touched)
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_selftest_quantiser(ssdr_ctx *c, uint64_t *mismatches)
+int ssdr_selftest_quantiser(ssdr_ctx *c, uint64_t *mismatches) SSDR_GUARD
 {
     if (!c || !mismatches) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -1681,7 +1718,7 @@ int ssdr_selftest_quantiser(ssdr_ctx *c, uint64_t *mismatches)
     HIP_TRY(hipStreamSynchronize(c->stream));
     *mismatches = v;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
 // kiwi_waterfall.run's feeding of wf_data (utils_supersdr.py:893-897) for `lines` colour lines [lines][n_ch][1024] on
 // the device: each line joins the 3-deep queue (a full queue drops its oldest entry first); from the 4th line on the
@@ -1707,7 +1744,7 @@ static int wfdata_feed(ssdr_ctx *c, const float *color, uint32_t lines)
     return SSDR_OK;
 }
 
-int ssdr_set_post_channels(ssdr_ctx *c, const uint32_t *channels, uint32_t count)
+int ssdr_set_post_channels(ssdr_ctx *c, const uint32_t *channels, uint32_t count) SSDR_GUARD
 {
     if (!c || (count && !channels && count != c->n_ch) || count > c->n_ch) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -1732,9 +1769,9 @@ int ssdr_set_post_channels(ssdr_ctx *c, const uint32_t *channels, uint32_t count
         c->wfdata_head = 0; c->wfdata_seen = c->wfpend_first = 0; c->wfpend_n = 0;
     }
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_run_db2col(ssdr_ctx *c, ssdr_db2col_chan *chans, float *color_out, int out_is_device)
+int ssdr_run_db2col(ssdr_ctx *c, ssdr_db2col_chan *chans, float *color_out, int out_is_device) SSDR_GUARD
 {
     if (!c || !chans) return SSDR_EINVAL;
     if (!c->d_wf_out && c->wf_lines_ready) return SSDR_ESTATE;
@@ -1769,9 +1806,9 @@ int ssdr_run_db2col(ssdr_ctx *c, ssdr_db2col_chan *chans, float *color_out, int 
                                out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_db2col_line(ssdr_ctx *c, const int16_t *wf_sum, uint32_t n_avg, ssdr_db2col_chan *chan, float *color_out)
+int ssdr_db2col_line(ssdr_ctx *c, const int16_t *wf_sum, uint32_t n_avg, ssdr_db2col_chan *chan, float *color_out) SSDR_GUARD
 {
     if (!c || !wf_sum || !chan || !color_out || n_avg < 1 || n_avg > 100) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -1799,9 +1836,9 @@ int ssdr_db2col_line(ssdr_ctx *c, const int16_t *wf_sum, uint32_t n_avg, ssdr_db
     HIP_TRY(hipMemcpyAsync(color_out, c->d_color1, SSDR_NFFT * sizeof(float), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_output_checksum(ssdr_ctx *c, uint64_t sums[3])
+int ssdr_output_checksum(ssdr_ctx *c, uint64_t sums[3]) SSDR_GUARD
 {
     if (!c || !sums) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -1818,9 +1855,9 @@ int ssdr_output_checksum(ssdr_ctx *c, uint64_t sums[3])
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 3; i++) sums[i] = v[i];
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_wfdata_rows(ssdr_ctx *c, uint32_t rows)
+int ssdr_set_wfdata_rows(ssdr_ctx *c, uint32_t rows) SSDR_GUARD
 {
     if (!c || rows > 4096) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -1843,9 +1880,9 @@ int ssdr_set_wfdata_rows(ssdr_ctx *c, uint32_t rows)
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_push_color_lines(ssdr_ctx *c, const float *color, uint32_t lines, int color_is_device)
+int ssdr_push_color_lines(ssdr_ctx *c, const float *color, uint32_t lines, int color_is_device) SSDR_GUARD
 {
     if (!c || (!color && lines)) return SSDR_EINVAL;
     if (!c->d_wfdata) return SSDR_ESTATE;
@@ -1866,9 +1903,9 @@ int ssdr_push_color_lines(ssdr_ctx *c, const float *color, uint32_t lines, int c
     if (rc != SSDR_OK) return rc;
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_wfdata_white_flag(ssdr_ctx *c, uint32_t first, uint32_t count)
+int ssdr_wfdata_white_flag(ssdr_ctx *c, uint32_t first, uint32_t count) SSDR_GUARD
 {
     if (!c || first + count > c->n_post || first + count < first) return SSDR_EINVAL;      // (positions in the selection)
     if (!c->d_wfdata) return SSDR_ESTATE;
@@ -1881,9 +1918,9 @@ int ssdr_wfdata_white_flag(ssdr_ctx *c, uint32_t first, uint32_t count)
     HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(row0), (int)bits, (size_t)count * SSDR_NFFT, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_run_trace(ssdr_ctx *c, uint32_t t_avg, uint32_t spectrum_height, double *trace_out, int32_t *y_out, int out_is_device)
+int ssdr_run_trace(ssdr_ctx *c, uint32_t t_avg, uint32_t spectrum_height, double *trace_out, int32_t *y_out, int out_is_device) SSDR_GUARD
 {
     if (!c || t_avg == 0) return SSDR_EINVAL;
     if (!c->d_wfdata) return SSDR_ESTATE;
@@ -1913,9 +1950,9 @@ int ssdr_run_trace(ssdr_ctx *c, uint32_t t_avg, uint32_t spectrum_height, double
     if (y_out) HIP_TRY(hipMemcpyAsync(y_out, c->d_trace_y, n * sizeof(int32_t), kind, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_run_smeter(ssdr_ctx *c, ssdr_smeter_chan *chans, const double *rssi_in, double fps)
+int ssdr_run_smeter(ssdr_ctx *c, ssdr_smeter_chan *chans, const double *rssi_in, double fps) SSDR_GUARD
 {
     if (!c || !chans || !(fps > 0.0)) return SSDR_EINVAL;
     if (!rssi_in && (!c->d_rssi || c->audio_frames == 0 || c->audio_run_frames == 0)) return SSDR_ESTATE;
@@ -1941,9 +1978,9 @@ int ssdr_run_smeter(ssdr_ctx *c, ssdr_smeter_chan *chans, const double *rssi_in,
     HIP_TRY(hipMemcpyAsync(chans, c->d_smeter, (size_t)c->n_ch * sizeof(ssdr_smeter_chan), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_kiwi_rate(ssdr_ctx *c, uint32_t kiwi_rate)
+int ssdr_set_kiwi_rate(ssdr_ctx *c, uint32_t kiwi_rate) SSDR_GUARD
 {
     if (!c || (kiwi_rate != SSDR_RATE && kiwi_rate != SSDR_RATE_WIDE)) return SSDR_EINVAL;
     if (kiwi_rate == c->kiwi_rate) return SSDR_OK;
@@ -1951,25 +1988,31 @@ int ssdr_set_kiwi_rate(ssdr_ctx *c, uint32_t kiwi_rate)
     HIP_TRY(hipSetDevice(c->device));
     // the rate of the play-back stage AND of the IQ the channels receive: every channel's constants (NCO steps, filter,
     // AGC time constants, NBFM scale) are compiled for it, and streams of the old rate mean nothing at the new one
+    std::vector<ssdr_chan_params> all = c->h_params;
     const uint32_t keep = c->kiwi_rate;
     c->kiwi_rate = kiwi_rate;
-    std::vector<ssdr_chan_params> all = c->h_params;
     int rc = ssdr_set_params(c, 0, c->n_ch, all.data());
-    if (rc != SSDR_OK) { c->kiwi_rate = keep; (void)ssdr_set_params(c, 0, c->n_ch, all.data()); return rc; }
-    c->have_input = false;
-    rc = ssdr_reset_state(c, 0, c->n_ch);
-    if (rc == SSDR_OK) rc = zoom_restart(c, 0, c->n_ch);
+    if (rc == SSDR_OK) {
+        c->have_input = false;
+        rc = ssdr_reset_state(c, 0, c->n_ch);
+        if (rc == SSDR_OK) rc = zoom_restart(c, 0, c->n_ch);
+    }
+    if (rc != SSDR_OK) {                                          // all or nothing, as ssdr_set_decimation
+        c->kiwi_rate = keep;
+        (void)ssdr_set_params(c, 0, c->n_ch, all.data());
+        (void)ssdr_reset_state(c, 0, c->n_ch);
+    }
     return rc;
-}
+} SSDR_UNGUARD
 
-int ssdr_playbuffer_frame_len(ssdr_ctx *c, uint32_t *samples_per_frame)
+int ssdr_playbuffer_frame_len(ssdr_ctx *c, uint32_t *samples_per_frame) SSDR_GUARD
 {
     if (!c || !samples_per_frame) return SSDR_EINVAL;
     *samples_per_frame = (c->kiwi_rate == SSDR_RATE) ? 2048u : (uint32_t)SSDR_RS_OUT_PER_FRAME;   // int(512 * SAMPLE_RATIO) (:1211)
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, int out_is_device)
+int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, int out_is_device) SSDR_GUARD
 {
     if (!c || !chans) return SSDR_EINVAL;
     if (!c->d_pcm || c->audio_run_frames == 0 || c->audio_frames < c->audio_run_frames) return SSDR_ESTATE;
@@ -2018,17 +2061,17 @@ int ssdr_run_playbuffer(ssdr_ctx *c, const ssdr_play_chan *chans, int16_t *out, 
                                out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_recording(ssdr_ctx *c, int on)
+int ssdr_set_recording(ssdr_ctx *c, int on) SSDR_GUARD
 {
     if (!c) return SSDR_EINVAL;
     c->recording = on != 0;
     if (!c->recording) c->play_run_frames = 0;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_playbuffer_mono(ssdr_ctx *c, int16_t *mono_out, int out_is_device)
+int ssdr_playbuffer_mono(ssdr_ctx *c, int16_t *mono_out, int out_is_device) SSDR_GUARD
 {
     if (!c || !mono_out) return SSDR_EINVAL;
     if (!c->d_play_mono || c->play_run_frames == 0) return SSDR_ESTATE;       // the last ssdr_run_playbuffer did not record
@@ -2037,9 +2080,9 @@ int ssdr_playbuffer_mono(ssdr_ctx *c, int16_t *mono_out, int out_is_device)
                            out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_push_iq_wire(ssdr_ctx *c, const uint8_t *bodies, uint32_t n_frames, float *rssi_out)
+int ssdr_push_iq_wire(ssdr_ctx *c, const uint8_t *bodies, uint32_t n_frames, float *rssi_out) SSDR_GUARD
 {
     if (!c || !bodies || n_frames == 0) return SSDR_EINVAL;
     if (c->decim != 1) return SSDR_ESTATE;                       // SND bodies carry 512 IQ samples at 12 kHz
@@ -2077,9 +2120,9 @@ int ssdr_push_iq_wire(ssdr_ctx *c, const uint8_t *bodies, uint32_t n_frames, flo
     c->in_frames = n_frames;
     c->have_input = true;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_wire_gps(ssdr_ctx *c, uint32_t *gps_out)
+int ssdr_wire_gps(ssdr_ctx *c, uint32_t *gps_out) SSDR_GUARD
 {
     if (!c || !gps_out) return SSDR_EINVAL;
     if (!c->d_wire_gps || c->wire_run_frames == 0) return SSDR_ESTATE;
@@ -2087,9 +2130,9 @@ int ssdr_wire_gps(ssdr_ctx *c, uint32_t *gps_out)
     HIP_TRY(hipMemcpyAsync(gps_out, c->d_wire_gps, (size_t)c->n_ch * c->wire_run_frames * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_adpcm_decode(ssdr_ctx *c, const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state, int16_t *out)
+int ssdr_adpcm_decode(ssdr_ctx *c, const uint8_t *data, uint32_t n_streams, uint32_t n_bytes, int32_t *state, int16_t *out) SSDR_GUARD
 {
     if (!c || !data || !state || !out || n_streams == 0 || n_bytes == 0) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -2113,9 +2156,9 @@ int ssdr_adpcm_decode(ssdr_ctx *c, const uint8_t *data, uint32_t n_streams, uint
     if (d_st) (void)hipFree(d_st);
     if (d_out) (void)hipFree(d_out);
     return rc;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_wf_lines(ssdr_ctx *c, const int16_t *wf_sum, uint32_t lines)
+int ssdr_set_wf_lines(ssdr_ctx *c, const int16_t *wf_sum, uint32_t lines) SSDR_GUARD
 {
     if (!c || !wf_sum || lines == 0) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -2128,9 +2171,9 @@ int ssdr_set_wf_lines(ssdr_ctx *c, const int16_t *wf_sum, uint32_t lines)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->wf_lines_ready = lines;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_set_pcm(ssdr_ctx *c, const int16_t *pcm, uint32_t n_frames)
+int ssdr_set_pcm(ssdr_ctx *c, const int16_t *pcm, uint32_t n_frames) SSDR_GUARD
 {
     if (!c || !pcm || n_frames == 0) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -2148,9 +2191,9 @@ int ssdr_set_pcm(ssdr_ctx *c, const int16_t *pcm, uint32_t n_frames)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->audio_run_frames = n_frames;          // the input batch (d_iq / in_frames / have_input) is not touched
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
-int ssdr_selftest_sqrt_values(ssdr_ctx *c, const float *in, float *out_scaled, float *out_int, uint32_t n)
+int ssdr_selftest_sqrt_values(ssdr_ctx *c, const float *in, float *out_scaled, float *out_int, uint32_t n) SSDR_GUARD
 {
     if (!c || !in || !out_scaled || !out_int || n == 0) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -2166,9 +2209,9 @@ int ssdr_selftest_sqrt_values(ssdr_ctx *c, const float *in, float *out_scaled, f
     }();
     (void)hipFree(d);
     return rc;
-}
+} SSDR_UNGUARD
 
-int ssdr_selftest_sqrt(ssdr_ctx *c, uint64_t *mismatches)
+int ssdr_selftest_sqrt(ssdr_ctx *c, uint64_t *mismatches) SSDR_GUARD
 {
     if (!c || !mismatches) return SSDR_EINVAL;
     HIP_TRY(hipSetDevice(c->device));
@@ -2179,6 +2222,6 @@ int ssdr_selftest_sqrt(ssdr_ctx *c, uint64_t *mismatches)
     HIP_TRY(hipStreamSynchronize(c->stream));
     *mismatches = v;
     return SSDR_OK;
-}
+} SSDR_UNGUARD
 
 } // extern "C"

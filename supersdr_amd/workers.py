@@ -159,13 +159,17 @@ class IQHub:
                  backlog_superframes=8, stall_superframes=4, pipeline=False, depth=3, hop=1024, zoom=1, lazy=None,
                  batch_superframes=1, wire=False, copy_threads=None, exact_bins=False, lazy_out=False):
         self.n_ch = int(n_channels)
+        # argument combinations that cannot work are refused BEFORE an engine (a GPU context) exists
+        self._lazy = (self.n_ch > self.LAZY_ABOVE) if lazy is None else bool(lazy)
+        if int(zoom) != 1 and pipeline:
+            raise ValueError("zoom needs the synchronous hub (the pipelined feed's slots hold un-zoomed lines)")
+        if lazy_out and not (pipeline and self._lazy):
+            raise ValueError("lazy_out needs the pipelined feed and a lazy hub (pipeline=True, lazy=True)")
         self.engine = engine if engine is not None else SsdrEngine(self.n_ch, device)
         # waterfall zoom ("SET zoom=", utils_supersdr.py:741, 839): the lines then span 1/zoom of the IQ band around each
         # channel's zoom centre (set_wf_center) and one line needs `zoom` superframes: the hub batches that many per GPU run
         self.zoom = int(zoom)
         if self.zoom != 1:
-            if pipeline:
-                raise ValueError("zoom needs the synchronous hub (the pipelined feed's slots hold un-zoomed lines)")
             self.engine.set_wf_zoom(self.zoom)
         self.batch_superframes = max(1, int(batch_superframes))
         self._sf = L.NFFT * self.zoom * self.batch_superframes       # samples per channel and GPU run
@@ -228,7 +232,6 @@ class IQHub:
         # ---- results
         self.last = None                             # SuperframeResult of the newest GPU run
         self._subscribers = []
-        self._lazy = (self.n_ch > self.LAZY_ABOVE) if lazy is None else bool(lazy)
         self._max_queue = int(max_queue)
         self.wf_queue = _Queues(self, "wf", self._max_queue)
         self.snd_queue = _Queues(self, "snd", 2 * self._max_queue)
@@ -243,8 +246,9 @@ class IQHub:
         # (a hub of 10^5 receivers has a handful of listeners); the result arrays then have one row per attached channel
         # (SuperframeResult.out_channels) and every channel's results stay on the device (engine.feed_device())
         self._lazy_out = bool(lazy_out)
-        if self._lazy_out and not (self.pipeline and self._post_select):
-            raise ValueError("lazy_out needs the pipelined feed and a lazy hub (pipeline=True, lazy=True)")
+        if self._lazy_out and not self._post_select:
+            raise ValueError("lazy_out needs an engine with set_post_channels")
+        self._att_count = {}                         # lazy_out: channel -> queues attached (wf, snd): the rows that come back, at most L.FEED_LAZY_MAX
         self._post_sel, self._post_pos, self._post_dirty = None, None, self._post_select
         self._inflight_sel = deque()                 # pipelined: the selection each batch in flight was submitted with
         self._alloc_post_arrays(self.n_ch)
@@ -273,12 +277,20 @@ class IQHub:
             raise IndexError("channel %d of %d" % (c, self.n_ch))
         with self._lock:
             import bisect
+            if self._lazy_out and (wf or snd) and c not in self._att_count and len(self._att_count) >= L.FEED_LAZY_MAX:
+                # ssdr_feed_submit refuses a batch whose selection has more rows than the compact buffers hold (SSDR_FEED_LAZY_MAX):
+                # say so HERE, where the listener asks, not on the feeding thread a superframe later
+                raise ValueError("a lazy_out hub hands back at most %d channels (SSDR_FEED_LAZY_MAX); channel %d would be one more -- "
+                                 "open the hub without lazy_out to copy every channel back" % (L.FEED_LAZY_MAX, c))
             if wf and c not in self.wf_queue._q:
                 self.wf_queue._q[c] = queue.Queue(self._max_queue)
                 bisect.insort(self._wf_att, c)
             if snd and c not in self.snd_queue._q:
                 self.snd_queue._q[c] = queue.Queue(2 * self._max_queue)
                 bisect.insort(self._snd_att, c)
+            n_q = (c in self.wf_queue._q) + (c in self.snd_queue._q)
+            if n_q:
+                self._att_count[c] = n_q
             self._post_dirty = self._post_select            # the selection follows who is attached (re-derived before the next superframe)
         return {"wf": self.wf_queue._q.get(c), "snd": self.snd_queue._q.get(c)}
 
@@ -289,6 +301,11 @@ class IQHub:
                 self._wf_att.remove(c)
             if snd and self.snd_queue._q.pop(c, None) is not None:
                 self._snd_att.remove(c)
+            n_q = (c in self.wf_queue._q) + (c in self.snd_queue._q)
+            if n_q:
+                self._att_count[c] = n_q
+            else:
+                self._att_count.pop(c, None)
             self._post_dirty = self._post_select
 
     def subscribe(self, fn):
@@ -622,12 +639,14 @@ class IQHub:
             eng.feed_post(self._db_arr, self._play_arr)
         if self._post_dirty:                          # (without gpu_post nobody else re-derives it: lazy_out's rows follow the attached channels)
             self._apply_post_selection()
-        self._inflight_sel.append(self._post_sel)
         if hasattr(eng, "feed_submit_from"):
             eng.feed_submit_from(batch)               # the H2D copy reads the hub's slot itself
         else:
             eng.feed_slot()[:] = batch
             eng.feed_submit()
+        # only a batch that WAS submitted has a selection in flight (a refused submit raises above: the deque must stay in step
+        # with the engine's slots, or every later result would be paired with another batch's rows)
+        self._inflight_sel.append(self._post_sel)
         self._inflight += 1
         self.superframes += 1
         if self._inflight == self._depth:

@@ -1107,3 +1107,120 @@ def test_a_reservation_overtaken_by_the_stall_rule_is_refused_not_misfiled():
     stream = np.concatenate([b[2] for b in eng.batches])                  # channel 2 as the engine saw it, run after run
     at = np.flatnonzero((stream == 7000).all(axis=1))
     assert len(at) == 512 and at[-1] - at[0] == 511                      # the second block, once, in one piece; the first nowhere
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round 6: a lazy_out hub whose submit is refused (the selection deque ran ahead of the engine's slots)
+# ---------------------------------------------------------------------------------------------------------------
+class LazyFeedDouble:
+    """The pipelined feed of SsdrEngine as IQHub uses it with lazy_out (compact rows in the order of the selection in force at
+    submit), no arithmetic: row r of batch b carries (b, channel) in its first two cells, so a result handed to the wrong
+    listener or paired with the wrong batch's selection is visible.  `refuse` makes the next submit raise, as
+    ssdr_feed_submit does with SSDR_ESTATE when the selection has more rows than SSDR_FEED_LAZY_MAX."""
+
+    def __init__(self, n_ch):
+        from collections import deque
+        self.n_ch, self.sel, self.inflight, self.submitted, self.refuse = n_ch, None, deque(), 0, 0
+        self.feed_n_avg, self.feed_flags, self.sel_log = 1, None, []
+
+    def set_kiwi_rate(self, rate):
+        pass
+
+    def set_averaging(self, n):
+        pass
+
+    def playbuffer_frame_len(self):
+        return 2048
+
+    def set_post_channels(self, channels=None):
+        self.sel = None if channels is None else list(channels)
+        self.sel_log.append(self.sel)
+
+    def feed_open(self, n_frames, depth=3, post=False, lazy_out=False):
+        assert lazy_out and not post
+        self.frames, self.depth = n_frames, depth
+
+    def feed_submit_from(self, batch):
+        if self.refuse:
+            self.refuse -= 1
+            from supersdr_amd import SsdrError
+            raise SsdrError(-5, "ssdr_feed_submit_from")
+        assert len(self.inflight) < self.depth
+        self.submitted += 1
+        self.inflight.append((self.submitted, list(range(self.n_ch)) if self.sel is None else list(self.sel)))
+
+    def feed_collect(self):
+        b, sel = self.inflight.popleft()
+        wf = np.zeros((self.frames // 2, len(sel), 1024), np.int16)
+        pcm = np.zeros((len(sel), self.frames * 512), np.int16)
+        for r, c in enumerate(sel):
+            wf[:, r, 0], wf[:, r, 1], pcm[r, 0], pcm[r, 1] = b, c, b, c
+        self.feed_flags = np.zeros((len(sel), self.frames), np.uint8)
+        return wf, pcm, np.zeros((len(sel), self.frames), np.float32)
+
+    def close(self):
+        pass
+
+
+def test_a_refused_submit_leaves_the_lazy_hub_in_step():
+    from supersdr_amd import SsdrError
+    from supersdr_amd.workers import IQHub
+    n = 16
+    eng = LazyFeedDouble(n)
+    hub = IQHub(n, engine=eng, pipeline=True, depth=3, lazy=True, lazy_out=True, gpu_post=False)
+    q3, q7 = hub.attach(3, wf=True, snd=True), hub.attach(7, wf=True)
+    sf = np.zeros((n, 1024, 2), np.int16)
+    for _ in range(4):
+        hub.feed_block(0, sf)
+    eng.refuse = 2                                   # two submits in a row are refused: the feeding call raises, nothing is lost
+    for _ in range(2):
+        with pytest.raises(SsdrError):
+            hub.feed_block(0, sf)
+    assert len(hub._inflight_sel) == hub._inflight == len(eng.inflight)
+    q9 = hub.attach(9, wf=True, snd=True)            # the selection changes while older batches are in flight
+    for _ in range(5):
+        hub.feed_block(0, sf)
+    hub.flush()
+    assert hub._inflight == 0 and not hub._inflight_sel and not eng.inflight
+
+    def drain(q):
+        out = []
+        while not q.empty():
+            out.append(q.get_nowait())
+        return out
+    for c, qs in ((3, q3), (7, q7), (9, q9)):
+        lines = [e[0] for e in drain(qs["wf"])]          # (line, n_avg, colours)
+        assert lines and all(int(ln[1]) == c for ln in lines), "channel %d was handed another receiver's line" % c
+        batches = [int(ln[0]) for ln in lines]
+        assert batches == sorted(set(batches)) and batches[-1] == eng.submitted
+        if qs["snd"] is not None:
+            frames = drain(qs["snd"])
+            assert frames and all(int(f[1]) == c for f in frames[::2]), "channel %d was handed another receiver's audio" % c
+    assert eng.sel_log[-1] == [3, 7, 9]
+
+
+def test_lazy_out_attach_limit_and_argument_checks_come_before_the_engine(monkeypatch):
+    from supersdr_amd import _lib as L
+    from supersdr_amd.workers import IQHub
+    assert L.FEED_LAZY_MAX == 4096
+    hdr = open(os.path.join(ROOT, "include", "ssdr.h")).read()
+    assert "#define SSDR_FEED_LAZY_MAX 4096u" in hdr
+    monkeypatch.setattr(L, "FEED_LAZY_MAX", 4)
+    hub = IQHub(16, engine=LazyFeedDouble(16), pipeline=True, depth=2, lazy=True, lazy_out=True, gpu_post=False)
+    for c in (1, 2, 3):
+        hub.attach(c, wf=True)
+    hub.attach(3, snd=True)                           # a second queue of an attached channel is not a new row
+    hub.attach(4, snd=True)
+    with pytest.raises(ValueError, match="SSDR_FEED_LAZY_MAX"):
+        hub.attach(5, wf=True)
+    assert 5 not in hub.wf_queue._q and len(hub._att_count) == 4
+    hub.detach(3, wf=True, snd=False)                 # still listening to its audio: the row stays
+    with pytest.raises(ValueError):
+        hub.attach(5, wf=True)
+    hub.detach(3)
+    hub.attach(5, wf=True)
+    # impossible argument sets are refused before an engine is built (without a GPU the engine's constructor would raise SsdrError)
+    with pytest.raises(ValueError, match="lazy_out"):
+        IQHub(8, lazy=True, lazy_out=True)
+    with pytest.raises(ValueError, match="zoom"):
+        IQHub(8, pipeline=True, zoom=2)

@@ -213,3 +213,53 @@ def test_param_compile_for_a_decimating_front_end_equals_oracle(S, decim):
     assert S.compile_params(S.default_params("usb", f_shift_hz=11000.0), 2)[0]["decim"] == 2      # inside +-12 kHz
     with pytest.raises(S.SsdrError):
         S.compile_params(S.default_params("usb", f_shift_hz=12000.5), 2)
+
+
+# ---- include/ssdr.h:11-14 "never throws or aborts" (the reference's own policy: errors become a flag, utils_supersdr.py:1031-1036) ----
+
+def test_every_int_entry_point_is_a_function_try_block():
+    """every `int ssdr_*` definition inside csrc/ssdr_api.cpp's extern "C" block carries SSDR_GUARD ... SSDR_UNGUARD
+    (catch std::bad_alloc -> SSDR_ENOMEM, anything else -> SSDR_EHIP), and the header's functions are all defined there"""
+    src = open(os.path.join(ROOT, "supersdr_amd", "csrc", "ssdr_api.cpp")).read()
+    body = src[src.index('extern "C" {'):]
+    defs = re.findall(r"^int (ssdr_\w+)\([^;{]*?\)( SSDR_GUARD)?\n\{", body, flags=re.M)
+    assert len(defs) >= 70
+    unguarded = [n for n, g in defs if not g]
+    assert not unguarded, unguarded
+    assert body.count("} SSDR_UNGUARD") == len(defs)
+    returning_int = set(n for n, _ in defs)
+    hdr = open(os.path.join(ROOT, "include", "ssdr.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared_int = set(re.findall(r"^int (ssdr_\w+)\s*\(", hdr, flags=re.M))
+    assert declared_int == returning_int, declared_int ^ returning_int
+
+
+def build_fault_harness(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "abi_fault_harness")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-rdynamic", "-o", exe,
+                           os.path.join(ROOT, "tests", "abi_fault_harness.cpp"), "-ldl"])
+    return exe
+
+
+def test_failing_host_allocations_come_back_as_codes_cpu(tmp_path):
+    """tests/abi_fault_harness.cpp: a process whose operator new fails for every allocation made from libssdr.so still gets
+    return codes from the entry points that need no GPU (and SSDR_ENODEV / SSDR_ENOMEM, no half-built ctx, from ssdr_create)"""
+    import subprocess
+    from supersdr_amd import _lib as L
+    out = subprocess.run([build_fault_harness(tmp_path), L.LIB_PATH, "cpu"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "PASS" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_failing_host_allocations_come_back_as_codes_gpu(tmp_path):
+    """the fault-injection sweep on a live ctx: in ssdr_create, ssdr_set_params, ssdr_reset_state, the run calls (channel-list
+    rebuild), get / set state, checkpoint save / load, the post-processing selection and kernels, the feed, zoom, exact bins, rate
+    and decimation changes, the 1st, 2nd, 3rd ... host allocation fails in turn: every time the call RETURNS SSDR_ENOMEM (a
+    std::bad_alloc crossing the C boundary would be SIGABRT), the ctx stays usable and the same call then succeeds"""
+    import subprocess
+    from supersdr_amd import _lib as L
+    out = subprocess.run([build_fault_harness(tmp_path), L.LIB_PATH, "gpu"], capture_output=True, text=True, timeout=600)
+    print(out.stdout)
+    assert out.returncode == 0 and "PASS" in out.stdout, out.stdout + out.stderr
+    assert "ssdr_checkpoint_load" in out.stdout and "ssdr_create" in out.stdout
