@@ -70,13 +70,12 @@ PATH_TEXT = ("general: NCO -> FIR -> demodulator", "full-band lane shift: NCO, n
 PATH_SHORT = ("general (NCO -> channel FIR -> demodulator)", "full-band lane shift (NCO, no FIR)", "full-band AM (no NCO, no FIR)")
 F32_PEAK_TFLOPS = 157.3                          # MI355X_MICROARCH.md: vector f32 peak (an FMA = 2 flop)
 RIDGE_FLOP_PER_BYTE = F32_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBPS * 1e9)          # 19.7
-# Executed vector work per unit: VALU wave-instructions from PMC SQ_INSTS_VALU / wave-units (profiles/r04_*_pmc_summary.txt:
-# 6.152e8 per 524 288 line pairs, 3.727e8 per 327 680, 1.2204e9 per 1 048 576 (hop 512); 5.456e8 / 1.898e8 / 7.958e7 per
-# 655 360 / 327 680 / 327 680 frames; the fused superframe kernel 1.1262e9 (hop 1024) / 1.7386e9 (hop 512) per 1 048 576
-# channel-superframes; 7.031e8 per 262 144 frames at D = 4), FMA share from the opcode mix of the loops
-# (profiles/r04_isa_histograms.txt; the filters' multiply-adds -- 512 per frame for 33 taps, 2000 for 125 at D = 4 -- are dynamic).
-# lane-ops = 64 lanes x (instructions + FMA instructions): issue-slot work, see roofline().
-KERNEL_VALU = {
+# Executed vector work per unit: VALU wave-instructions from PMC SQ_INSTS_VALU / wave-units.  The per-launch counts are READ from the
+# newest committed profiles/rNN_<workload>_pmc_summary.txt (tools/profile_round.sh) and divided by the units that workload's launch
+# processes (VALU_SOURCES); the constants below are only the fall-back for a kernel no committed summary names (round 4's figures).
+# FMA share: from the opcode mix of the loops (profiles/r04_isa_histograms.txt; the filters' multiply-adds -- 512 per frame for
+# 33 taps, 2000 for 125 at D = 4 -- are dynamic).  lane-ops = 64 lanes x (instructions + FMA instructions): issue-slot work, see roofline().
+KERNEL_VALU_FALLBACK = {
     "ssdr_wf_kernel<false, false>": ("line", 1173.5 / 2, 0.65),
     "ssdr_wf_kernel<true, false>": ("line", 1137.5 / 2, 0.60),
     "ssdr_wf_kernel<false, true>": ("line", 1163.9 / 2, 0.65),
@@ -87,6 +86,64 @@ KERNEL_VALU = {
     "ssdr_fused_am_kernel<false, false>": ("channel-superframe", 1074.0, 0.45),
     "ssdr_fused_am_kernel<true, false>": ("channel-superframe", 1658.0, 0.50),
     "ssdr_audio_dec_kernel<4>": ("frame", 2682, 0.85),
+}
+# kernel -> (summary of which profiled workload, units of that kernel in one launch of it)
+VALU_SOURCES = {
+    "ssdr_wf_kernel<false, false>": ("wf", 4096 * 256),
+    "ssdr_wf_kernel<true, false>": ("mixed_serial", 65536 * 10),
+    "ssdr_wf_kernel<false, true>": ("wf_hop512", 4096 * 512),
+    "ssdr_audio_kernel<0>": ("mixed_serial", 32768 * 20),
+    "ssdr_audio_kernel<1>": ("mixed_serial", 16384 * 20),
+    "ssdr_audio_kernel<2>": ("mixed_serial", 16384 * 20),
+    "ssdr_fused_am_kernel<false, false>": ("full", 65536 * 16),
+    "ssdr_fused_am_kernel<true, false>": ("full_hop512_fused", 65536 * 16),
+    "ssdr_audio_dec_kernel<4>": ("decim4", 16384 * 16),
+}
+
+
+def load_kernel_valu():
+    """-> (KERNEL_VALU, {kernel: the profiles/ file its instruction count was read from})"""
+    import glob, re
+    table, sources = dict(KERNEL_VALU_FALLBACK), {}
+    for kernel, (wl, units) in VALU_SOURCES.items():
+        best = None
+        for path in glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_summary.txt" % wl)):
+            m = re.match(r"r(\d+)_", os.path.basename(path))
+            if m and (best is None or int(m.group(1)) > best[0]):
+                best = (int(m.group(1)), path)
+        if best is None:
+            continue
+        stem = kernel[:kernel.index("<")]
+        targs = kernel[kernel.index("<"):]
+        for line in open(best[1]):
+            # names are cut at 60 characters ("...ssdr_fused_am_kernel<false, fals"): the template arguments match as a prefix
+            m = re.search(r"(ssdr_\w+_kernel)(<[^(>]*>?)?.*\bSQ_INSTS_VALU\s+n=\d+\s+mean=([0-9.e+]+)", line)
+            if m and m.group(1) == stem and m.group(2) and targs.startswith(m.group(2).rstrip()):
+                unit, _, fma = KERNEL_VALU_FALLBACK[kernel]
+                table[kernel] = (unit, float(m.group(3)) / units, fma)
+                sources[kernel] = os.path.basename(best[1])
+                break
+    table["ssdr_wf_kernel<true, true>"] = table["ssdr_wf_kernel<true, false>"]
+    return table, sources
+
+
+KERNEL_VALU, KERNEL_VALU_SOURCE = load_kernel_valu()
+
+# What a kernel that does nothing but move bytes sustains on this chip for the read : write mix of each kernel (tools/ubench/hbm_stream.hip, bare
+# stream kernels, streaming loads / stores, best grid; two boxes: profiles/r04_ubench_hbm_stream.txt) -- the denominator of
+# roofline.frac_of_measured_stream.  The roofline fractions proper stay against the 8 TB/s of MI355X_MICROARCH.md.
+STREAM_SOURCE = "profiles/r04_ubench_hbm_stream.txt (tools/ubench/hbm_stream.hip)"
+MEASURED_STREAM_GBPS = {                      # kernel stem -> (mix, lowest, highest GB/s of the two boxes)
+    "ssdr_fused_am_kernel": ("copy 1:1", 5290.0, 5670.0),            # 4096 B in, 2048 + 2048 B out per channel-superframe
+    "ssdr_fused_exact_am_kernel": ("copy 1:1", 5290.0, 5670.0),
+    "ssdr_wf_kernel": ("2 read : 1 write", 5340.0, 5510.0),          # 4096 in, 2048 out
+    "ssdr_wf_exact_kernel": ("2 read : 1 write", 5340.0, 5510.0),
+    "ssdr_audio_kernel": ("2 read : 1 write", 5340.0, 5510.0),       # 2048 in, 1024 out
+    "ssdr_audio_dec_kernel": ("read only", 6940.0, 7030.0),          # 8192 in, 1024 out at D = 4: nearest probe
+    "ssdr_db2col_kernel": ("1 read : 2 write", 5070.0, 5550.0),
+    "ssdr_play_kernel": ("1 read : 8 write", 4450.0, 5280.0),
+    "ssdr_play_rs_kernel": ("1 read : 8 write", 4450.0, 5280.0),
+    "ssdr_iqwire_kernel": ("copy 1:1", 5290.0, 5670.0),
 }
 
 
@@ -278,6 +335,51 @@ def spawn_ranks(gpus, argv):
 # ---------------------------------------------------------------------------------------------------------------
 # one measurement
 # ---------------------------------------------------------------------------------------------------------------
+class SetupFailed(RuntimeError):
+    """raised on EVERY rank alike when one of them could not set a measurement up (measure())"""
+
+
+# What the driver's single `--gpus N` command (N > 1) measures after the main `full` run, on every rank, by the same barrier / max-wall
+# rule: BASELINE configs[4] (2^20 channels in total, 2^20 / N per GPU: the strong-scaling curve) and configs[3] (weak).
+#                     key        workload   steps  scaling
+MULTI_RANK_EXTRAS = (("million", "million", 5,     "strong"),
+                     ("mixed",   "mixed",   60,    "weak"))
+
+
+def multi_rank_extras(rdv, rank, world, run_one, probe=None):
+    """Collective: every rank calls it.  run_one(workload, channels, sframes, first_channel_id, steps) -> measure()'s dict;
+    probe(workload, first_channel_id, fused) -> the three checksums of a fresh probe of that block (None: no parity ring).
+    -> {key: {value (all ranks' channel-superframes over the slowest rank's wall), per_rank, channels_per_gpu, scaling, parity ...}}"""
+    from supersdr_amd.dist import channel_block
+    out = {}
+    for key, wl, nsteps, scaling in MULTI_RANK_EXTRAS:
+        total, sf, n_avg = WORKLOADS[wl][0], WORKLOADS[wl][1], WORKLOADS[wl][2]
+        first, ch = channel_block(rank, world, total) if scaling == "strong" else (rank * total, total)
+        try:
+            e = run_one(wl, ch, sf, first, nsteps)
+        except SetupFailed as ex:
+            out[key] = {"error": str(ex)[:300]}
+            print("bench.py: extra.%s skipped on all ranks: %s" % (key, ex), file=sys.stderr, flush=True)
+            continue
+        per_rank = [v[0] for v in rdv.gather_floats([e["own_value"]])]
+        chans = [int(v[0]) for v in rdv.gather_ints([ch])]
+        firsts = [int(v[0]) for v in rdv.gather_ints([first])]
+        b = ch * sf * (4096.0 + 2048.0 / n_avg + 2048.0)           # SURVEY.md 8d fused budget of THIS rank's block, over the step time
+        out[key] = {"workload": WORKLOAD_TEXT[wl], "value": e["value"], "unit": "rt_channels", "ms_per_step": e["ms_per_step"], "steps": nsteps,
+                    "scaling": scaling, "n_gpus": world, "channels_per_gpu": chans, "channels_total": sum(chans), "first_channel_ids": firsts,
+                    "superframes_per_step": sf, "averaging_n": n_avg,
+                    "chain_frac": b / e["ms_per_step"] / 1e6 / HBM_PEAK_GBPS,
+                    "per_rank": {"values": per_rank, "value_min": min(per_rank), "value_max": max(per_rank),
+                                 "note": "each rank's own channel-superframes / its own wall time; `value` uses the max wall over ranks"}}
+        if "kernels" in e:
+            out[key]["kernels"] = e["kernels"]
+        if probe is not None:
+            own, cross = probe(wl, first, 1), probe(wl, firsts[(rank + 1) % world], 0)
+            par = parity_report(rdv, world, firsts, own, cross, "as the main parity ring, on this workload's channel blocks")
+            out[key]["parity"] = {"ranks_agree": par["ranks_agree"], "mismatching_ranks": par["mismatching_ranks"]}
+    return out
+
+
 def configure(S, eng, workload, channels, first_channel_id, hop=1024, fused=1, concurrent=0, exact=0, overlap=1):
     """channel parameters of `workload` for the block of channels that starts at global id `first_channel_id`
     (mode by channel id mod len(modes), tuning by the generator's carrier formula)"""
@@ -306,7 +408,8 @@ def parity_probe(S, local_rank, workload, first_channel_id, channels=256, sframe
     global id `first_channel_id` and returns the checksums of what it produced (ssdr_output_checksum: waterfall sums,
     PCM, RSSI).  Integer arithmetic over the result bytes: the same channel block gives the same three numbers on any
     rank, any GPU, any launch shape -- or the ranks do not compute the same thing."""
-    _, _, _, _, do_wf, do_audio = WORKLOADS[workload]
+    _, _, n_avg, _, do_wf, do_audio = WORKLOADS[workload]
+    sframes = max(sframes, n_avg)                         # (N-line binning: at least one complete group per step)
     with S.SsdrEngine(channels, device=local_rank) as eng:
         configure(S, eng, workload, channels, first_channel_id, fused=fused)
         eng.synth_iq(2 * sframes, seed=0x5D5D, first_channel_id=first_channel_id)
@@ -328,10 +431,21 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     n_frames = 2 * sframes
     if first_channel_id is None:
         first_channel_id = rank * channels
-    eng = S.SsdrEngine(channels, device=local_rank)
-    n_avg, decim = configure(S, eng, workload, channels, first_channel_id, hop, fused, concurrent, exact, overlap)
-    eng.synth_iq(n_frames, seed=0x5D5D, first_channel_id=first_channel_id)    # resident in HBM from here on
-    eng.sync()
+    # set-up (context, buffers, synthetic input): a rank that cannot do it (memory) says so and ALL ranks leave together -- nobody waits at
+    # the barrier below for a rank that never reaches it
+    eng, err = None, None
+    try:
+        eng = S.SsdrEngine(channels, device=local_rank)
+        n_avg, decim = configure(S, eng, workload, channels, first_channel_id, hop, fused, concurrent, exact, overlap)
+        eng.synth_iq(n_frames, seed=0x5D5D, first_channel_id=first_channel_id)    # resident in HBM from here on
+        eng.sync()
+    except Exception as ex:                                # noqa: BLE001
+        err = ex
+    if not rdv.all_ok(err is None):
+        if eng is not None:
+            eng.close()
+        raise SetupFailed("%s on %d channels x %d superframes: set-up failed on %s" % (
+            workload, channels, sframes, ("this rank (%d): %s: %s" % (rank, type(err).__name__, str(err)[:160])) if err else "another rank"))
 
     def step():
         if do_wf:
@@ -398,7 +512,7 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     fu_ms, fu_n = eng.kernel_stats(L.K_FUSED)
     paths = eng.audio_paths()
     eng.close()
-    units = channels * sframes * steps * world                 # channel-superframes, whole job
+    units = rdv.sum_over_ranks(channels) * sframes * steps     # channel-superframes, whole job (blocks may differ by one channel)
     # algorithmic bytes per launch: WF 4096 B in + 2048/N B out per line;
     # audio 2048 B in + 1024 B out per 512-sample frame
     stages = {}
@@ -699,6 +813,14 @@ def roofline(stage, traffic=None, src=None):
     r = {"kernel": stage["kernel"], "bound": "hbm", "achieved": stage["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
          "frac": hbm, "frac_hbm": hbm, "traffic": traffic, "avg_kernel_ms": stage["avg_ms"],
          "algorithmic_bytes_per_launch": stage["bytes"]}
+    import re
+    stems = set(re.findall(r"(ssdr_\w+_kernel)", stage["kernel"]))
+    mixes = {MEASURED_STREAM_GBPS[k] for k in stems if k in MEASURED_STREAM_GBPS}
+    if len(mixes) == 1 and len(stems & set(MEASURED_STREAM_GBPS)) == len(stems):
+        mix, lo, hi = next(iter(mixes))
+        # against the HIGHER of the two boxes' figures: 0.53-of-spec and 0.7x-of-a-copy side by side (review r5, item 7)
+        r.update({"frac_of_measured_stream": stage["GBps"] / hi, "measured_stream_GBps": [lo, hi], "measured_stream_mix": mix,
+                  "measured_stream_source": STREAM_SOURCE})
     fl = executed_flops(stage)
     if fl is not None:
         tf = fl / stage["avg_ms"] / 1e9
@@ -706,8 +828,10 @@ def roofline(stage, traffic=None, src=None):
         # ops included), an FMA twice -- the measure of how busy the vector ALU is against its f32 FMA peak
         r["issue"] = {"lane_ops_per_launch": fl, "lane_ops_per_algorithmic_byte": fl / stage["bytes"], "ridge_per_byte": RIDGE_FLOP_PER_BYTE,
                       "achieved_tera_ops": tf, "peak_tflops": F32_PEAK_TFLOPS, "frac_f32": tf / F32_PEAK_TFLOPS,
-                      "source": "constants from profiles/: PMC SQ_INSTS_VALU per wave-unit x 64 lanes, FMA share from the opcode mix "
-                                "(profiles/r04_isa_histograms.txt); not an observation of this run"}
+                      "source": "PMC SQ_INSTS_VALU per wave-unit x 64 lanes read from %s; FMA share from the opcode mix "
+                                "(profiles/r04_isa_histograms.txt); not an observation of this run"
+                                % (", ".join(sorted({"profiles/" + KERNEL_VALU_SOURCE[k] for k in (stage.get("units_by_kernel") or {stage["kernel"]: 0})
+                                                     if k in KERNEL_VALU_SOURCE})) or "bench.py:KERNEL_VALU_FALLBACK (round 4)")}
         if fl / stage["bytes"] > RIDGE_FLOP_PER_BYTE:       # right of the ridge: the vector ALU's roof is the lower one
             r.update({"bound": "valu", "achieved": tf, "peak": F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / F32_PEAK_TFLOPS})
     if traffic is not None:
@@ -817,8 +941,23 @@ def main():
                 print(json.dumps(dict(line, dry_run=True)), flush=True)
             rdv.close()
             return
+        dry_extra = None
+        if world > 1 and args.workload == "full" and not args.no_extra:
+            def fake_run(wl, ch, sf, first, nsteps):               # the arithmetic of measure(): all ranks' units over the slowest rank's wall
+                own_wall = 1e-3 * (rank + 1)
+                if os.environ.get("SSDR_DRYRUN_FAIL_SETUP") == "%s:%d" % (wl, rank):
+                    ok = rdv.all_ok(False)
+                else:
+                    ok = rdv.all_ok(True)
+                if not ok:
+                    raise SetupFailed("%s: set-up failed on a rank (dry run)" % wl)
+                units = rdv.sum_over_ranks(ch) * sf * nsteps
+                w = rdv.max_over_ranks(own_wall)
+                return {"value": units / w / RT_SUPERFRAMES_PER_S, "ms_per_step": w / nsteps * 1e3, "own_value": ch * sf * nsteps / own_wall / RT_SUPERFRAMES_PER_S}
+            dry_extra = multi_rank_extras(rdv, rank, world, fake_run, lambda wl, fid, fused: fake(fid))
         if rank == 0:
             print(json.dumps({"metric": "real-time IQ channels sustained (WF+demod)", "value": None, "unit": "rt_channels",
+                              **({"extra": dry_extra} if dry_extra is not None else {}),
                               "n_gpus": world, "dry_run": True, "channels_total": int(total), "max_wall": wall, "parity": parity,
                               "config": {"workload": WORKLOAD_TEXT[args.workload], "channels_per_gpu": channels,
                                          "first_channel_ids": firsts, "rendezvous": rdv.backend if world > 1 else "none"}}), flush=True)
@@ -928,6 +1067,20 @@ def main():
         full["roofline_chain"] = {"kernel": "waterfall + audio stage", "bound": "hbm", "achieved": b / ms / 1e6, "peak": HBM_PEAK_GBPS,
                                   "unit": "GB/s", "frac": b / ms / 1e6 / HBM_PEAK_GBPS, "traffic": None, "avg_kernel_ms": ms,
                                   "algorithmic_bytes_per_launch": b}
+
+    if world > 1 and args.workload == "full" and not args.no_extra and not args.host_feed:
+        # the driver's single N > 1 command: after the weak-scaling `full` figure (which stays `value`, so N = 1 agrees with BENCH), every rank
+        # times configs[4] (its 2^20 / N block: the strong-scaling curve) and configs[3], same barrier / max-wall rule (review r5, item 1)
+        def run_one(wl, ch, sf, first, nsteps):
+            e = measure(S, L, torch, rdv, rank, world, local_rank, wl, ch, sf, nsteps, 2, 0.5, first_channel_id=first)
+            e["kernels"] = {k: {"kernel": v["kernel"], "ms": round(v["avg_ms"], 4), "frac_hbm": round(v["GBps"] / HBM_PEAK_GBPS, 4)} for k, v in e["stages"].items()}
+            return e
+        full["extra"] = multi_rank_extras(rdv, rank, world, run_one,
+                                          None if args.no_parity_probe else (lambda wl, fid, fused: parity_probe(S, local_rank, wl, fid, fused=fused)))
+        for k, v in full["extra"].items():
+            if "parity" in v and not v["parity"]["ranks_agree"]:
+                parity = dict(parity, ranks_agree=False, extra_mismatch=k)
+                full["parity"] = parity
 
     if rank == 0 and world == 1 and args.workload == "full" and not args.no_extra and not args.host_feed:
         extra = {}
@@ -1047,7 +1200,8 @@ def compact_line(full):
     out["parity"] = {k: p[k] for k in ("ranks_agree", "checksums", "skipped") if k in p}
     out["per_rank"] = {k: full["per_rank"][k] for k in ("value_min", "value_max")}
     r = full["roofline"]
-    out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_hbm", "traffic", "traffic_source",
+    out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_hbm", "frac_of_measured_stream", "measured_stream_GBps",
+                                          "measured_stream_mix", "measured_stream_source", "traffic", "traffic_source",
                                           "traffic_commit", "traffic_csrc_sha256", "traffic_matches_this_build", "avg_kernel_ms",
                                           "algorithmic_bytes_per_launch", "stages") if k in r}
     out["build"] = full.get("build")
@@ -1070,7 +1224,10 @@ def compact_line(full):
             if "error" in v:
                 out["extra"][k] = {"error": v["error"]}
             elif "value" in v:
-                out["extra"][k] = {kk: (round(v[kk], 4) if isinstance(v[kk], float) else v[kk]) for kk in ("value", "ms_per_step", "chain_frac") if kk in v}
+                out["extra"][k] = {kk: (round(v[kk], 4) if isinstance(v[kk], float) else v[kk])
+                                   for kk in ("value", "ms_per_step", "chain_frac", "scaling", "n_gpus", "channels_total", "channels_per_gpu", "kernels", "parity") if kk in v}
+                if "per_rank" in v:
+                    out["extra"][k]["per_rank"] = {kk: v["per_rank"][kk] for kk in ("value_min", "value_max", "values")}
             elif k == "ui_hub":
                 out["extra"][k] = {kk: (round(v[kk], 3) if isinstance(v[kk], float) else v[kk]) for kk in ("receivers", "ms_per_superframe_median", "ms_per_superframe_max", "real_time_ms")}
             elif k == "hub_feed":

@@ -92,6 +92,17 @@ class Rendezvous:
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
         return float(t.item())
 
+    def all_ok(self, ok):
+        """True when `ok` is true on EVERY rank (a MIN all-reduce: also a rendezvous).  What lets the ranks skip an optional
+        measurement together when one of them could not set it up, instead of the others waiting at a barrier it never reaches."""
+        if self._dist is None:
+            return bool(ok)
+        import torch
+        dev = self.device if (self.backend == "nccl" and self.device is not None) else "cpu"
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
     def sum_over_ranks(self, value):
         if self._dist is None:
             return float(value)

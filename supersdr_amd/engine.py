@@ -211,6 +211,27 @@ class SsdrEngine:
         check(lib.ssdr_copy_from_device(self._ctx, rssi.ctypes.data, r, rssi.nbytes), "ssdr_copy_from_device")
         return pcm, rssi
 
+    def fetch_rows(self, channels, lines):
+        """the device-resident results of the last run for a FEW channels, row by row (ssdr_copy_from_device) -- for batches whose
+        whole result arrays (64 GiB at 2^20 channels x 16 superframes) must not be copied back:
+        -> (wf int16 [lines, k, 1024], pcm int16 [k, n_frames*512], rssi float32 [k, n_frames])"""
+        ch = [int(c) for c in channels]
+        wf = np.empty((lines, len(ch), L.NFFT), np.int16)
+        pcm = np.empty((len(ch), self.audio_frames * L.FRAME), np.int16)
+        rssi = np.empty((len(ch), self.audio_frames), np.float32)
+        wptr, n, p, r = L._P(), C.c_uint32(0), L._P(), L._P()
+        check(lib.ssdr_wf_device(self._ctx, C.byref(wptr), C.byref(n)), "ssdr_wf_device")
+        check(lib.ssdr_audio_device(self._ctx, C.byref(p), C.byref(r)), "ssdr_audio_device")
+        if lines > n.value:
+            raise ValueError("the last run left %d lines, not %d" % (n.value, lines))
+        row_wf, row_pcm, row_rssi = L.NFFT * 2, self.audio_frames * L.FRAME * 2, self.audio_frames * 4
+        for i, c in enumerate(ch):
+            for ln in range(lines):
+                check(lib.ssdr_copy_from_device(self._ctx, wf[ln, i].ctypes.data, C.c_void_p(wptr.value + (ln * self.n_ch + c) * row_wf), row_wf), "ssdr_copy_from_device")
+            check(lib.ssdr_copy_from_device(self._ctx, pcm[i].ctypes.data, C.c_void_p(p.value + c * row_pcm), row_pcm), "ssdr_copy_from_device")
+            check(lib.ssdr_copy_from_device(self._ctx, rssi[i].ctypes.data, C.c_void_p(r.value + c * row_rssi), row_rssi), "ssdr_copy_from_device")
+        return wf, pcm, rssi
+
     def audio_flags(self):
         """-> uint8 [n_ch, n_frames]: the SND header's ADC-overflow bit (utils_supersdr.py:1066-1067) for every frame of the
         last run_audio."""

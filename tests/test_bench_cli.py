@@ -30,6 +30,45 @@ def test_gpus_2_starts_two_ranks_that_meet_and_shard():
     assert abs(d["max_wall"] - 2e-3) < 1e-9                       # MAX over ranks, not rank 0's own
 
 
+def check_multi_rank_extras(d, world):
+    """round 6: the driver's ONE `--gpus N` command also returns BASELINE configs[4] (2^20 channels over the ranks: the strong-scaling
+    curve) and configs[3], timed on every rank by the barrier / max-wall rule; `value` stays the weak-scaling `full` figure"""
+    ex = d["extra"]
+    assert set(ex) == {"million", "mixed"}
+    m, x = ex["million"], ex["mixed"]
+    assert m["scaling"] == "strong" and m["n_gpus"] == world and m["channels_total"] == 1 << 20
+    assert m["channels_per_gpu"] == [(1 << 20) // world] * world and m["first_channel_ids"] == [r * ((1 << 20) // world) for r in range(world)]
+    assert x["scaling"] == "weak" and x["channels_total"] == world * 65536 and x["channels_per_gpu"] == [65536] * world
+    for e, units in ((m, (1 << 20) * 16 * 5), (x, world * 65536 * 10 * 60)):
+        # all ranks' channel-superframes over the SLOWEST rank's wall (the dry run's rank r takes (r + 1) ms)
+        assert abs(e["value"] - units / (world * 1e-3) / 11.71875) < 1e-6 * e["value"]
+        assert len(e["per_rank"]["values"]) == world and e["per_rank"]["value_max"] == e["per_rank"]["values"][0]
+        assert abs(e["per_rank"]["value_min"] * world - e["value"]) < 1e-6 * e["value"]       # the slowest rank's own rate x N = the job's
+        assert e["parity"]["ranks_agree"] and e["parity"]["mismatching_ranks"] == []
+
+
+def test_two_ranks_also_time_the_million_channel_and_mixed_configurations():
+    p = run(["--gpus", "2", "--dry-run"])
+    assert p.returncode == 0, p.stderr
+    d = last_json(p)
+    check_multi_rank_extras(d, 2)
+    assert d["channels_total"] == 2 * 65536                       # the main figure is still the weak-scaling `full` one
+    # --no-extra and the other workloads: the main measurement only
+    assert "extra" not in last_json(run(["--gpus", "2", "--dry-run", "--no-extra"]))
+    assert "extra" not in last_json(run(["--gpus", "2", "--dry-run", "--workload", "mixed"]))
+    assert "extra" not in last_json(run(["--gpus", "1", "--dry-run"]))
+
+
+def test_a_rank_that_cannot_set_an_extra_up_makes_all_ranks_skip_it_together():
+    """one rank out of memory for configs[4] must not leave the others at a barrier: the set-up result is agreed (MIN all-reduce),
+    the extra is reported as an error, the next one runs, the line is printed and the exit code is 0"""
+    p = run(["--gpus", "3", "--dry-run"], {"SSDR_DRYRUN_FAIL_SETUP": "million:1"})
+    assert p.returncode == 0, p.stderr
+    d = last_json(p)
+    assert "error" in d["extra"]["million"] and "set-up failed" in d["extra"]["million"]["error"]
+    assert d["extra"]["mixed"]["channels_total"] == 3 * 65536 and d["extra"]["mixed"]["parity"]["ranks_agree"]
+
+
 def test_million_workload_is_strong_scaling_over_the_ranks():
     p = run(["--gpus", "3", "--dry-run", "--workload", "million"])
     assert p.returncode == 0, p.stderr
@@ -129,6 +168,19 @@ def test_eight_ranks_meet_over_gloo_shard_a_million_channels_and_close_the_parit
     assert d["config"]["rendezvous"] == "gloo" and d["parity"]["ranks_agree"]
     assert d["parity"]["first_channel_ids"] == [r * 131072 for r in range(8)] and len({tuple(c) for c in d["parity"]["checksums"]}) == 8
     assert abs(d["max_wall"] - 8e-3) < 1e-9
+
+
+def test_eight_ranks_under_the_drivers_command_return_both_scaling_curves():
+    """exactly the driver's N = 8 command line (default workload): the weak-scaling `full` figure plus extra.million / extra.mixed"""
+    port = 31500 + os.getpid() % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "8", "--steps", "20", "--warmup", "3", "--dry-run"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = last_json(p)
+    assert d["n_gpus"] == 8 and d["channels_total"] == 8 * 65536 and d["parity"]["ranks_agree"]
+    check_multi_rank_extras(d, 8)
 
 
 def test_hub_feed_line_sums_over_the_ranks():

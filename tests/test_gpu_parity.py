@@ -931,6 +931,56 @@ def test_parity_at_the_timed_shape_full_chain(S, twin):
     print("full chain at the timed shape vs the float64 oracle, 256 channels: PCM RMS max %.2e, %d of %d bins one step apart" % (rms.max(), (d > 0).sum(), d.size))
 
 
+@pytest.mark.parametrize("n_ch,first_id", [(1 << 20, 0), (131072, 7 * 131072)])
+def test_parity_at_configs4_timed_shape_through_the_fused_kernel(S, twin, n_ch, first_id):
+    """BASELINE configs[4] exactly as bench.py times it (review r5, weak #3): 2^20 channels x 16 superframes in ONE launch of the fused
+    kernel on one GPU (137 GB per launch: the > 4 Gi-element outputs, 64-bit indexing), and the per-rank shape of the 8-GPU run
+    (131 072 channels, the LAST rank's channel ids).  ssdr_run_chain must take the fused kernel; two steps on the same resident input
+    with carried state, as the bench's timed loop; a strided 64 channels incl. the last -- every waterfall line, PCM sample, RSSI float,
+    ADC flag and the carried state after each step -- bit-exact vs the twin, fetched row by row (nothing of the 64 GiB of results is
+    copied back whole); the checksum of ALL outputs equals a second fresh context's."""
+    sf = 16
+    sub = np.unique(np.concatenate([np.arange(0, n_ch, n_ch // 63 + 1)[:63], [n_ch - 1]]))
+    assert len(sub) == 64 and sub[-1] == n_ch - 1
+    period = 97
+    ps = [S.default_params("am", f_shift_hz=(((first_id + c) * 37) % 97 - 48) * 100.0) for c in range(period)]
+    big = ps * 40                                               # (97-channel parameter pattern, laid in runs of 3880)
+    sums, got = [], {}
+    for attempt in range(2):
+        with S.SsdrEngine(n_ch) as eng:
+            for first in range(0, n_ch, len(big)):
+                eng.set_params(first, big[: min(len(big), n_ch - first)])
+            eng.reset_state()
+            eng.synth_iq(2 * sf, seed=0x5D5D, first_channel_id=first_id)
+            assert eng.audio_paths() == (0, 0, n_ch)
+            if attempt == 0:
+                got["iq"] = np.stack([eng.read_input(int(c), 1)[0] for c in sub])
+                got["k"], got["t"] = (np.concatenate(x) for x in zip(*[eng.get_consts(int(c), 1) for c in sub]))
+            per_step = []
+            for step in range(2):
+                lines, fused = eng.run_chain()
+                assert fused == 1 and lines == sf               # the kernel the bench's `million` workload times
+                per_step.append(eng.output_checksum())
+                if attempt == 0:
+                    wf, pcm, rssi = eng.fetch_rows(sub, sf)
+                    flags = eng.audio_flags()
+                    st = [eng.get_state(int(c), 1) for c in sub]
+                    got[step] = (wf, pcm, rssi, flags[sub], np.concatenate([x[0] for x in st]), np.concatenate([x[1] for x in st]), bool(flags.any()))
+            sums.append(per_step)
+    assert sums[0] == sums[1]                                   # a second fresh ctx reproduces every output byte of both steps
+    k, t, iq = got["k"], got["t"], got["iq"]
+    assert (k["fir_flags"] & 1).all() and (k["mode"] == 0).all()
+    st, hist = twinlib.fresh_state(k)
+    wf_t = twin.wf(iq, 1, k["wf_cal_lin"])
+    for step in range(2):
+        wf, pcm, rssi, flags, st_g, hist_g, any_flag = got[step]
+        pcm_t, rssi_t, flags_t = twin.audio(iq, k, t, st, hist, want_flags=True)
+        assert np.array_equal(wf, wf_t), "waterfall lines, step %d" % step
+        assert np.array_equal(pcm, pcm_t) and np.array_equal(rssi, rssi_t) and np.array_equal(flags, flags_t), "audio, step %d" % step
+        assert st_g.tobytes() == st.tobytes() and np.array_equal(hist_g, hist), "carried state after step %d" % step
+        assert not any_flag and (np.abs(pcm).max(axis=1) > 1000).all() and (wf.max(axis=2) > 150).all()
+
+
 def test_checkpoint_restore_continues_bit_exactly(S):
     """ssdr_checkpoint_save / _load: a fresh ctx restored from the blob continues every stream bit for bit --
     NCO phases, FIR history, DC / AGC / discriminator memory, the waterfall's partial sums in the middle of an N = 3

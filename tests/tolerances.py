@@ -28,7 +28,8 @@ The rule's bound is the oracle's statement about itself; two things keep it hone
 (ABS_RMS_CEILING, over the samples off the discriminator's branch cut) that does not use the bound at all, and a test that the bound
 is tight -- the float64 chain run with its filter sums actually perturbed by EPS times their dot-product bound moves, at its worst sample, by most of
 what error_sensitivity predicts (0.9-1.0 in the test's channels), never by more (tests/test_oracle_known_answers.py::test_error_sensitivity_is_a_tight_bound).
-The figures of each sweep are kept in REPORT (printed with pytest -s): incl. how many channels fall outside the plain 1e-5.
+The figures of each sweep are kept in REPORT; how many channels fall outside the plain 1e-5 is GATED since round 6 (PLAIN_MISS_SHARE: at most 1 % of all the
+channels compared in a session) and written to gpurun_out/tolerance_report_{cpu,gpu}.json by tests/conftest.py.
 """
 import numpy as np
 
@@ -40,6 +41,9 @@ ABS_RMS_CEILING = 3e-3          # EVERY channel, however badly conditioned, over
                                 # 9600 channels of tests/random_params.py: largest value 2.6e-4; GPU soak, 394 sweeps / 27 024 channels incl. the
                                 # decimating front ends: largest 1.07e-3 (one D = 4 channel behind its 125 taps; profiles/r05_soak_parity.txt).
                                 # 0.4-0.5 % of the channels miss the plain 1e-5
+PLAIN_MISS_SHARE = 0.01         # GATE (round 6; it was a printout): over all the channels compared so far in this process (REPORT), at most 1 % may
+                                # miss north_star's PLAIN 1e-5 RMS -- plus three standard deviations of that share while the count is small
+                                # (96 channels: 3; 384: 9; 10 000: 129 = 1.3 %; the soaks measure 0.4-0.5 %).  assert_share_outside_plain()
 EPS = 2.0 ** -20
 WELL_FRACTION = 0.8            # of a random sweep, expected (measured: 0.84); min_well_for(n) is four sigma under it
 REPORT = []                     # one dict per sweep
@@ -61,6 +65,41 @@ def rssi_well_conditioned(iq, rssi_o, smeter_cal_db):
 def oracle_with_bound(iq, params, decim=1, rate=O.RATE):
     """(pcm_o, rssi_o, bound): the float64 chain and, per sample, how far a backward-stable fp32 evaluation may lie from it"""
     return O.audio_chain_with_bound(iq, params, EPS, decim, rate)
+
+
+def share_outside_plain(report=None):
+    """-> (channels, how many of them miss the plain 1e-5 RMS, the number the gate allows) over the sweeps recorded so far"""
+    rep = REPORT if report is None else report
+    n = sum(r["channels"] for r in rep)
+    out = sum(r["outside_plain_tolerance"] for r in rep)
+    allowed = int(np.floor(PLAIN_MISS_SHARE * n + 3.0 * np.sqrt(PLAIN_MISS_SHARE * (1.0 - PLAIN_MISS_SHARE) * n)))
+    return n, out, allowed
+
+
+def assert_share_outside_plain(report=None, strict_above=5000):
+    """the gate: the share of channels that miss north_star's plain figure stays at or under 1 % (from `strict_above` channels on without
+    the small-sample allowance)"""
+    n, out, allowed = share_outside_plain(report)
+    if n >= strict_above:
+        allowed = int(np.floor(PLAIN_MISS_SHARE * n))
+    assert out <= allowed, ("too many channels outside the plain 1e-5 RMS", out, "of", n, "allowed", allowed)
+    return n, out, allowed
+
+
+def write_report(path, report=None):
+    """REPORT + its totals as JSON (tests/conftest.py writes gpurun_out/tolerance_report_*.json at the end of a session)"""
+    import json
+    import os
+    rep = REPORT if report is None else report
+    n, out, allowed = share_outside_plain(rep)
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    with open(path, "w") as f:
+        json.dump({"north_star_plain_tolerance_rms": PCM_RMS_TOL, "channels": n, "outside_plain_tolerance": out,
+                   "share_outside_plain_tolerance": (out / n) if n else None, "gate": "<= %g of the channels (+ 3 sigma while n < 5000)" % PLAIN_MISS_SHARE,
+                   "allowed_at_this_count": allowed, "well_conditioned": sum(r["well_conditioned"] for r in rep),
+                   "largest_rms_of_any_channel_off_the_branch_cut": max((r["rms_all_channels_off_the_branch_cut_max"] for r in rep), default=None),
+                   "largest_untrimmed_rms_of_a_well_conditioned_channel": max((r["untrimmed_max_well"] for r in rep), default=None),
+                   "absolute_ceiling": ABS_RMS_CEILING, "eps": EPS, "sweeps": rep}, f, indent=1)
 
 
 def assert_pcm_within_tolerance(pcm, pcm_o, bound, min_well=None, what=""):
@@ -92,4 +131,5 @@ def assert_pcm_within_tolerance(pcm, pcm_o, bound, min_well=None, what=""):
     assert over.max() < 0.0, ("channel RMS beyond its bound", int(np.argmax(over)), float(rms[np.argmax(over)]), float(brms[np.argmax(over)]))
     assert rms[well].max(initial=0.0) < PCM_RMS_TOL, (int(np.argmax(rms * well)), float((rms * well).max()))
     assert rms_abs.max() < ABS_RMS_CEILING, ("channel beyond the absolute ceiling", int(np.argmax(rms_abs)), float(rms_abs.max()))
+    assert_share_outside_plain()                                # cumulative over this process's sweeps: a gate, not a printout
     return well, rms

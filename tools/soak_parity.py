@@ -79,6 +79,13 @@ def run_sweeps(a, sweeps, T):
             out = sum(r["outside_plain_tolerance"] for r in rep)
             lines.append("channels outside the plain 1e-5 RMS: %d of %d (%.1f %%); largest RMS of ANY channel over its samples off the branch cut: %.2e"
                          % (out, chans, 100.0 * out / max(chans, 1), max(r["rms_all_channels_off_the_branch_cut_max"] for r in rep)))
+        try:                                                       # the gate of tests/tolerances.py on the soak's own total (no small-sample allowance)
+            n, out, allowed = T.assert_share_outside_plain(rep, strict_above=0)
+            lines.append("gate: at most %.0f %% of the channels outside the plain 1e-5 RMS -- %d of %d, %d allowed: ok" % (100 * T.PLAIN_MISS_SHARE, out, n, allowed))
+        except AssertionError as e:
+            bad += 1
+            lines.append("GATE FAILED: %r" % (e.args,))
+        T.write_report(os.path.join(os.path.dirname(a.out) if a.out else os.path.join(ROOT, "gpurun_out"), "tolerance_report_soak.json"), rep)
     text = "\n".join(lines) + "\n"
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
