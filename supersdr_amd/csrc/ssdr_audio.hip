@@ -25,19 +25,6 @@
 //   * store: 8 int16 = 16 B per lane, 1 KB contiguous per wave
 #include "ssdr_audio_dev.h"
 
-#ifndef SSDR_AUDIO_PREFETCH
-#define SSDR_AUDIO_PREFETCH 0
-#endif
-// A/B only (profiles/README.md, round 3): the general path's FIR as a banded-Toeplitz product on the f32 matrix instruction
-// v_mfma_f32_4x4x1_16b_f32 instead of v_fmac chains.  Bit-identical (an f32 MFMA is a k-ordered fmaf chain; zero taps are
-// exact no-ops), and not faster: on gfx950 the f32 MFMA executes at the vector FMA rate and its time ADDS to the VALU's
-// on the same SIMD (tools/ubench/mfma_overlap.hip).  Off in the shipped library.
-#ifndef SSDR_FIR_MFMA
-#define SSDR_FIR_MFMA 0
-#endif
-constexpr int TT_S = 144;                       // row stride of the per-lane-class tap table of the MFMA form
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 namespace {
 
 enum { PATH_GENERAL = SSDR_PATH_GENERAL, PATH_DELAY4 = SSDR_PATH_DELAY4, PATH_AM_RAW = SSDR_PATH_AM_RAW };
@@ -76,21 +63,12 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
     float2 tail_z[4];                                   // PATH_DELAY4: mixed samples -4..-1 (wave-uniform)
     uint32_t tail_q[4];                                 // PATH_AM_RAW: I*I + Q*Q of samples -4..-1 (wave-uniform)
     if constexpr (PATH == PATH_GENERAL) {
-#if SSDR_FIR_MFMA
-        // MFMA form: block b of the instruction = lanes 4b..4b+3 = outputs (8 lane + 4 half + i), i = lane & 3.  Step s feeds
-        // sample (newest - s) as B and tap h[i + s - 3] as A: row s of a table per i, TT[i][s] (zero outside the taps).
-        for (int idx = l; idx < 4 * TT_S; idx += 64) {
-            const int i = idx / TT_S, t = i + (idx - i * TT_S) - 3;
-            s_taps[idx] = (t >= 0 && t < SSDR_NTAP_MAX) ? a.taps[(size_t)ch * SSDR_NTAP_MAX + t] : 0.0f;
-        }
-#else
         {   // the channel's taps go to LDS once; the FIR reads them back as broadcasts
             const float2 t = reinterpret_cast<const float2 *>(a.taps + (size_t)ch * SSDR_NTAP_MAX)[l];
             s_taps[2 * l] = t.x;
             s_taps[2 * l + 1] = t.y;
             if (l < 8) s_taps[SSDR_NTAP_MAX + l] = 0.0f;
         }
-#endif
         // history z1[-128..-1]: re-mix the raw tail kept in HBM exactly as the previous frame mixed it
         // (block t of the tail was block 48+t of that frame): lanes 0..15, one octet each
         if (l < HOCT) {
@@ -129,13 +107,6 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
     float *rssi_row = a.rssi + (uint64_t)ch * a.n_frames;
     uint8_t *flag_row = a.flags + (uint64_t)ch * a.n_frames;
     u32x4 raw0, raw1;
-#if SSDR_AUDIO_PREFETCH
-    u32x4 nxt0 = {0, 0, 0, 0}, nxt1 = {0, 0, 0, 0};
-    if (a.n_frames) {
-        nxt0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src));
-        nxt1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src) + 1);
-    }
-#endif
     float rssi_sum = 0.0f;
     uint32_t flag_keep = 0;
 
@@ -144,18 +115,8 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
             if constexpr (PATH != PATH_AM_RAW) nco_frame_table(n1, phi1, l);
             if constexpr (PATH != PATH_AM_RAW) if (mode >= SSDR_MODE_LSB && mode <= SSDR_MODE_CW) nco_frame_table(n2, phi2, l);
         }
-#if SSDR_AUDIO_PREFETCH
-        // the next frame's 2 KB are requested before this frame's arithmetic starts: their HBM latency hides under it
-        raw0 = nxt0;
-        raw1 = nxt1;
-        if (f + 1 < a.n_frames) {
-            nxt0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + SSDR_FRAME));
-            nxt1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + SSDR_FRAME) + 1);
-        }
-#else
         raw0 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src));
         raw1 = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src) + 1);
-#endif
         const uint32_t rw[8] = {raw0.x, raw0.y, raw0.z, raw0.w, raw1.x, raw1.y, raw1.z, raw1.w};
         float p[8], aud[8];
         float yr[8], yi[8];                                 // the channel filter's output (unused on the full-band AM path)
@@ -212,40 +173,6 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
                 // 1. NCO mix of this lane's 8 samples -> LDS
                 store_oct(s_z, HOCT + l, A);
                 lds_sync();
-#if SSDR_FIR_MFMA
-                // 2. FIR on the matrix instruction.  d = distance of a sample from the lane's newest (sample 8l+7-d), walked
-                //    upwards = taps ascending for every output; outputs 4..7 (acc1) take table row d, outputs 0..3 (acc0) row d-4.
-                {
-                    f32x4 a1r = {0, 0, 0, 0}, a1i = {0, 0, 0, 0}, a0r = {0, 0, 0, 0}, a0i = {0, 0, 0, 0};
-                    const f32x4 *tt = reinterpret_cast<const f32x4 *>(s_taps + (l & 3) * TT_S);
-                    const uint32_t nq = (kc.ntap + 6) >> 2;              // row groups of four that hold a tap: rows 0 .. ntap+2
-                    f32x4 tprev = {0, 0, 0, 0};
-                    for (uint32_t o = 0; 2 * o <= nq; o++) {             // octet o = samples 8(l-o) .. 8(l-o)+7
-                        if (o) load_oct(s_z, HOCT + l - (int)o, A);
-#pragma unroll
-                        for (int hh = 0; hh < 2; hh++) {
-                            const uint32_t g = 2 * o + hh;
-                            if (g > nq) break;                            // wave-uniform
-                            const f32x4 tcur = tt[g];                     // rows 4g..4g+3 (zero beyond the taps)
-#pragma unroll
-                            for (int k = 0; k < 4; k++) {
-                                const float2 v = A[7 - 4 * hh - k];
-                                if (g < nq) {
-                                    a1r = __builtin_amdgcn_mfma_f32_4x4x1f32(tcur[k], v.x, a1r, 0, 0, 0);
-                                    a1i = __builtin_amdgcn_mfma_f32_4x4x1f32(tcur[k], v.y, a1i, 0, 0, 0);
-                                }
-                                if (g) {
-                                    a0r = __builtin_amdgcn_mfma_f32_4x4x1f32(tprev[k], v.x, a0r, 0, 0, 0);
-                                    a0i = __builtin_amdgcn_mfma_f32_4x4x1f32(tprev[k], v.y, a0i, 0, 0, 0);
-                                }
-                            }
-                            tprev = tcur;
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { yr[j] = a0r[j]; yi[j] = a0i[j]; yr[4 + j] = a1r[j]; yi[4 + j] = a1i[j]; }
-                }
-#else
                 // 2. FIR: y[n] = sum_k h[k] z1[n-k], k ascending, fma chain from zero.  Blocks of 8 taps go in pairs with
                 //    the two register octets swapping roles (newer, older) -> (older, newer), so no window is ever copied.
 #pragma unroll
@@ -273,7 +200,6 @@ SSDR_DEV void channel_frames(const SsdrAudioArgs &a, const uint32_t ch, const in
                         a_oct = b + 2;
                     }
                 }
-#endif
             }
             // 3. power, demodulation
 #pragma unroll
@@ -601,7 +527,7 @@ __global__ __launch_bounds__(SSDR_AUDIO_BLOCK) __attribute__((amdgpu_waves_per_e
 {
     constexpr bool FIR = PATH == PATH_GENERAL;
     __shared__ __attribute__((aligned(16))) float2 s_z[FIR ? NOCT * OCT : 1];            // 6400 B
-    __shared__ __attribute__((aligned(16))) float s_taps[FIR ? (SSDR_FIR_MFMA ? 4 * TT_S : SSDR_NTAP_MAX + 8) : 1];   // + one block of padding for odd block counts
+    __shared__ __attribute__((aligned(16))) float s_taps[FIR ? SSDR_NTAP_MAX + 8 : 1];   // + one block of padding for odd block counts
     const int l = threadIdx.x;
     if (blockIdx.x >= a.list_n) return;
     const uint32_t ch = a.chan_list[blockIdx.x];

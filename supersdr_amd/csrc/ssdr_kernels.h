@@ -10,9 +10,6 @@
 #ifndef SSDR_WF_WAVES_PER_EU
 #define SSDR_WF_WAVES_PER_EU 4
 #endif
-#ifndef SSDR_WF_ABLATE
-#define SSDR_WF_ABLATE 0                     // profiling ablations only (1 memory-only, 2 no loads, 3 no stores)
-#endif
 #define SSDR_TW_STAGE_N 992                  // per-stage twiddle table entries: 32*(1+2+4+8+16)
 // dB quantiser table: one 32-bit word per quarter-octave segment of [0, 1] (0.75 dB < 1 dB: at most one threshold
 // inside a segment), indexed by bits(p') >> (23 - SSDR_LUT_BITS) where p' = p * 2^-48 clamped to [0, 1] (the top

@@ -28,20 +28,6 @@
 #include "ssdr_math.h"
 #include "ssdr_kernels.h"
 #include "ssdr_audio_dev.h"
-
-#ifndef SSDR_FUSED_ABLATE
-#define SSDR_FUSED_ABLATE 0                  // timing ablations of the fused kernel only (1: no FFT, 2: no audio chain)
-#endif
-#ifndef SSDR_FUSED_WIDE_LOADS
-#define SSDR_FUSED_WIDE_LOADS 1              // the fused kernel fetches a line 16 bytes per lane (A/B: 0 = 4 bytes per lane in the FFT's layout)
-#endif
-#ifndef SSDR_WF_PAIR_MAJOR
-#define SSDR_WF_PAIR_MAJOR 0
-#endif
-#ifndef SSDR_WF_BLOCKED_ITEMS
-#define SSDR_WF_BLOCKED_ITEMS 0              // A/B: each wave takes a contiguous range of work items instead of a strided one
-#endif
-
 #include "ssdr_wf_dev.h"
 
 namespace {
@@ -66,21 +52,14 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
     const uint32_t n_pairs = (a.n_ch + 1) >> 1;
     // work items: hop 1024 -- one (group, channel pair) each, group-major; hop 512 -- a run of a.grp_run consecutive groups
     // of a channel pair, pair-major: the wave walks the pair's lines in order
-    const uint32_t run = (HOP || SSDR_WF_PAIR_MAJOR) ? a.grp_run : 1u;
+    const uint32_t run = HOP ? a.grp_run : 1u;
     const uint32_t n_runs = (a.n_groups + run - 1) / run;
     const uint32_t n_items = n_pairs * n_runs;
     const uint32_t wave_stride = gridDim.x * WAVES;
 
-#if SSDR_WF_BLOCKED_ITEMS
-    const uint32_t per_wave = (n_items + wave_stride - 1) / wave_stride;
-    const uint32_t item_begin = (blockIdx.x * WAVES + wave) * per_wave;
-    const uint32_t item_end = min(item_begin + per_wave, n_items);
-    for (uint32_t item = item_begin; item < item_end; item++) {
-#else
     for (uint32_t item = blockIdx.x * WAVES + wave; item < n_items; item += wave_stride) {
-#endif
       uint32_t pair, g_begin, g_end;
-      if (HOP || SSDR_WF_PAIR_MAJOR) {
+      if (HOP) {
           pair = item / n_runs;
           g_begin = (item - pair * n_runs) * run;
           g_end = min(g_begin + run, a.n_groups);
@@ -89,7 +68,7 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
           pair = item - g_begin * n_pairs;
           g_end = g_begin + 1;
       }
-      const uint32_t n_trips = (HOP || SSDR_WF_PAIR_MAJOR) ? g_end - g_begin : 1u;
+      const uint32_t n_trips = HOP ? g_end - g_begin : 1u;
       for (uint32_t trip = 0; trip < n_trips; trip++) {
         const uint32_t grp = g_begin + trip;
         uint32_t pair_now = __builtin_amdgcn_readfirstlane(pair);   // everything derived from the pair is recomputed per group
@@ -105,18 +84,8 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
         for (uint32_t line = it.l0; line < it.l1; line++, src += LINE_STEP) {
             f32x2 z[32];
             uint32_t raw[32];
-#if SSDR_WF_ABLATE == 2      // ablation: no global loads
-#pragma unroll
-            for (int r = 0; r < 32; r++) raw[r] = (uint32_t)(line * 2654435761u + r * 40503u + lane * 97u) & 0x1FFF1FFFu;
-#else
             if (HOP) load_line_halves(line ? src - SSDR_NFFT / 2 : a.tail + (uint64_t)it.ch * (SSDR_NFFT / 2) + l, src, raw);
             else load_line(src, raw);
-#endif
-#if SSDR_WF_ABLATE == 1      // ablation: memory traffic only
-            int16_t *x16 = reinterpret_cast<int16_t *>(xch_wave + opaque(h) * XCH_FLOATS) + opaque(l);
-#pragma unroll
-            for (int j = 0; j < 32; j++) x16[32 * ((j + 16) & 31)] = (int16_t)(raw[j] & 0xFF);
-#else
             if (SSDR_PRIO_WF) prio_compute_phase();
             window_line(raw, smem, l, z);
             SCHED_FENCE();
@@ -136,7 +105,6 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_wf_k
                     x16[32 * j] = (int16_t)(q[j] >> 16);
                 }
             }
-#endif
         }
 
         float *xch = xch_wave + opaque(h) * XCH_FLOATS;
@@ -251,7 +219,6 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
             // channel at a time (8 load and 8 LDS store instructions per line pair instead of 32 and 16).  The audio chain reads them back
             // eight consecutive samples per lane, the FFT takes them out of the LDS in its own layout afterwards: one read from HBM
             // (streaming), none from the L2, and no 32 registers held across the audio chain.
-#if SSDR_FUSED_WIDE_LOADS
             {
                 const uint32_t lw = opaque(lane);
                 u32x4 t[2][4];
@@ -279,23 +246,11 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
                     for (int i = 0; i < 4; i++) reinterpret_cast<u32x4 *>(qbuf + c * XCH_FLOATS)[64 * i + lw] = t[c][i];
                 SCHED_FENCE();
             }
-#else
-            {
-                uint32_t *q = qbuf + opaque(h) * XCH_FLOATS + opaque(l);
-                uint32_t t[32];                     // all 32 loads in flight, then the stores: left alone the compiler issues
-                if (HOP) load_line_halves(line ? src - SSDR_NFFT / 2 : a.tail + (uint64_t)ch * (SSDR_NFFT / 2) + l, src, t);
-                else load_line(src, t);             // load, wait, store one sample at a time -- 32 round trips to memory per line
-                SCHED_FENCE();
-#pragma unroll
-                for (int r = 0; r < 32; r++) q[32 * r] = t[r];
-                SCHED_FENCE();
-            }
-#endif
             wave_lds_sync();
             // ---- audio, phase 2: channel A, then channel B, two frames each, all 64 lanes on one channel
             prio_latency_phase();                                             // (the call's first line; later ones arrive with it)
 #pragma unroll
-            for (int c = 0; c < (SSDR_FUSED_ABLATE == 2 ? 0 : 2); c++) {      // (timing ablation 2: no audio chain)
+            for (int c = 0; c < 2; c++) {
                 if ((uint32_t)c >= n_sub) continue;                           // wave-uniform
                 uint32_t pair_now = __builtin_amdgcn_readfirstlane(pair);     // per line: the channel's constants and output rows are
                 asm volatile("" : "+s"(pair_now));                              // fetched again (scalar loads) rather than kept across the FFT
@@ -360,10 +315,6 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
             }
             last_raw31 = raw[31];
             uint32_t qn[16];
-#if SSDR_FUSED_ABLATE == 1              // timing ablation: no FFT (the audio phase, the loads and the stores remain)
-#pragma unroll
-            for (int j = 0; j < 16; j++) qn[j] = raw[j] ^ raw[j + 16];
-#else
             f32x2 z[32];
             window_line(raw, smem, l, z);
             SCHED_FENCE();
@@ -371,7 +322,6 @@ __global__ __launch_bounds__(SSDR_WF_BLOCK, SSDR_WF_WAVES_PER_EU) void ssdr_fuse
             prio_latency_phase();                             // quantiser look-ups, the line's store, the next line's loads and audio phase
             if (AVG) quantise32(z, cal_wf, lut, [&](int j, uint32_t q01) { acc[j] += q01; });
             else quantise32(z, cal_wf, lut, [&](int j, uint32_t q01) { qn[j] = q01; });
-#endif
             // AVG: line `line` is line (phase + line) of the stream of groups; a group leaves when its N-th line is in, the last
             // (partial) one of the call goes to acc_out
             const uint32_t pos = a.phase + line;
