@@ -68,18 +68,17 @@ struct ssdr_ctx {
     uint32_t *d_hist = nullptr;
     std::vector<ssdr_chan_consts> h_consts;             // host mirror of d_consts
     uint32_t *d_chan_list = nullptr;                    // channels sorted by audio frame path (ssdr_audio_path)
+    uint32_t *d_ws_list = nullptr;                      // [n_ch] + 1 ticket word: the same channels as pairs, the paths interleaved (ssdr_chain_ws_kernel)
     uint32_t path_off[SSDR_PATH_COUNT] = {}, path_n[SSDR_PATH_COUNT] = {};
     bool chan_list_dirty = true;
     bool summary_dirty = true;                          // path counts / any channel in IQ mode: recounted after the constants change
     uint32_t sum_paths[SSDR_PATH_COUNT] = {0, 0, 0};
     bool sum_any_iq = false;
-    uint32_t sum_gen_ntap = 0;                          // the longest channel filter among the general-path channels
     hipStream_t path_stream[SSDR_PATH_COUNT - 1] = {};  // the audio kernels of different paths run side by side
     hipEvent_t ev_fork = nullptr, ev_path[SSDR_PATH_COUNT - 1] = {};
-    int fused_enabled = 1;                              // ssdr_set_fused: 0 never, 1 at hop 1024 (default), 2 at hop 512 as well, 3 + the general-mode kernel
-    bool fuse_gen_next = false;                         // ... and that kernel is ssdr_fused_gen_kernel (any mix of audio paths)
-    uint32_t gen_grid = 0;
-    uint32_t *d_gen_park = nullptr;                     // [gen_grid * waves][16][64]: the N-line sums of ssdr_fused_gen_kernel<AVG> while its audio phases run
+    int fused_enabled = 1;                              // ssdr_set_fused: 0 never, 1 at hop 1024 (default), 2 at hop 512 as well, 3 + the wave-specialised kernel
+    bool fuse_ws_next = false;                          // ... and that kernel is ssdr_chain_ws_kernel (any mix of audio paths)
+    uint32_t ws_grid = 0;
     bool overlap_enabled = true;                        // ssdr_set_overlap: un-fused ssdr_run_chain batches run the audio stage beside the waterfall kernel
     bool fuse_next = false;                             // ssdr_run_chain: run_wf parks its arguments, run_audio launches the fused kernel
     SsdrWfArgs fused_wf;
@@ -263,10 +262,10 @@ void ssdr_destroy(ssdr_ctx *c)
     (void)hipSetDevice(c->device);
     (void)ssdr_feed_close(c);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-    void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_wf_tail, c->d_wf_acc[0], c->d_wf_acc[1],
+    void *ptrs[] = {c->d_win, c->d_thr, c->d_tw, c->d_lut, c->d_consts, c->d_taps, c->d_state, c->d_hist, c->d_chan_list, c->d_ws_list, c->d_wf_tail, c->d_wf_acc[0], c->d_wf_acc[1],
                     c->d_iq_own, c->d_wf_out, c->d_pcm, c->d_rssi, c->d_flags, c->d_scratch, c->d_db2col, c->d_color, c->d_play,
                     c->d_play_taps, c->d_play_hist, c->d_play_hist_alt, c->d_play_rs_taps, c->d_play_out, c->d_wfdata, c->d_wfpend, c->d_trace, c->d_trace_y, c->d_smeter,
-                    c->d_smeter_in, c->d_post_sel, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64, c->d_wire_gps, c->d_iq_out, c->d_zoom_taps, c->d_zoom_dphi, c->d_zoom_phase, c->d_zoom_hist, c->d_zoom_out, c->d_gen_park};
+                    c->d_smeter_in, c->d_post_sel, c->d_wire, c->d_wire_rssi, c->d_play_mono, c->d_line1, c->d_dbchan1, c->d_color1, c->d_tw64, c->d_wire_gps, c->d_iq_out, c->d_zoom_taps, c->d_zoom_dphi, c->d_zoom_phase, c->d_zoom_hist, c->d_zoom_out};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -433,6 +432,7 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         HIP_TRY(hipMalloc(&c->d_taps, (size_t)n_channels * SSDR_NTAP_MAX * sizeof(float)));
         HIP_TRY(hipMalloc(&c->d_state, (size_t)n_channels * sizeof(ssdr_chan_state)));
         HIP_TRY(hipMalloc(&c->d_chan_list, (size_t)n_channels * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&c->d_ws_list, ((size_t)n_channels + 1) * sizeof(uint32_t)));
         c->h_consts.resize(n_channels);
         c->h_params.resize(n_channels);
         HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -466,9 +466,9 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         int fused_per_cu = 0;
         HIP_TRY(ssdr_fused_blocks_per_cu(&fused_per_cu));
         c->fused_grid = (uint32_t)prop.multiProcessorCount * (uint32_t)(fused_per_cu < 1 ? 1 : fused_per_cu);
-        int gen_per_cu = 0;
-        HIP_TRY(ssdr_fused_gen_blocks_per_cu(&gen_per_cu));
-        c->gen_grid = (uint32_t)prop.multiProcessorCount * (uint32_t)(gen_per_cu < 1 ? 1 : gen_per_cu);
+        int ws_per_cu = 0;
+        HIP_TRY(ssdr_chain_ws_blocks_per_cu(&ws_per_cu));
+        c->ws_grid = (uint32_t)prop.multiProcessorCount * (uint32_t)(ws_per_cu < 0 ? 0 : ws_per_cu);     // 0: not resident on this device, never chosen
         return SSDR_OK;
     }();
     if (rc == SSDR_OK) {
@@ -734,12 +734,10 @@ static void chan_summary(ssdr_ctx *c)
     if (!c->summary_dirty) return;
     for (int p = 0; p < SSDR_PATH_COUNT; p++) c->sum_paths[p] = 0;
     c->sum_any_iq = false;
-    c->sum_gen_ntap = 0;
     for (uint32_t ch = 0; ch < c->n_ch; ch++) {
         const int path = ssdr_audio_path(c->h_consts[ch]);
         c->sum_paths[path]++;
         c->sum_any_iq = c->sum_any_iq || c->h_consts[ch].mode == SSDR_MODE_IQ;
-        if (path == SSDR_PATH_GENERAL) c->sum_gen_ntap = std::max(c->sum_gen_ntap, c->h_consts[ch].ntap);
     }
     c->summary_dirty = false;
 }
@@ -758,6 +756,29 @@ static int ensure_chan_list(ssdr_ctx *c, hipStream_t s)
         cnt[p] = pos - off[p];
     }
     HIP_TRY(hipMemcpyAsync(c->d_chan_list, list.data(), (size_t)c->n_ch * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    // the chain list of the wave-specialised kernel: consecutive channels of the sorted list form pairs (so a pair is of one path,
+    // except where two paths meet); the pairs of the three paths are dealt out evenly over the list -- pair m of a path with p pairs
+    // sits at (m + 1/2) / p of the way -- so that at any time the trios of a workgroup work on the ctx's mix of paths
+    std::vector<uint32_t> ws(c->n_ch);
+    {
+        const uint32_t n_pairs = (c->n_ch + 1) / 2;
+        std::vector<uint32_t> first_of[SSDR_PATH_COUNT];                   // pairs by the path of their first channel
+        for (uint32_t j = 0; j < n_pairs; j++) first_of[ssdr_audio_path(c->h_consts[list[2 * j]])].push_back(j);
+        std::vector<std::pair<double, uint32_t>> order;
+        order.reserve(n_pairs);
+        for (int p = 0; p < SSDR_PATH_COUNT; p++)
+            for (size_t m = 0; m < first_of[p].size(); m++)
+                if (first_of[p][m] != n_pairs - 1 || !(c->n_ch & 1u))          // (a single last channel stays the list's last pair)
+                    order.emplace_back(((double)m + 0.5) / (double)first_of[p].size(), first_of[p][m]);
+        std::stable_sort(order.begin(), order.end(), [](const std::pair<double, uint32_t> &x, const std::pair<double, uint32_t> &y) { return x.first < y.first; });
+        if (c->n_ch & 1u) order.emplace_back(2.0, n_pairs - 1);
+        uint32_t w = 0;
+        for (const auto &o : order) {
+            ws[w++] = list[2 * o.second];
+            if (2 * o.second + 1 < c->n_ch) ws[w++] = list[2 * o.second + 1];
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(c->d_ws_list, ws.data(), (size_t)c->n_ch * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     HIP_TRY(hipStreamSynchronize(s));    // `list` goes out of scope
     for (int p = 0; p < SSDR_PATH_COUNT; p++) { c->path_off[p] = off[p]; c->path_n[p] = cnt[p]; }
     c->chan_list_dirty = false;
@@ -1007,19 +1028,18 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         SsdrFusedArgs fa;
         fa.wf = c->fused_wf;
         fa.au = a;
-        fa.park = nullptr;
-        if (c->fuse_gen_next) {
-            if (!c->d_gen_park) HIP_TRY(hipMalloc(&c->d_gen_park, (size_t)c->gen_grid * (SSDR_GEN_BLOCK / 64) * 16 * 64 * 4));
-            fa.park = c->d_gen_park;
-        }
+        fa.au.chan_list = c->d_ws_list;        // (the wave-specialised kernel draws pairs from its own list of all channels)
+        fa.au.list_n = c->n_ch;
+        fa.ticket = c->d_ws_list + c->n_ch;
+        if (c->fuse_ws_next) HIP_TRY(hipMemsetAsync(fa.ticket, 0, sizeof(uint32_t), s));
         const uint64_t pairs = (c->n_ch + 1) / 2;
         const uint64_t need = (pairs + SSDR_WF_BLOCK / 64 - 1) / (SSDR_WF_BLOCK / 64);
         const uint32_t grid = (uint32_t)(need < c->fused_grid ? need : c->fused_grid);
         if ((rc = timed_begin(c, s)) != SSDR_OK) return rc;
-        if (c->fuse_gen_next) {
-            const uint64_t need_g = (pairs + SSDR_GEN_BLOCK / 64 - 1) / (SSDR_GEN_BLOCK / 64);
-            const uint32_t grid_g = (uint32_t)(need_g < c->gen_grid ? need_g : c->gen_grid);
-            HIP_TRY(ssdr_launch_fused_gen(fa, grid_g ? grid_g : 1, s));
+        if (c->fuse_ws_next) {
+            const uint64_t need_g = ((uint64_t)c->n_ch + SSDR_WS_AUDIO_WAVES - 1) / SSDR_WS_AUDIO_WAVES;
+            const uint32_t grid_g = (uint32_t)(need_g < c->ws_grid ? need_g : c->ws_grid);
+            HIP_TRY(ssdr_launch_chain_ws(fa, grid_g ? grid_g : 1, s));
         } else if (c->exact_bins) HIP_TRY(ssdr_launch_fused_exact_am(fa, c->d_tw64, s));
         else HIP_TRY(ssdr_launch_fused_am(fa, grid ? grid : 1, s));
         if ((rc = timed_end(c, SSDR_K_FUSED, s)) != SSDR_OK) return rc;
@@ -1088,14 +1108,13 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused) SSDR_GUARD
                           c->in_frames >= 8 &&
                           !c->concurrent && c->fused_grid != 0 && c->fused_enabled >= ((hop512 || c->n_avg > 1) ? 2 : 1) && c->zoom == 1 &&
                           (!c->exact_bins || (!hop512 && c->n_avg == 1));
-    // the general-mode kernel (ssdr_fused_gen.hip; ssdr_set_fused(ctx, 3)): any mix of audio paths and any N at hop 1024, channel filters of
-    // up to 33 taps, no SSDR_MODE_IQ channel (its second output row), fp32 bins
-    const bool eligible_gen = !eligible && c->fused_enabled >= 3 && c->gen_grid != 0 && c->decim == 1 && !hop512 && !(c->in_frames & 1u) &&
-                              c->in_frames >= 4 && !c->concurrent && c->zoom == 1 && !c->exact_bins && !c->sum_any_iq &&
-                              c->sum_gen_ntap <= SSDR_GEN_NTAP_MAX;
-    if (fused) *fused = eligible ? 1 : (eligible_gen ? 2 : 0);
-    c->fuse_next = eligible || eligible_gen;
-    c->fuse_gen_next = eligible_gen;
+    // the wave-specialised kernel (ssdr_chain_ws.hip; ssdr_set_fused(ctx, 3)): any mix of audio paths, any filter and any N at hop 1024,
+    // fp32 bins
+    const bool eligible_ws = !eligible && c->fused_enabled >= 3 && c->ws_grid != 0 && c->decim == 1 && !hop512 && !(c->in_frames & 1u) &&
+                             !c->concurrent && c->zoom == 1 && !c->exact_bins;
+    if (fused) *fused = eligible ? 1 : (eligible_ws ? 2 : 0);
+    c->fuse_next = eligible || eligible_ws;
+    c->fuse_ws_next = eligible_ws;
     {   // both stages or neither: what ssdr_run_wf and ssdr_run_audio would refuse is refused before either is launched
         int rcv = validate_wf_batch(c);
         if (rcv == SSDR_OK && c->decim > 1) {
@@ -1106,7 +1125,7 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused) SSDR_GUARD
             rcv = [&]() -> int { HIP_TRY(hipSetDevice(c->device)); return join_audio(c); }();
             if (rcv == SSDR_OK) rcv = ensure_chan_list(c, c->stream);
         }
-        if (rcv != SSDR_OK) { c->fuse_next = false; c->fuse_gen_next = false; if (fused) *fused = 0; return rcv; }
+        if (rcv != SSDR_OK) { c->fuse_next = false; c->fuse_ws_next = false; if (fused) *fused = 0; return rcv; }
     }
     // Everything else: the two stages side by side -- the audio stage on a second stream beside the waterfall kernel (one workgroup
     // per CU then), each filling the issue slots the other leaves: +2.7 % on configs[3], +9 % on the full chain at hop 512
@@ -1127,7 +1146,7 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused) SSDR_GUARD
         if (rc == SSDR_OK) rc = ssdr_run_audio(c, nullptr, nullptr, 0);
     }
     c->fuse_next = false;
-    c->fuse_gen_next = false;
+    c->fuse_ws_next = false;
     return rc;
 } SSDR_UNGUARD
 

@@ -153,18 +153,27 @@ struct SsdrZoomArgs {
     uint32_t *out;                           // [n_ch][n_in / zoom] I | Q << 16
 };
 hipError_t ssdr_launch_zoom(const SsdrZoomArgs &a, hipStream_t stream);
-struct SsdrFusedArgs { SsdrWfArgs wf; SsdrAudioArgs au; uint32_t *park; };      // park: ssdr_fused_gen_kernel<AVG>, [waves of the grid][16][64] dwords
-// the general-mode fused kernel (ssdr_fused_gen.hip): one 1024-thread workgroup per CU; channel filters of up to 33 taps (4 history octets)
-#ifndef SSDR_GEN_BLOCK
-#define SSDR_GEN_BLOCK 1024
+struct SsdrFusedArgs { SsdrWfArgs wf; SsdrAudioArgs au; uint32_t *ticket; };      // ticket: ssdr_chain_ws_kernel's pair counter (zero at launch)
+// the wave-specialised chain kernel (ssdr_chain_ws.hip): a workgroup of SSDR_WS_AUDIO_WAVES audio waves (one receiver each) and half as
+// many FFT waves (one channel pair each); one workgroup per CU
+#ifndef SSDR_WS_AUDIO_WAVES
+#define SSDR_WS_AUDIO_WAVES 8
 #endif
-#ifndef SSDR_GEN_WAVES_PER_EU
-#define SSDR_GEN_WAVES_PER_EU (SSDR_GEN_BLOCK / 256)
+#define SSDR_WS_BLOCK (64 * (SSDR_WS_AUDIO_WAVES + SSDR_WS_AUDIO_WAVES / 2))
+#ifndef SSDR_WS_RING_FRAMES
+#define SSDR_WS_RING_FRAMES 2                // 512-sample frames of raw IQ a channel's ring holds
 #endif
-#define SSDR_GEN_HIST_OCT 4
-#define SSDR_GEN_NTAP_MAX 33
-hipError_t ssdr_launch_fused_gen(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream);
-hipError_t ssdr_fused_gen_blocks_per_cu(int *blocks);
+#ifndef SSDR_WS_PREFETCH
+#define SSDR_WS_PREFETCH 1                   // audio waves request frame f + 1 before they work on frame f
+#endif
+#ifndef SSDR_WS_SLEEP
+#define SSDR_WS_SLEEP 1                      // s_sleep argument of a waiting wave (units of 64 clocks)
+#endif
+#ifndef SSDR_WS_PRIO_AUDIO
+#define SSDR_WS_PRIO_AUDIO 0                 // s_setprio level of the audio waves (the FFT waves: 0 in their butterflies, 3 elsewhere)
+#endif
+hipError_t ssdr_launch_chain_ws(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream);
+hipError_t ssdr_chain_ws_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_fused_am(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream);
 hipError_t ssdr_fused_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_fused_exact_am(const SsdrFusedArgs &a, const double2 *tw, hipStream_t stream);   // ssdr_wf_exact.hip: float64 bins; chooses its grid

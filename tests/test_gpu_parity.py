@@ -1377,17 +1377,18 @@ def test_fused_kernel_with_time_binning_equals_the_two_kernels(S, hop):
 
 
 def _gen_fused_params(S, n_ch, seed):
-    """random receivers whose channel filters the general-mode fused kernel takes (<= 33 taps, no CW / IQ), in every pairing of
-    audio paths: general + general, general + shift, shift + general, shift + shift, AM-shift with all of them"""
+    """random receivers in every pairing of audio paths inside a workgroup's group of eight: general (short and long filters, CW's
+    127 taps, mod=iq with its second output row), shift, AM-shift"""
     import random_params as RP
     rng = np.random.default_rng(seed)
-    kinds = ["am", "nbfm", "usb", "lsb", "am_narrow", "nbfm_narrow", "usb_wide", "am", "usb"]
+    kinds = ["am", "nbfm", "usb", "lsb", "am_narrow", "nbfm_narrow", "usb_wide", "am", "usb", "cw", "iq", "am_very_narrow"]
     ps = []
     for c in range(n_ch):
         d = RP.draw(rng)
         kind = kinds[int(rng.integers(0, len(kinds)))]
         mode, lc, hc = {"am": ("am", -6000.0, 6000.0), "nbfm": ("nbfm", -6000.0, 6000.0), "usb": ("usb", 30.0, 3000.0), "lsb": ("lsb", -3000.0, -30.0),
-                        "am_narrow": ("am", -4000.0, 4000.0), "nbfm_narrow": ("nbfm", -5000.0, 5000.0), "usb_wide": ("usb", 100.0, 3900.0)}[kind]
+                        "am_narrow": ("am", -4000.0, 4000.0), "nbfm_narrow": ("nbfm", -5000.0, 5000.0), "usb_wide": ("usb", 100.0, 3900.0),
+                        "cw": ("cw", 300.0, 700.0), "iq": ("iq", -5000.0, 5000.0), "am_very_narrow": ("am", -1500.0, 1500.0)}[kind]
         ps.append(S.default_params(mode, f_shift_hz=d["f_shift_hz"] if rng.random() < 0.85 else 0.0, low_cut=lc, high_cut=hc, agc_on=d["agc_on"],
                                    agc_hang=d["hang"], agc_thresh=d["thresh"], agc_slope=d["slope"], agc_decay=d["decay"],
                                    agc_man_gain=d["man_gain"], wf_cal_db=d["wf_cal_db"], smeter_cal_db=d["smeter_cal_db"]))
@@ -1396,10 +1397,11 @@ def _gen_fused_params(S, n_ch, seed):
 
 @pytest.mark.parametrize("n_ch,n_avg,seed", [(1, 1, 5), (2, 1, 6), (37, 1, 7), (64, 3, 8), (301, 10, 9)])
 def test_general_fused_kernel_equals_the_two_kernels(S, n_ch, n_avg, seed):
-    """Round 5: ssdr_fused_gen_kernel (ssdr_set_fused(ctx, 3)) -- both stages on one read of the input for ANY mix of audio paths and
-    any N.  Bit-identical to the two kernels in everything they leave behind: waterfall sums (groups straddling the calls both ways),
-    PCM, RSSI, ADC-overflow flags, carried state and raw history, over several calls incl. a parameter change between two of them
-    and a call of more than 64 frames (the RSSI keepers wrap)."""
+    """Round 6: ssdr_chain_ws_kernel (ssdr_set_fused(ctx, 3)) -- both stages on one read of the input for ANY mix of audio paths, any
+    filter and any N: audio waves hand every raw frame to an FFT wave of their workgroup through the LDS.  Bit-identical to the two
+    kernels in everything they leave behind: waterfall sums (groups straddling the calls both ways), PCM, mod=iq pairs, RSSI,
+    ADC-overflow flags, carried state and raw history, over several calls incl. a parameter change between two of them and a call
+    of more than 64 frames (the RSSI keepers wrap)."""
     import random_params as RP
     calls = [8, 4, 14, 132 if n_ch <= 37 else 10, 6]
     rng = np.random.default_rng(1000 + seed)
@@ -1419,21 +1421,26 @@ def test_general_fused_kernel_equals_the_two_kernels(S, n_ch, n_avg, seed):
                 assert (was in (1, 2)) if f == 3 else was == 0, (was, paths)      # (1: every channel happens to be full-band AM)
                 got += [eng.fetch_wf(lines).copy() if lines else np.zeros(0), eng.fetch_audio()[0].copy(), eng.fetch_audio()[1].copy(), eng.audio_flags().copy()]
                 st, hist = eng.get_state()
-                got += [st.tobytes(), hist.tobytes()]
+                try:
+                    pairs = eng.audio_iq().copy()          # (refused when the ctx holds no mod=iq channel: then by both)
+                except Exception:
+                    pairs = np.zeros(0)
+                got += [st.tobytes(), hist.tobytes(), pairs]
                 if i == 1:                      # a retune and a mode change between two calls: the carried state is re-read per call
                     eng.set_params(0, [S.default_params("lsb", f_shift_hz=-1234.5)])
                 pos += nf
         outs[f] = got
-    names = ["wf", "pcm", "rssi", "flags", "state", "hist"]
+    names = ["wf", "pcm", "rssi", "flags", "state", "hist", "iq pairs"]
     for k, (a, b) in enumerate(zip(outs[0], outs[3])):
         same = (a == b) if isinstance(a, bytes) else np.array_equal(a, b)
-        assert same, "call %d: %s differs" % (k // 6, names[k % 6])
+        assert same, "call %d: %s differs" % (k // 7, names[k % 7])
 
 
 def test_general_fused_kernel_declines_what_it_does_not_cover(S):
-    """a CW channel (127 taps), an IQ-mode channel, hop 512, float64 bins: ssdr_run_chain falls back to the two kernels"""
+    """hop 512, float64 bins, a waterfall zoom, a decimating front end: ssdr_run_chain falls back to the two kernels; a CW channel
+    (127 taps) or an IQ-mode channel does not make it"""
     iq = O.synth_iq(4, 8 * 512, seed=3)
-    for setup in ("cw", "iq", "hop", "exact"):
+    for setup in ("cw", "iq", "hop", "exact", "zoom"):
         with S.SsdrEngine(4) as eng:
             eng.set_fused(3)
             eng.set_params(0, [S.default_params("usb")] * 4)
@@ -1443,10 +1450,12 @@ def test_general_fused_kernel_declines_what_it_does_not_cover(S):
                 eng.set_params(2, [S.default_params("iq")])
             elif setup == "hop":
                 eng.set_hop(512)
+            elif setup == "zoom":
+                eng.set_wf_zoom(2)
             else:
                 eng.set_exact_bins(1)
             eng.push_iq(iq)
-            assert eng.run_chain()[1] == 0, setup
+            assert eng.run_chain()[1] == (2 if setup in ("cw", "iq") else 0), setup
         with S.SsdrEngine(4) as eng:
             eng.set_fused(3)
             eng.set_params(0, [S.default_params("usb")] * 4)
