@@ -55,6 +55,10 @@ WORKLOADS = {
     # configs[2]'s shape with the AM passband narrowed to +-4 kHz (change_passband, utils_supersdr.py:1078-1092): the channel filter is a
     # real 25-tap FIR then and the NCO mixes -- every channel on the general path, which the default workload's full-band AM never times
     "am_narrow": (65536, 16,          1,     ("am",),               True, True),
+    # A/B shapes of round 6's wave-specialised chain kernel (tools/ab_ws.sh): every channel a side-band listener (33-tap filters), and
+    # three general-path channels in four
+    "ssb":       (65536, 16,          1,     ("usb", "lsb"),        True, True),
+    "mixed75":   (65536, 16,          1,     ("usb", "lsb", "am", "usb"), True, True),
 }
 WORKLOAD_DECIM = {"decim4": 4}
 WORKLOAD_PARAMS = {"am_narrow": {"low_cut": -4000.0, "high_cut": 4000.0}}
@@ -63,7 +67,9 @@ WORKLOAD_TEXT = {"full": "65536 channels full chain (WF + AM demod + AGC), BASEL
                  "mixed": "65536 channels mixed AM/USB/LSB/NBFM + 10x time binning, BASELINE configs[3]",
                  "million": "2^20 channels full chain in total, channel-sharded, BASELINE configs[4]",
                  "decim4": "16384 channels, IQ at 48 kHz (ssdr_set_decimation(4)): USB / LSB behind 125-tap decimating channel filters + waterfall",
-                 "am_narrow": "65536 channels full chain, every channel AM with the passband narrowed to +-4 kHz (NCO + 25-tap channel FIR: the general audio path)"}
+                 "am_narrow": "65536 channels full chain, every channel AM with the passband narrowed to +-4 kHz (NCO + 25-tap channel FIR: the general audio path)",
+                 "ssb": "65536 channels full chain, USB / LSB by channel (33-tap channel FIR: the general audio path)",
+                 "mixed75": "65536 channels full chain, USB / LSB / full-band AM / USB by channel (three of four on the general audio path)"}
 PATH_NAMES = ("FIR", "shift", "AM-shift")        # ssdr_audio_kernel<0|1|2>
 PATH_TEXT = ("general: NCO -> FIR -> demodulator", "full-band lane shift: NCO, no FIR", "full-band AM: no NCO, no FIR (|x e^{j phi}| = |x|)")
 # what the headline's audio stage does NOT time when every channel sits on the reference's default AM passband: extra.full_am_narrow does
@@ -86,6 +92,8 @@ KERNEL_VALU_FALLBACK = {
     "ssdr_fused_am_kernel<false, false>": ("channel-superframe", 1074.0, 0.45),
     "ssdr_fused_am_kernel<true, false>": ("channel-superframe", 1658.0, 0.50),
     "ssdr_audio_dec_kernel<4>": ("frame", 2682, 0.85),
+    "ssdr_chain_ws_kernel<false>": ("channel-superframe", 1796.0, 0.55),        # am_narrow, profiles/r06_am_narrow_pmc_summary.txt
+    "ssdr_chain_ws_kernel<true>": ("channel-superframe", 1886.0, 0.59),         # configs[3] with --fused 3
 }
 # kernel -> (summary of which profiled workload, units of that kernel in one launch of it)
 VALU_SOURCES = {
@@ -98,6 +106,8 @@ VALU_SOURCES = {
     "ssdr_fused_am_kernel<false, false>": ("full", 65536 * 16),
     "ssdr_fused_am_kernel<true, false>": ("full_hop512_fused", 65536 * 16),
     "ssdr_audio_dec_kernel<4>": ("decim4", 16384 * 16),
+    "ssdr_chain_ws_kernel<false>": ("am_narrow", 65536 * 16),
+    "ssdr_chain_ws_kernel<true>": ("mixed_chain_ws", 65536 * 10),
 }
 
 
@@ -136,6 +146,7 @@ STREAM_SOURCE = "profiles/r04_ubench_hbm_stream.txt (tools/ubench/hbm_stream.hip
 MEASURED_STREAM_GBPS = {                      # kernel stem -> (mix, lowest, highest GB/s of the two boxes)
     "ssdr_fused_am_kernel": ("copy 1:1", 5290.0, 5670.0),            # 4096 B in, 2048 + 2048 B out per channel-superframe
     "ssdr_fused_exact_am_kernel": ("copy 1:1", 5290.0, 5670.0),
+    "ssdr_chain_ws_kernel": ("copy 1:1", 5290.0, 5670.0),            # 4096 B in, 2048 / N + 2048 B out per channel-superframe
     "ssdr_wf_kernel": ("2 read : 1 write", 5340.0, 5510.0),          # 4096 in, 2048 out
     "ssdr_wf_exact_kernel": ("2 read : 1 write", 5340.0, 5510.0),
     "ssdr_audio_kernel": ("2 read : 1 write", 5340.0, 5510.0),       # 2048 in, 1024 out
@@ -453,9 +464,10 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
         if do_audio:
             eng.run_audio(fetch=False)
 
+    chain_kind = [0]                                      # which way ssdr_run_chain went: 0 two stages, 1 ssdr_fused_am_kernel, 2 ssdr_chain_ws_kernel
     if do_wf and do_audio:
-        def step():                                       # noqa: F811  (ssdr_run_chain: the fused superframe kernel where the
-            eng.run_chain()                               #  configuration allows it and --fused is not 0, else the two kernels)
+        def step():                                       # noqa: F811  (ssdr_run_chain: a one-read kernel where the
+            chain_kind[0] = eng.run_chain()[1]            #  configuration allows it and --fused is not 0, else the two kernels)
 
     inflight = [0]
     if host_feed:
@@ -539,8 +551,10 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
                                               else {name: channels * n_frames}}
     if fu_n:
         avg = fu_ms / fu_n
-        b = channels * sframes * (4096.0 + (2 if hop == 512 else 1) * 2048.0 + 2048.0)      # SURVEY.md 8d, fused budget at N = 1: 4096 in + 2048 per line + 2048 PCM out
+        # SURVEY.md 8d, fused budget: 4096 in + 2048 / N per line + 2048 PCM out
+        b = channels * sframes * (4096.0 + (2 if hop == 512 else 1) * 2048.0 / n_avg + 2048.0)
         stages["fused"] = {"kernel": "ssdr_fused_exact_am_kernel (float64 waterfall)" if exact else
+                                     ("ssdr_chain_ws_kernel<%s>" % ("true" if n_avg > 1 else "false")) if chain_kind[0] == 2 else
                                      "ssdr_fused_am_kernel<%s, %s>" % ("true" if hop == 512 else "false", "true" if n_avg > 1 else "false"),
                            "avg_ms": avg, "launches": fu_n,
                            "bytes": b, "GBps": b / avg / 1e6, "units": channels * sframes}
@@ -548,7 +562,7 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     for st in stages.values():
         st["side_by_side"] = side                       # the two stages ran beside each other: their durations overlap
     return {"value": units / wall / RT_SUPERFRAMES_PER_S, "ms_per_step": wall / steps * 1e3, "stages": stages,
-            "n_avg": n_avg, "paths": paths, "decim": decim, "side_by_side": side,
+            "n_avg": n_avg, "paths": paths, "decim": decim, "side_by_side": side, "chain_kind": chain_kind[0],
             "own_value": channels * sframes * steps / own_wall / RT_SUPERFRAMES_PER_S}
 
 
@@ -1022,7 +1036,9 @@ def main():
                    "audio_paths": {PATH_TEXT[p]: m["paths"][p] for p in range(3) if m["paths"][p]} if do_audio else {},
                    "audio_path": (" + ".join(PATH_SHORT[p] for p in range(3) if m["paths"][p]) if do_audio else "none"),
                    "input_decimation": m["decim"], "wf_exact_bins": bool(args.exact),
-                   "chain": ("ssdr_run_chain: one fused kernel for both stages (one read of the input; bit-identical to the two per-stage "
+                   "chain": ("ssdr_run_chain: one wave-specialised kernel for both stages (audio waves hand raw frames to FFT waves through the LDS: "
+                             "one read of the input; bit-identical to the two per-stage kernels)" if m.get("chain_kind") == 2 else
+                             "ssdr_run_chain: one fused kernel for both stages (one read of the input; bit-identical to the two per-stage "
                              "kernels, which extra.full_two_kernels times)" if "fused" in m["stages"] else
                              "the per-stage kernels" + (" side by side on two streams" if m["side_by_side"] else " one after the other")),
                    "clock_spinup_s": args.spinup,
@@ -1127,7 +1143,10 @@ def main():
         e = run_extra("wf_hop512", "wf", nst, ", hop 512 (23.4 lines/s)", hop=512)
         if e is not None:
             extra["wf_hop512"]["lines_per_s"] = e["stages"]["wf"]["lines_per_launch"] / e["ms_per_step"] * 1e3
-        run_extra("full_am_narrow", "am_narrow", nst, ": what an AM listener who narrows the passband gets -- the general audio path beside the waterfall kernel")
+        run_extra("full_am_narrow", "am_narrow", nst, ": what an AM listener who narrows the passband gets -- every channel on the general audio path: "
+                  "ssdr_run_chain's wave-specialised kernel (one read of the input)")
+        run_extra("full_am_narrow_two_kernels", "am_narrow", nst, ", the general audio path beside the waterfall kernel (--fused 0): what round 5 ran by default", fused=0)
+        run_extra("mixed_chain_ws", "mixed", max(60, args.steps // 2), ", the wave-specialised kernel (--fused 3: opt-in where full-band channels are among them)", spin=1.0, fused=3)
         run_extra("full_hop512", "full", nst, ", waterfall at hop 512 (23.4 lines/s, the reference's line rate), the two stages side by side", hop=512)
         # configs[4] at N = 1 (2^20 channels on this one GPU, 16 superframes per call) and the decimating front end
         run_extra("million", "million", 5, warm=1, spin=0.3)

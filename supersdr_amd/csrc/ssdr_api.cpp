@@ -69,6 +69,7 @@ struct ssdr_ctx {
     std::vector<ssdr_chan_consts> h_consts;             // host mirror of d_consts
     uint32_t *d_chan_list = nullptr;                    // channels sorted by audio frame path (ssdr_audio_path)
     uint32_t *d_ws_list = nullptr;                      // [n_ch] + 1 ticket word: the same channels as pairs, the paths interleaved (ssdr_chain_ws_kernel)
+    uint32_t ws_ticket = 0;                             // where the ticket word stands (it only counts up: SsdrFusedArgs)
     uint32_t path_off[SSDR_PATH_COUNT] = {}, path_n[SSDR_PATH_COUNT] = {};
     bool chan_list_dirty = true;
     bool summary_dirty = true;                          // path counts / any channel in IQ mode: recounted after the constants change
@@ -433,6 +434,7 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         HIP_TRY(hipMalloc(&c->d_state, (size_t)n_channels * sizeof(ssdr_chan_state)));
         HIP_TRY(hipMalloc(&c->d_chan_list, (size_t)n_channels * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_ws_list, ((size_t)n_channels + 1) * sizeof(uint32_t)));
+        HIP_TRY(hipMemset(c->d_ws_list + n_channels, 0, sizeof(uint32_t)));
         c->h_consts.resize(n_channels);
         c->h_params.resize(n_channels);
         HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -1031,7 +1033,7 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
         fa.au.chan_list = c->d_ws_list;        // (the wave-specialised kernel draws pairs from its own list of all channels)
         fa.au.list_n = c->n_ch;
         fa.ticket = c->d_ws_list + c->n_ch;
-        if (c->fuse_ws_next) HIP_TRY(hipMemsetAsync(fa.ticket, 0, sizeof(uint32_t), s));
+        fa.ticket_base = c->ws_ticket;
         const uint64_t pairs = (c->n_ch + 1) / 2;
         const uint64_t need = (pairs + SSDR_WF_BLOCK / 64 - 1) / (SSDR_WF_BLOCK / 64);
         const uint32_t grid = (uint32_t)(need < c->fused_grid ? need : c->fused_grid);
@@ -1040,6 +1042,7 @@ int ssdr_run_audio(ssdr_ctx *c, int16_t *pcm_out, float *rssi_out, int out_is_de
             const uint64_t need_g = ((uint64_t)c->n_ch + SSDR_WS_AUDIO_WAVES - 1) / SSDR_WS_AUDIO_WAVES;
             const uint32_t grid_g = (uint32_t)(need_g < c->ws_grid ? need_g : c->ws_grid);
             HIP_TRY(ssdr_launch_chain_ws(fa, grid_g ? grid_g : 1, s));
+            c->ws_ticket += (uint32_t)pairs + (grid_g ? grid_g : 1) * (SSDR_WS_AUDIO_WAVES / 2);     // (wraps as the device word does)
         } else if (c->exact_bins) HIP_TRY(ssdr_launch_fused_exact_am(fa, c->d_tw64, s));
         else HIP_TRY(ssdr_launch_fused_am(fa, grid ? grid : 1, s));
         if ((rc = timed_end(c, SSDR_K_FUSED, s)) != SSDR_OK) return rc;
@@ -1108,10 +1111,13 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused) SSDR_GUARD
                           c->in_frames >= 8 &&
                           !c->concurrent && c->fused_grid != 0 && c->fused_enabled >= ((hop512 || c->n_avg > 1) ? 2 : 1) && c->zoom == 1 &&
                           (!c->exact_bins || (!hop512 && c->n_avg == 1));
-    // the wave-specialised kernel (ssdr_chain_ws.hip; ssdr_set_fused(ctx, 3)): any mix of audio paths, any filter and any N at hop 1024,
-    // fp32 bins
-    const bool eligible_ws = !eligible && c->fused_enabled >= 3 && c->ws_grid != 0 && c->decim == 1 && !hop512 && !(c->in_frames & 1u) &&
-                             !c->concurrent && c->zoom == 1 && !c->exact_bins;
+    // the wave-specialised kernel (ssdr_chain_ws.hip): any mix of audio paths, any filter and any N at hop 1024, fp32 bins -- both stages on one
+    // read of the input.  By default where it is also the faster way (profiles/r06_ab_chain_ws.txt): when every channel runs the general path
+    // (a filter to apply: the stages side by side are bound by the board's power cap there, and the second read of the input is energy);
+    // for every batch it can take with ssdr_set_fused(ctx, 3) (full-band channels among them: 1 % slower than side by side, 39 % less HBM traffic)
+    const bool ws_can = c->ws_grid != 0 && c->decim == 1 && !hop512 && !(c->in_frames & 1u) && !c->concurrent && c->zoom == 1 && !c->exact_bins;
+    const bool eligible_ws = !eligible && ws_can &&
+                             (c->fused_enabled >= 3 || (c->fused_enabled >= 1 && c->sum_paths[SSDR_PATH_GENERAL] == c->n_ch && c->in_frames >= 8));
     if (fused) *fused = eligible ? 1 : (eligible_ws ? 2 : 0);
     c->fuse_next = eligible || eligible_ws;
     c->fuse_ws_next = eligible_ws;

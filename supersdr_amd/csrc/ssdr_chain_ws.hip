@@ -58,7 +58,12 @@ SSDR_DEV uint32_t flag_read(const uint32_t *p)
 // sleep until the counter has reached `need` (counters are monotonic; compared as a signed difference)
 SSDR_DEV void flag_wait(const uint32_t *p, uint32_t need)
 {
-    while ((int32_t)(flag_read(p) - need) < 0) __builtin_amdgcn_s_sleep(SSDR_WS_SLEEP);
+    // (a look costs an LDS read and a vector instruction -- v_readfirstlane -- on a port the other waves want: a few short naps for the
+    //  hand-over that is almost there, long ones for a consumer that is a frame ahead of its producers)
+    for (uint32_t looks = 0; (int32_t)(flag_read(p) - need) < 0; looks++) {
+        if (looks < SSDR_WS_SHORT_LOOKS) __builtin_amdgcn_s_sleep(SSDR_WS_SLEEP);
+        else __builtin_amdgcn_s_sleep(SSDR_WS_SLEEP_LONG);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 SSDR_DEV void flag_publish(uint32_t *p, uint32_t v, int lane)
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(SSDR_WS_BLOCK) void ssdr_chain_ws_kernel(SsdrFusedA
     uint32_t *prod_a = prod + 2 * pw, *cons_a = cons + 2 * pw;
     auto draw = [&]() -> uint32_t {                              // (the value is not needed before the first line is out)
         uint32_t v = 0;
-        if (lane == 0) v = __hip_atomic_fetch_add(fa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) v = __hip_atomic_fetch_add(fa.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - fa.ticket_base;
         return v;
     };
     auto announce = [&](uint32_t n, uint32_t item) {             // item n of this trio
@@ -181,11 +186,11 @@ __global__ __launch_bounds__(SSDR_WS_BLOCK) void ssdr_chain_ws_kernel(SsdrFusedA
                 if (lane < 2) __hip_atomic_store(cons_a + lane, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             SCHED_FENCE();
-            if (SSDR_PRIO_WF) prio_compute_phase();
+            if (SSDR_PRIO_WF) __builtin_amdgcn_s_setprio(SSDR_WS_PRIO_FFT);
             f32x2 z[32];
             window_line(raw, smem, l, z);
             SCHED_FENCE();
-            fft_line<AVG>(z, smem, xch_wave, h, l);
+            fft_line<AVG && SSDR_WS_FFT_TIGHT>(z, smem, xch_wave, h, l);
             if (SSDR_PRIO_WF) prio_latency_phase();              // quantiser look-ups, the line's store, the next line's hand-shake
             uint32_t qn[16];
             if (AVG) quantise32(z, calq, lut, [&](int j, uint32_t q01) { acc[j] += q01; });

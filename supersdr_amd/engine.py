@@ -178,8 +178,9 @@ class SsdrEngine:
         return pcm, rssi
 
     def set_fused(self, on):
-        """0 / False: never the fused superframe kernel; 1 / True (default): at hop 1024; 2: at hop 512 as well; 3: and the general-mode
-        fused kernel for batches of mixed audio paths (run_chain then reports fused == 2)"""
+        """0 / False: never a one-read kernel; 1 / True (default): the fused superframe kernel at hop 1024 (full-band AM batches) and the
+        wave-specialised chain kernel for batches whose channels all run the general audio path; 2: the former at hop 512 / N > 1 as well;
+        3: the latter for every batch it can take (any mix of audio paths at hop 1024)"""
         check(lib.ssdr_set_fused(self._ctx, int(on)), "ssdr_set_fused")
 
     def set_overlap(self, on):
@@ -187,7 +188,8 @@ class SsdrEngine:
         check(lib.ssdr_set_overlap(self._ctx, int(bool(on))), "ssdr_set_overlap")
 
     def run_chain(self):
-        """both stages on the current batch, results left on the device -> (lines ready, fused?)"""
+        """both stages on the current batch, results left on the device -> (lines ready, which way: 0 the two stages side by side,
+        1 ssdr_fused_am_kernel, 2 ssdr_chain_ws_kernel -- an int, not a bool: test it with `!= 0`)"""
         n, fused = C.c_uint32(0), C.c_int(0)
         self.audio_frames = self.in_frames
         check(lib.ssdr_run_chain(self._ctx, C.byref(n), C.byref(fused)), "ssdr_run_chain")

@@ -1376,7 +1376,7 @@ def test_fused_kernel_with_time_binning_equals_the_two_kernels(S, hop):
         assert eng.run_chain()[1] == 0
 
 
-def _gen_fused_params(S, n_ch, seed):
+def _chain_ws_params(S, n_ch, seed):
     """random receivers in every pairing of audio paths inside a workgroup's group of eight: general (short and long filters, CW's
     127 taps, mod=iq with its second output row), shift, AM-shift"""
     import random_params as RP
@@ -1396,7 +1396,7 @@ def _gen_fused_params(S, n_ch, seed):
 
 
 @pytest.mark.parametrize("n_ch,n_avg,seed", [(1, 1, 5), (2, 1, 6), (37, 1, 7), (64, 3, 8), (301, 10, 9)])
-def test_general_fused_kernel_equals_the_two_kernels(S, n_ch, n_avg, seed):
+def test_wave_specialised_kernel_equals_the_two_kernels(S, n_ch, n_avg, seed):
     """Round 6: ssdr_chain_ws_kernel (ssdr_set_fused(ctx, 3)) -- both stages on one read of the input for ANY mix of audio paths, any
     filter and any N: audio waves hand every raw frame to an FFT wave of their workgroup through the LDS.  Bit-identical to the two
     kernels in everything they leave behind: waterfall sums (groups straddling the calls both ways), PCM, mod=iq pairs, RSSI,
@@ -1406,7 +1406,7 @@ def test_general_fused_kernel_equals_the_two_kernels(S, n_ch, n_avg, seed):
     calls = [8, 4, 14, 132 if n_ch <= 37 else 10, 6]
     rng = np.random.default_rng(1000 + seed)
     iq = RP.signal(rng, n_ch, sum(calls) * 512)
-    ps = _gen_fused_params(S, n_ch, seed)
+    ps = _chain_ws_params(S, n_ch, seed)
     outs = {}
     for f in (0, 3):
         with S.SsdrEngine(n_ch) as eng:
@@ -1436,7 +1436,7 @@ def test_general_fused_kernel_equals_the_two_kernels(S, n_ch, n_avg, seed):
         assert same, "call %d: %s differs" % (k // 7, names[k % 7])
 
 
-def test_general_fused_kernel_declines_what_it_does_not_cover(S):
+def test_wave_specialised_kernel_declines_what_it_does_not_cover(S):
     """hop 512, float64 bins, a waterfall zoom, a decimating front end: ssdr_run_chain falls back to the two kernels; a CW channel
     (127 taps) or an IQ-mode channel does not make it"""
     iq = O.synth_iq(4, 8 * 512, seed=3)
@@ -1461,6 +1461,43 @@ def test_general_fused_kernel_declines_what_it_does_not_cover(S):
             eng.set_params(0, [S.default_params("usb")] * 4)
             eng.push_iq(iq)
             assert eng.run_chain()[1] == 2
+
+
+def test_run_chain_default_takes_the_wave_specialised_kernel_where_every_channel_filters(S):
+    """ssdr_run_chain's default (ssdr_set_fused level 1): a batch whose channels ALL run the general audio path (SSB, CW, a narrowed
+    AM passband: `change_passband`, utils_supersdr.py:1078-1092) goes through ssdr_chain_ws_kernel (fused == 2), with the bytes of
+    the two kernels; one full-band channel among them, fewer than 8 frames, or level 0 and it is the stages side by side"""
+    n_ch, calls = 77, [8, 16, 10]
+    iq = O.synth_iq(n_ch, sum(calls) * 512, seed=606)
+    kinds = [("usb", {}), ("lsb", {}), ("cw", {}), ("am", {"low_cut": -4000.0, "high_cut": 4000.0}), ("nbfm", {"low_cut": -5000.0, "high_cut": 5000.0})]
+    ps = [S.default_params(kinds[c % 5][0], f_shift_hz=((c * 37) % 97 - 48) * 100.0, **kinds[c % 5][1]) for c in range(n_ch)]
+    outs = {}
+    for level in (0, 1):
+        with S.SsdrEngine(n_ch) as eng:
+            eng.set_fused(level)
+            eng.set_params(0, ps)
+            assert eng.audio_paths()[0] == n_ch
+            got, pos = [], 0
+            for nf in calls:
+                eng.push_iq(iq[:, pos * 512:(pos + nf) * 512])
+                lines, was = eng.run_chain()
+                assert was == (2 if level else 0)
+                st, hist = eng.get_state()
+                got += [eng.fetch_wf(lines).copy(), eng.fetch_audio()[0].copy(), eng.fetch_audio()[1].copy(), eng.audio_flags().copy(), st.tobytes(), hist.tobytes()]
+                pos += nf
+        outs[level] = got
+    for k, (a, b) in enumerate(zip(outs[0], outs[1])):
+        assert (a == b) if isinstance(a, bytes) else np.array_equal(a, b), "call %d, item %d differs" % (k // 6, k % 6)
+    with S.SsdrEngine(4) as eng:
+        eng.set_params(0, [S.default_params("usb")] * 4)
+        eng.push_iq(iq[:4, :6 * 512])
+        assert eng.run_chain()[1] == 0                    # a short batch: the per-call set-up would not pay
+        eng.set_params(3, [S.default_params("am")])       # a full-band AM receiver among them: the AM-shift path
+        eng.push_iq(iq[:4, :8 * 512])
+        assert eng.run_chain()[1] == 0
+        eng.set_fused(3)
+        eng.push_iq(iq[:4, :8 * 512])
+        assert eng.run_chain()[1] == 2
 
 
 def test_run_chain_side_by_side_stages_are_bit_identical_and_joined_before_what_depends_on_them(S):

@@ -9,7 +9,7 @@ import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e6,2), 'M', round(d['ms_per_step'],3), 'ms', 'chain_frac', round(d.get('chain_frac', 0) or 0, 4))"
 }
 for round in $(seq 1 $R); do for wl in $W; do
-  run side_by_side $PWD/supersdr_amd/libssdr.so 1 $wl
+  run side_by_side $PWD/supersdr_amd/libssdr.so 0 $wl        # (--fused 0: the two stages side by side on two streams)
   for v in $V; do
     lib=$PWD/supersdr_amd/libssdr_$v.so; [ $v = main ] && lib=$PWD/supersdr_amd/libssdr.so
     run ws:$v $lib 3 $wl

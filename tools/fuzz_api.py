@@ -48,7 +48,7 @@ def one_sequence(S, seed, n_ops, log):
     A, B = S.SsdrEngine(n_ch), S.SsdrEngine(n_ch)
     counts = {"fused": 0, "runs": 0}
     try:
-        A.set_fused(int(rng.integers(1, 4)))                       # 3: incl. the general-mode fused kernel (round 5) wherever the batch allows it
+        A.set_fused(int(rng.integers(1, 4)))                       # 3: the wave-specialised chain kernel (round 6) wherever the batch allows it
         B.set_fused(0)
         B.set_overlap(0)
         ps = random_params(S, rng, n_ch, am_bias)
@@ -87,7 +87,7 @@ def one_sequence(S, seed, n_ops, log):
             elif op <= 6:
                 (la, fa), (lb, fb) = A.run_chain(), B.run_chain()
                 counts["fused"] += int(fa != 0)
-                counts["fused_gen"] = counts.get("fused_gen", 0) + int(fa == 2)
+                counts["chain_ws"] = counts.get("chain_ws", 0) + int(fa == 2)
                 counts["runs"] += 1
                 assert not fb
                 compare_results(la, lb, True)
@@ -154,20 +154,20 @@ def main():
     a = ap.parse_args()
     import supersdr_amd as S
     lines, bad, fused, runs, t0 = [], 0, 0, 0, time.time()
-    fused_gen = 0
+    chain_ws = 0
     for seed in range(a.first, a.first + a.count):
         try:
             c = one_sequence(S, seed, a.ops, lines)
             fused += c["fused"]
-            fused_gen += c.get("fused_gen", 0)
+            chain_ws += c.get("chain_ws", 0)
             runs += c["runs"]
         except Exception as e:                                                    # noqa: BLE001 -- reported per seed, the run goes on
             bad += 1
             tb = traceback.format_exc().strip().splitlines()
             lines.append("  seed %d: %s: %s | %s" % (seed, type(e).__name__, e, " / ".join(x.strip() for x in tb[-4:-1])[:300]))
             print(lines[-1], flush=True)
-    lines.append("differential API fuzz: seeds %d..%d, %d calls each: %d sequences differed; %d kernel runs compared, %d of them through a fused kernel (%d through the general-mode one) (%.0f s)"
-                 % (a.first, a.first + a.count - 1, a.ops, bad, runs, fused, fused_gen, time.time() - t0))
+    lines.append("differential API fuzz: seeds %d..%d, %d calls each: %d sequences differed; %d kernel runs compared, %d of them through a fused kernel (%d through the wave-specialised one) (%.0f s)"
+                 % (a.first, a.first + a.count - 1, a.ops, bad, runs, fused, chain_ws, time.time() - t0))
     text = "\n".join(lines) + "\n"
     print(text)
     if a.out:

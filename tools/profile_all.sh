@@ -12,5 +12,5 @@ bash tools/profile_round.sh ${R}_full_hop512_fused full --hop 512 --fused 2 > /d
 bash tools/profile_round.sh ${R}_wf_exact wf --exact 1 > /dev/null 2>&1
 bash tools/profile_round.sh ${R}_decim4 decim4 > /dev/null 2>&1                                  # the decimating front end (D = 4)
 bash tools/profile_round.sh ${R}_am_narrow am_narrow > /dev/null 2>&1                            # all-AM at +-4 kHz: the general audio path beside the waterfall kernel
-bash tools/profile_round.sh ${R}_mixed_fused_gen mixed --fused 3 > /dev/null 2>&1                # the general-mode one-read kernel (opt-in)
+bash tools/profile_round.sh ${R}_mixed_chain_ws mixed --fused 3 > /dev/null 2>&1                 # the wave-specialised one-read kernel on configs[3] (opt-in there)
 for d in gpurun_out/prof_${R}_*; do echo "== $d"; head -6 $d/kernel_stats.txt; done
