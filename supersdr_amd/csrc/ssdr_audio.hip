@@ -28,6 +28,11 @@
 
 namespace {
 
+// The decimating kernels' loads are PLAIN ones: a lane's 8 D consecutive inputs are 64 or 128 bytes, fetched 16 at a time, so a 128-byte line is
+// completed by two to eight load instructions of the wave.  Marked non-temporal, a line was dropped between two of them and fetched again: the
+// kernel read 1.22 x its input at D = 4 (profiles/r05_traffic_decim4.json); plain loads read 1.01 x and the workload runs 7 % faster
+// (profiles/r06_ab_dec_plain_loads.txt).
+#define SSDR_DEC_LOAD(p) (*(p))
 #ifndef SSDR_DEC_PHASED
 #define SSDR_DEC_PHASED 1
 #endif
@@ -118,7 +123,7 @@ SSDR_DEV void channel_frames_dec(const SsdrAudioArgs &a, const uint32_t ch, cons
         uint32_t rw[NB];
 #pragma unroll
         for (int i = 0; i < NB / 4; i++) {
-            const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src) + i);
+            const u32x4 v = SSDR_DEC_LOAD(reinterpret_cast<const u32x4 *>(src) + i);
             rw[4 * i] = v.x; rw[4 * i + 1] = v.y; rw[4 * i + 2] = v.z; rw[4 * i + 3] = v.w;
         }
         float p[8], aud[8], yr[8], yi[8];
