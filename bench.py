@@ -1214,7 +1214,8 @@ def compact_line(full):
     c = full["config"]
     out["config"] = {k: c[k] for k in ("workload", "workload_key", "channels_per_gpu", "superframes_per_step", "averaging_n", "wf_hop", "wf_exact_bins",
                                         "audio_path", "input", "sharding", "rendezvous")}
-    out["config"]["chain"] = "fused kernel (ssdr_run_chain)" if c["chain"].startswith("ssdr_run_chain") else c["chain"]
+    out["config"]["chain"] = ("wave-specialised kernel (ssdr_run_chain)" if c["chain"].startswith("ssdr_run_chain: one wave-specialised") else
+                              "fused kernel (ssdr_run_chain)" if c["chain"].startswith("ssdr_run_chain") else c["chain"])
     p = full["parity"]
     out["parity"] = {k: p[k] for k in ("ranks_agree", "checksums", "skipped") if k in p}
     out["per_rank"] = {k: full["per_rank"][k] for k in ("value_min", "value_max")}

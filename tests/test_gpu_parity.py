@@ -1500,6 +1500,35 @@ def test_run_chain_default_takes_the_wave_specialised_kernel_where_every_channel
         assert eng.run_chain()[1] == 2
 
 
+@pytest.mark.parametrize("workload,n_avg,sf", [("am_narrow", 1, 16), ("mixed", 10, 10)])
+def test_wave_specialised_kernel_at_the_timed_shapes(S, workload, n_avg, sf):
+    """bench.py's extra.full_am_narrow (ssdr_run_chain's default there) and extra.mixed_chain_ws (configs[3] with ssdr_set_fused 3) exactly
+    as timed -- 65536 channels, synthetic input, the bench's parameter pattern: two steps through ssdr_chain_ws_kernel leave the two
+    kernels' bytes (checksums of every waterfall sum, PCM sample and RSSI value; carried state; raw history)"""
+    n_ch = 65536
+    modes = ("am",) if workload == "am_narrow" else ("am", "usb", "lsb", "nbfm")
+    over = {"low_cut": -4000.0, "high_cut": 4000.0} if workload == "am_narrow" else {}
+    period = 97 * len(modes)
+    ps = [S.default_params(modes[c % len(modes)], f_shift_hz=((c * 37) % 97 - 48) * 100.0, **over) for c in range(period)]
+    got = {}
+    for level in (0, 3):
+        with S.SsdrEngine(n_ch) as eng:
+            eng.set_averaging(n_avg)
+            eng.set_fused(level)
+            for first in range(0, n_ch, period):
+                eng.set_params(first, ps[: min(period, n_ch - first)])
+            eng.reset_state()
+            eng.synth_iq(2 * sf, seed=0x5D5D)
+            steps = []
+            for _ in range(2):
+                lines, was = eng.run_chain()
+                assert was == (2 if level else 0) and lines == sf // n_avg
+                steps.append(eng.output_checksum())
+            st, hist = eng.get_state()
+            got[level] = (steps, st.tobytes(), hist.tobytes())
+    assert got[0] == got[3]
+
+
 def test_run_chain_side_by_side_stages_are_bit_identical_and_joined_before_what_depends_on_them(S):
     """Round 4: a batch ssdr_run_chain does not fuse runs its audio stage on a second stream beside the waterfall kernel
     (ssdr_set_overlap, default on).  Same bytes as one after the other -- waterfall sums (N = 3 groups straddling calls, hop 512),
