@@ -11,6 +11,7 @@ bash tools/profile_round.sh ${R}_full_hop512 full --hop 512 > /dev/null 2>&1    
 bash tools/profile_round.sh ${R}_full_hop512_fused full --hop 512 --fused 2 > /dev/null 2>&1     # the one-read kernel at hop 512 (opt-in)
 bash tools/profile_round.sh ${R}_wf_exact wf --exact 1 > /dev/null 2>&1
 bash tools/profile_round.sh ${R}_decim4 decim4 > /dev/null 2>&1                                  # the decimating front end (D = 4)
-bash tools/profile_round.sh ${R}_am_narrow am_narrow > /dev/null 2>&1                            # all-AM at +-4 kHz: the general audio path beside the waterfall kernel
+bash tools/profile_round.sh ${R}_am_narrow am_narrow > /dev/null 2>&1                            # all-AM at +-4 kHz, every channel on the general audio path: ssdr_run_chain's wave-specialised kernel
+bash tools/profile_round.sh ${R}_am_narrow_two_kernels am_narrow --fused 0 > /dev/null 2>&1      # ... and the general audio kernel beside the waterfall kernel (round 5's default)
 bash tools/profile_round.sh ${R}_mixed_chain_ws mixed --fused 3 > /dev/null 2>&1                 # the wave-specialised one-read kernel on configs[3] (opt-in there)
 for d in gpurun_out/prof_${R}_*; do echo "== $d"; head -6 $d/kernel_stats.txt; done
