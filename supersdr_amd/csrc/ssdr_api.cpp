@@ -434,7 +434,6 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         HIP_TRY(hipMalloc(&c->d_state, (size_t)n_channels * sizeof(ssdr_chan_state)));
         HIP_TRY(hipMalloc(&c->d_chan_list, (size_t)n_channels * sizeof(uint32_t)));
         HIP_TRY(hipMalloc(&c->d_ws_list, ((size_t)n_channels + 1) * sizeof(uint32_t)));
-        HIP_TRY(hipMemset(c->d_ws_list + n_channels, 0, sizeof(uint32_t)));
         c->h_consts.resize(n_channels);
         c->h_params.resize(n_channels);
         HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -761,7 +760,7 @@ static int ensure_chan_list(ssdr_ctx *c, hipStream_t s)
     // the chain list of the wave-specialised kernel: consecutive channels of the sorted list form pairs (so a pair is of one path,
     // except where two paths meet); the pairs of the three paths are dealt out evenly over the list -- pair m of a path with p pairs
     // sits at (m + 1/2) / p of the way -- so that at any time the trios of a workgroup work on the ctx's mix of paths
-    std::vector<uint32_t> ws(c->n_ch);
+    std::vector<uint32_t> ws((size_t)c->n_ch + 1, 0u);      // (+ the ticket word: it starts over at zero with every new list)
     {
         const uint32_t n_pairs = (c->n_ch + 1) / 2;
         std::vector<uint32_t> first_of[SSDR_PATH_COUNT];                   // pairs by the path of their first channel
@@ -780,7 +779,8 @@ static int ensure_chan_list(ssdr_ctx *c, hipStream_t s)
             if (2 * o.second + 1 < c->n_ch) ws[w++] = list[2 * o.second + 1];
         }
     }
-    HIP_TRY(hipMemcpyAsync(c->d_ws_list, ws.data(), (size_t)c->n_ch * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_ws_list, ws.data(), ((size_t)c->n_ch + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    c->ws_ticket = 0;
     HIP_TRY(hipStreamSynchronize(s));    // `list` goes out of scope
     for (int p = 0; p < SSDR_PATH_COUNT; p++) { c->path_off[p] = off[p]; c->path_n[p] = cnt[p]; }
     c->chan_list_dirty = false;
