@@ -560,6 +560,49 @@ def test_pipelined_feed_through_the_fused_kernel_equals_the_two_kernels(S):
             assert np.array_equal(got[b][k], want[b][k]), (b, k)
 
 
+def test_pipelined_feed_through_the_wave_specialised_kernel_equals_the_two_kernels(S):
+    """The feed's batches with every channel on the general audio path (SSB, CW, a narrowed AM passband), 8 frames per slot, N = 3: ssdr_run_chain
+    takes ssdr_chain_ws_kernel (its ticket counter only counts up from slot to slot, the slots' input buffers change under it).  Waterfall sums,
+    PCM, RSSI and ADC flags, batch after batch with the state carried, equal what the two per-stage kernels give synchronously."""
+    n_ch, nf, n_batches = 21, 8, 5
+    iq = O.synth_iq(n_ch, n_batches * nf * 512, seed=717)
+    iq[7, 11 * 512 + 3, 1] = -32768
+    kinds = [("usb", {}), ("lsb", {}), ("cw", {}), ("am", {"low_cut": -3000.0, "high_cut": 3000.0})]
+    ps = [S.default_params(kinds[c % 4][0], f_shift_hz=150.0 * c - 1500.0, agc_hang=int(c == 2), **kinds[c % 4][1]) for c in range(n_ch)]
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.set_averaging(3)
+        eng.set_fused(False)
+        want = []
+        for b in range(n_batches):
+            eng.push_iq(iq[:, b * nf * 512:(b + 1) * nf * 512])
+            lines, fused = eng.run_chain()
+            assert not fused
+            wf = eng.fetch_wf(lines).copy() if lines else np.zeros((0, n_ch, 1024), np.int16)
+            pcm, rssi = eng.fetch_audio()
+            want.append((wf, pcm.copy(), rssi.copy(), eng.audio_flags().copy()))
+    assert sum(int(w[3].sum()) for w in want) >= 1
+    with S.SsdrEngine(n_ch) as eng:
+        eng.set_params(0, ps)
+        eng.set_averaging(3)
+        eng.set_profiling(True)
+        eng.feed_open(nf, depth=2)
+        got = []
+        for b in range(n_batches):
+            if b >= 2:
+                got.append(tuple(x.copy() for x in eng.feed_collect()) + (eng.feed_flags.copy(),))
+            eng.feed_slot()[:] = iq[:, b * nf * 512:(b + 1) * nf * 512]
+            eng.feed_submit()
+        while len(got) < n_batches:
+            got.append(tuple(x.copy() for x in eng.feed_collect()) + (eng.feed_flags.copy(),))
+        eng.feed_close()
+        from supersdr_amd import _lib as L
+        assert eng.kernel_stats(L.K_FUSED)[1] == n_batches and eng.kernel_stats(L.K_WF)[1] == 0 and eng.kernel_stats(L.K_AUDIO)[1] == 0
+    for b in range(n_batches):
+        for k in range(4):
+            assert np.array_equal(np.asarray(got[b][k]).reshape(np.asarray(want[b][k]).shape), want[b][k]), (b, k)
+
+
 def test_pipelined_feed_wire_mode(S):
     """SSDR_FEED_WIRE: SND bodies (big-endian, 17-byte header) in, same results as the int16 path, header rssi out"""
     import struct
