@@ -178,20 +178,26 @@ int ssdr_audio_iq(ssdr_ctx *ctx, int16_t *iq_out, int out_is_device);
 /* Both stages on the current batch, results kept on the device (ssdr_wf_device / ssdr_audio_device / ssdr_audio_flags): what
  * ssdr_run_wf followed by ssdr_run_audio do, with results that are theirs bit for bit.  *fused (may be NULL) tells which way it went:
  *   1  every channel is on the reference's full-band AM passband, N = 1, hop 1024, 12 kHz IQ, no zoom, an even number of at least 8
- *      frames (the configuration of the metric): ONE kernel does both, each 4 KB line is read once for its FFT and its two audio
+ *      frames, and the ctx has at least ssdr_get_chain_floors' first number of channels (the configuration of the metric): ONE kernel does both, each 4 KB line is read once for its FFT and its two audio
  *      frames (ssdr_fused_am_kernel);
  *   2  every channel has a channel filter to apply (SSB, CW, IQ, a narrowed AM / NBFM passband: the general audio path), hop 1024,
- *      12 kHz IQ, no zoom, fp32 bins, any N, an even number of at least 8 frames: one kernel again, in which audio waves hand every
+ *      12 kHz IQ, no zoom, fp32 bins, any N, an even number of at least 8 frames, at least the second floor's channels: one kernel again, in which audio waves hand every
  *      raw frame to an FFT wave of their workgroup through the LDS (ssdr_chain_ws_kernel, round 6: one read of the input,
  *      1-2 % faster than the stages side by side);
  *   0  every other batch: the two stages side by side on two streams (ssdr_set_overlap).
  * ssdr_set_fused(ctx, 0) keeps the two kernels in every case.  The pipelined feed (ssdr_feed_*) runs its batches through this call. */
 int ssdr_run_chain(ssdr_ctx *ctx, uint32_t *lines_ready, int *fused);
-/* 0: never a one-read kernel; 1 (default): as listed at ssdr_run_chain; 2: ssdr_fused_am_kernel at hop 512 and with N > 1 as well
- * (there the two stages side by side are as fast or faster: ssdr_set_overlap); 3: ssdr_chain_ws_kernel for EVERY batch it can take --
+/* 0: never a one-read kernel; 1 (default): as listed at ssdr_run_chain; 2: ssdr_fused_am_kernel at hop 512, with N > 1 and below its channel
+ * floor as well (there the two stages side by side are as fast or faster: ssdr_set_overlap); 3: ssdr_chain_ws_kernel for EVERY batch it can take --
  * any mix of audio paths (full-band channels among them), any filter, any N, an even number of frames at hop 1024: on BASELINE's
  * configs[3] 1 % slower than the stages side by side, with 39 % less HBM traffic (profiles/r06_ab_chain_ws.txt). */
 int ssdr_set_fused(ssdr_ctx *ctx, int on);
+/* The batch sizes from which ssdr_run_chain's default (level 1) takes a one-read kernel.  Below them the two stages side by side are the faster way
+ * (a one-read kernel walks all lines of a channel pair in ONE wave; the waterfall kernel spreads them over the chip): at the reference's own scale,
+ * tens of receivers, 2-3 x.  ssdr_create sets them from the device (MI355X: 8192 channels for ssdr_fused_am_kernel = one pair per resident wave,
+ * 32768 for ssdr_chain_ws_kernel); 0 = no floor.  ssdr_set_fused(ctx, 2) / (ctx, 3) ignore the respective floor. */
+int ssdr_set_chain_floors(ssdr_ctx *ctx, uint32_t fused_am_min_channels, uint32_t chain_ws_min_channels);
+int ssdr_get_chain_floors(ssdr_ctx *ctx, uint32_t *fused_am_min_channels, uint32_t *chain_ws_min_channels);
 /* Batches ssdr_run_chain does not fuse (mixed modes, N > 1, hop 512, float64 bins, ...) run their two stages SIDE BY SIDE: the audio
  * stage on a second HIP stream beside the waterfall kernel, both reading the same input batch (default on; results are those of
  * one after the other, bit for bit).  Every later call that needs the audio stage's results, its state or the input buffer

@@ -89,6 +89,8 @@ _SIGS = {
     "ssdr_audio_iq": (C.c_int, [_P, _P, C.c_int]),
     "ssdr_run_chain": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "ssdr_set_fused": (C.c_int, [_P, C.c_int]),
+    "ssdr_set_chain_floors": (C.c_int, [_P, C.c_uint32, C.c_uint32]),
+    "ssdr_get_chain_floors": (C.c_int, [_P, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "ssdr_set_overlap": (C.c_int, [_P, C.c_int]),
     "ssdr_sync": (C.c_int, [_P]),
     "ssdr_set_post_channels": (C.c_int, [_P, _P, C.c_uint32]),

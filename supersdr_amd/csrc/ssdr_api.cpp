@@ -80,6 +80,7 @@ struct ssdr_ctx {
     int fused_enabled = 1;                              // ssdr_set_fused: 0 never, 1 at hop 1024 (default), 2 at hop 512 as well, 3 + the wave-specialised kernel
     bool fuse_ws_next = false;                          // ... and that kernel is ssdr_chain_ws_kernel (any mix of audio paths)
     uint32_t ws_grid = 0;
+    uint32_t am_floor = 0, ws_floor = 0;                // ssdr_set_chain_floors: fewest channels for which ssdr_run_chain's default takes a one-read kernel
     bool overlap_enabled = true;                        // ssdr_set_overlap: un-fused ssdr_run_chain batches run the audio stage beside the waterfall kernel
     bool fuse_next = false;                             // ssdr_run_chain: run_wf parks its arguments, run_audio launches the fused kernel
     SsdrWfArgs fused_wf;
@@ -470,6 +471,12 @@ int ssdr_create(int device_id, uint32_t n_channels, uint32_t nfft, uint32_t fram
         int ws_per_cu = 0;
         HIP_TRY(ssdr_chain_ws_blocks_per_cu(&ws_per_cu));
         c->ws_grid = (uint32_t)prop.multiProcessorCount * (uint32_t)(ws_per_cu < 0 ? 0 : ws_per_cu);     // 0: not resident on this device, never chosen
+        // Below these batch sizes the two stages side by side are FASTER than a one-read kernel (profiles/r06_ab_small_batches.txt): a one-read kernel
+        // walks all lines of a channel pair in one wave, the waterfall kernel spreads them over the chip.  Fused AM kernel: one channel pair per
+        // resident wave (8192 channels on an MI355X: -3 % at 6144, +10 % at 8192; 2.8 x slower at 64); wave-specialised kernel: 16 pairs per trio
+        // (32768 channels: +1.2 % on narrowed AM; 2 x slower at 1024).
+        c->am_floor = 2u * c->fused_grid * (SSDR_WF_BLOCK / 64);
+        c->ws_floor = 2u * 16u * c->ws_grid * (SSDR_WS_AUDIO_WAVES / 2);
         return SSDR_OK;
     }();
     if (rc == SSDR_OK) {
@@ -1110,6 +1117,7 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused) SSDR_GUARD
     const bool eligible = n_am == c->n_ch && c->decim == 1 && (hop512 || !(c->in_frames & 1u)) &&
                           c->in_frames >= 8 &&
                           !c->concurrent && c->fused_grid != 0 && c->fused_enabled >= ((hop512 || c->n_avg > 1) ? 2 : 1) && c->zoom == 1 &&
+                          (c->fused_enabled >= 2 || c->n_ch >= c->am_floor) &&
                           (!c->exact_bins || (!hop512 && c->n_avg == 1));
     // the wave-specialised kernel (ssdr_chain_ws.hip): any mix of audio paths, any filter and any N at hop 1024, fp32 bins -- both stages on one
     // read of the input.  By default where it is also the faster way (profiles/r06_ab_chain_ws.txt): when every channel runs the general path
@@ -1117,7 +1125,8 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused) SSDR_GUARD
     // for every batch it can take with ssdr_set_fused(ctx, 3) (full-band channels among them: 1 % slower than side by side, 39 % less HBM traffic)
     const bool ws_can = c->ws_grid != 0 && c->decim == 1 && !hop512 && !(c->in_frames & 1u) && !c->concurrent && c->zoom == 1 && !c->exact_bins;
     const bool eligible_ws = !eligible && ws_can &&
-                             (c->fused_enabled >= 3 || (c->fused_enabled >= 1 && c->sum_paths[SSDR_PATH_GENERAL] == c->n_ch && c->in_frames >= 8));
+                             (c->fused_enabled >= 3 || (c->fused_enabled >= 1 && c->sum_paths[SSDR_PATH_GENERAL] == c->n_ch && c->in_frames >= 8 &&
+                                                        c->n_ch >= c->ws_floor));
     if (fused) *fused = eligible ? 1 : (eligible_ws ? 2 : 0);
     c->fuse_next = eligible || eligible_ws;
     c->fuse_ws_next = eligible_ws;
@@ -1160,6 +1169,22 @@ int ssdr_set_fused(ssdr_ctx *c, int on) SSDR_GUARD
 {
     if (!c || on < 0 || on > 3) return SSDR_EINVAL;
     c->fused_enabled = on;
+    return SSDR_OK;
+} SSDR_UNGUARD
+
+int ssdr_set_chain_floors(ssdr_ctx *c, uint32_t fused_am_min_channels, uint32_t chain_ws_min_channels) SSDR_GUARD
+{
+    if (!c) return SSDR_EINVAL;
+    c->am_floor = fused_am_min_channels;
+    c->ws_floor = chain_ws_min_channels;
+    return SSDR_OK;
+} SSDR_UNGUARD
+
+int ssdr_get_chain_floors(ssdr_ctx *c, uint32_t *fused_am_min_channels, uint32_t *chain_ws_min_channels) SSDR_GUARD
+{
+    if (!c) return SSDR_EINVAL;
+    if (fused_am_min_channels) *fused_am_min_channels = c->am_floor;
+    if (chain_ws_min_channels) *chain_ws_min_channels = c->ws_floor;
     return SSDR_OK;
 } SSDR_UNGUARD
 

@@ -48,11 +48,19 @@ def table(which):
     return out
 
 
+# run_chain's channel-count floors of every new SsdrEngine: None = the library's (from the device); (0, 0) = none -- what a test suite that wants the
+# one-read kernels on its small batches sets (tests/conftest.py)
+DEFAULT_CHAIN_FLOORS = None
+
+
 class SsdrEngine:
-    def __init__(self, n_channels, device=0):
+    def __init__(self, n_channels, device=0, chain_floors=None):
         self.n_ch = int(n_channels)
         self._ctx = L._P()
         check(lib.ssdr_create(int(device), self.n_ch, L.NFFT, L.FRAME, C.byref(self._ctx)), "ssdr_create")
+        floors = DEFAULT_CHAIN_FLOORS if chain_floors is None else chain_floors          # "library": leave the device-derived ones alone
+        if floors is not None and floors != "library":
+            self.set_chain_floors(*floors)
         self.in_frames = 0
         self.hop = L.NFFT
         self.decim = 1
@@ -182,6 +190,15 @@ class SsdrEngine:
         wave-specialised chain kernel for batches whose channels all run the general audio path; 2: the former at hop 512 / N > 1 as well;
         3: the latter for every batch it can take (any mix of audio paths at hop 1024)"""
         check(lib.ssdr_set_fused(self._ctx, int(on)), "ssdr_set_fused")
+
+    def set_chain_floors(self, fused_am_min_channels, chain_ws_min_channels):
+        """fewest channels for which run_chain's default takes the fused AM / the wave-specialised kernel (0: no floor)"""
+        check(lib.ssdr_set_chain_floors(self._ctx, int(fused_am_min_channels), int(chain_ws_min_channels)), "ssdr_set_chain_floors")
+
+    def chain_floors(self):
+        a, w = C.c_uint32(0), C.c_uint32(0)
+        check(lib.ssdr_get_chain_floors(self._ctx, C.byref(a), C.byref(w)), "ssdr_get_chain_floors")
+        return a.value, w.value
 
     def set_overlap(self, on):
         """un-fused run_chain batches: the audio stage beside the waterfall kernel on a second stream (default on)"""

@@ -1572,6 +1572,38 @@ def test_wave_specialised_kernel_at_the_timed_shapes(S, workload, n_avg, sf):
     assert got[0] == got[3]
 
 
+def test_run_chain_floors_keep_small_batches_on_the_two_kernels(S):
+    """ssdr_run_chain's default takes a one-read kernel only from a batch size on (ssdr_get_chain_floors, from the device: one channel pair per
+    resident wave for the fused AM kernel, 16 pairs per trio for the wave-specialised one) -- below it the two stages side by side are 2-3 x
+    faster (profiles/r06_ab_small_batches.txt).  The levels that ask for a kernel explicitly ignore its floor; the floors can be set."""
+    with S.SsdrEngine(64, chain_floors="library") as eng:
+        am_floor, ws_floor = eng.chain_floors()
+        assert 1024 <= am_floor <= 65536 and am_floor <= ws_floor <= 262144
+        eng.synth_iq(16)
+        assert eng.run_chain()[1] == 0                    # 64 full-band AM receivers: far below the floor
+        eng.set_fused(2)
+        assert eng.run_chain()[1] == 1
+        eng.set_fused(1)
+        eng.set_params(0, [S.default_params("usb")] * 64)
+        assert eng.run_chain()[1] == 0
+        eng.set_fused(3)
+        assert eng.run_chain()[1] == 2
+        eng.set_fused(1)
+        eng.set_chain_floors(0, 64)
+        assert eng.chain_floors() == (0, 64) and eng.run_chain()[1] == 2
+        eng.set_chain_floors(0, 65)
+        assert eng.run_chain()[1] == 0
+    with S.SsdrEngine(am_floor, chain_floors="library") as eng:      # at the floor: the fused AM kernel
+        eng.synth_iq(8)
+        assert eng.run_chain()[1] == 1
+    with S.SsdrEngine(ws_floor, chain_floors="library") as eng:      # at the floor: the wave-specialised kernel
+        ps = [S.default_params("usb", f_shift_hz=100.0 * (c % 9)) for c in range(256)]
+        for first in range(0, ws_floor, 256):
+            eng.set_params(first, ps[: min(256, ws_floor - first)])
+        eng.synth_iq(8)
+        assert eng.run_chain()[1] == 2
+
+
 def test_run_chain_side_by_side_stages_are_bit_identical_and_joined_before_what_depends_on_them(S):
     """Round 4: a batch ssdr_run_chain does not fuse runs its audio stage on a second stream beside the waterfall kernel
     (ssdr_set_overlap, default on).  Same bytes as one after the other -- waterfall sums (N = 3 groups straddling calls, hop 512),

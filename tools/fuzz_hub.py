@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     import supersdr_amd as S
+    import supersdr_amd.engine as _E
+    _E.DEFAULT_CHAIN_FLOORS = (0, 0)                    # small batches through the one-read kernels too (ssdr_set_chain_floors)
     from supersdr_amd.workers import IQHub
     lines, bad, items, stalls, t0 = [], 0, 0, 0, time.time()
     for seed in range(a.first, a.first + a.count):

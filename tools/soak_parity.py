@@ -33,6 +33,8 @@ def main():
         sweeps = [("twin vs float64 oracle, 24 ch x 6 frames", lambda s: TK.test_twin_tracks_float64_oracle_over_random_parameters(s, 6))]
         return run_sweeps(a, sweeps, T)
     import supersdr_amd as S
+    import supersdr_amd.engine as _E
+    _E.DEFAULT_CHAIN_FLOORS = (0, 0)                    # small batches through the one-read kernels too (ssdr_set_chain_floors)
     import twinlib
     import test_gpu_parity as TP
     import test_gpu_post as TQ
