@@ -1157,8 +1157,19 @@ int ssdr_run_chain(ssdr_ctx *c, uint32_t *lines_ready, int *fused) SSDR_GUARD
         c->concurrent = false;                       // (audio_pending stays set: whoever needs the results or the input joins first)
         if (rc == SSDR_OK && c->stream != c->own_stream) rc = join_audio(c);     // a caller's stream (ssdr_set_stream): what they order behind it covers both stages
     } else {
+        // a one-read kernel: ssdr_run_wf only does the waterfall stage's bookkeeping and parks its arguments, ssdr_run_audio launches.  Should the
+        // launch fail, the bookkeeping goes back to where it stood: both stages or neither
+        const uint32_t phase0 = c->wf_phase, ready0 = c->wf_lines_ready;
+        const int acc0 = c->wf_acc_cur;
+        const bool one_read = c->fuse_next;
         rc = ssdr_run_wf(c, nullptr, lines_ready, 0);
-        if (rc == SSDR_OK) rc = ssdr_run_audio(c, nullptr, nullptr, 0);
+        if (rc == SSDR_OK) {
+            rc = ssdr_run_audio(c, nullptr, nullptr, 0);
+            if (rc != SSDR_OK && one_read) {
+                c->wf_phase = phase0; c->wf_lines_ready = ready0; c->wf_acc_cur = acc0;
+                if (lines_ready) *lines_ready = 0;
+            }
+        }
     }
     c->fuse_next = false;
     c->fuse_ws_next = false;

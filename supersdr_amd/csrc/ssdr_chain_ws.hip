@@ -1,6 +1,6 @@
 // ssdr_chain_ws.hip -- both stages on ONE read of the input for ANY mix of audio frame paths, by WAVE SPECIALISATION inside a
 // workgroup (round 6; successor of round 5's ssdr_fused_gen_kernel, which time-shared one wave between the two stages and lost 45 %
-// to the register and LDS squeeze: profiles/r05_ab_fused_general.txt, tools/experiments/ssdr_fused_gen.hip).
+// to the register and LDS squeeze: profiles/r05_ab_fused_general.txt; deleted, its source is in the history at 848c201).
 //
 // Stands where the reference receives W/F lines and SND frames of the same receiver from its server (utils_supersdr.py:780-785,
 // 1044-1076); tap formula of the channel filter: utils_supersdr.py:334-344 (ssdr_tables.cpp); what a listener's passband change

@@ -1,5 +1,5 @@
 // ssdr_wf_dev.h -- device pieces of the waterfall stage shared by the kernels that contain a 1024-point line FFT
-// (ssdr_wf.hip: ssdr_wf_kernel, ssdr_fused_am_kernel; ssdr_fused_gen.hip: ssdr_fused_gen_kernel): the LDS map of the tables,
+// (ssdr_wf.hip: ssdr_wf_kernel, ssdr_fused_am_kernel; ssdr_chain_ws.hip: the FFT waves of ssdr_chain_ws_kernel): the LDS map of the tables,
 // the 6-FMA butterflies and register stages, the one-transpose FFT of a 32-lane half, the window folded into stage 1, the
 // threshold-count dB quantiser.  "wave64 == two FFTs, 32 points per lane"; see ssdr_wf.hip for the mapping.
 // The including file defines WAVES (waves per workgroup) and LDS_TOTAL after this header.
