@@ -1543,12 +1543,13 @@ def test_run_chain_default_takes_the_wave_specialised_kernel_where_every_channel
         assert eng.run_chain()[1] == 2
 
 
-@pytest.mark.parametrize("workload,n_avg,sf", [("am_narrow", 1, 16), ("mixed", 10, 10)])
-def test_wave_specialised_kernel_at_the_timed_shapes(S, workload, n_avg, sf):
+@pytest.mark.parametrize("workload,n_avg,sf,n_ch", [("am_narrow", 1, 16, 65536), ("mixed", 10, 10, 65536), ("am_narrow", 1, 16, 1 << 20)])
+def test_wave_specialised_kernel_at_the_timed_shapes(S, workload, n_avg, sf, n_ch):
     """bench.py's extra.full_am_narrow (ssdr_run_chain's default there) and extra.mixed_chain_ws (configs[3] with ssdr_set_fused 3) exactly
     as timed -- 65536 channels, synthetic input, the bench's parameter pattern: two steps through ssdr_chain_ws_kernel leave the two
-    kernels' bytes (checksums of every waterfall sum, PCM sample and RSSI value; carried state; raw history)"""
-    n_ch = 65536
+    kernels' bytes (checksums of every waterfall sum, PCM sample and RSSI value; carried state; raw history).  And configs[4]'s shape with
+    every receiver on a narrowed passband: 2^20 channels x 16 superframes, 64 GiB of input and as much of results -- offsets beyond 2^32
+    elements in every row the kernel addresses, half a million tickets."""
     modes = ("am",) if workload == "am_narrow" else ("am", "usb", "lsb", "nbfm")
     over = {"low_cut": -4000.0, "high_cut": 4000.0} if workload == "am_narrow" else {}
     period = 97 * len(modes)
