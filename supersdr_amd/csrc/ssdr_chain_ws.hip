@@ -22,10 +22,19 @@
 //     wave took what sat there (it did so -- 16 LDS reads per frame -- a frame's worth of audio work earlier unless it has fallen
 //     behind).  The FFT wave waits for both producers of a frame, copies it into registers and hands the place back at once.
 //     No s_barrier after the tables are loaded; waiting waves sleep (s_sleep) and give the issue port to the others.
+//     Progress: a workgroup's twelve waves are resident together; a producer only ever waits for its consumer to have taken the frame
+//     RF places back, the consumer only for frames its producers file without waiting on it again -- no cycle; a slot without a channel
+//     (odd channel count) publishes its frames at once; the ticket that runs past the list ends a trio.
+//   * the audio waves ask for frame f + 1 before they work on frame f (8 more registers; at 3 waves per SIMD nothing else hides
+//     the HBM latency of a frame: -4 % time on all-filtering batches).
 // The input is read from HBM once; nothing of one stage lives in the other's registers; the instruction count is the two
 // kernels' plus the ring writes and the polls.  Results are the two kernels' bit for bit (same code, same scan orders).
 // Batches it takes: hop 1024, whole lines, 12 kHz IQ (D = 1), no waterfall zoom, fp32 bins; any mix of modes incl. SSDR_MODE_IQ,
 // any filter length, any N.
+// MEASURED (profiles/r06_ab_chain_ws.txt): 145 VGPRs, no scratch, 150.7 KB of LDS, 84 % of the SIMDs' quad-cycles issue a vector
+// instruction, HBM traffic 1.02 x the fused budget; +2 % against the two stages side by side where every channel filters, a tie on
+// all-SSB, -0.6 ... -1.5 % with full-band channels in the batch: both schedules sit at the board's power cap and spend the same joules.
+// ssdr_run_chain takes it by default where every channel runs the general path, from 32 768 channels on (ssdr_api.cpp).
 #include "ssdr_math.h"
 #include "ssdr_kernels.h"
 #include "ssdr_audio_dev.h"
