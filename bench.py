@@ -434,6 +434,47 @@ def parity_probe(S, local_rank, workload, first_channel_id, channels=256, sframe
         return eng.output_checksum()
 
 
+class EnergyProbe:
+    """The board's energy accumulator (rocm_smi: rsmi_dev_energy_count_get, 15.3 uJ steps) around a timed region -> joules and average socket
+    power of the GPU this rank runs on.  DESIGN.md section 5: every chain kernel sits at the board's power cap, so a step costs its joules;
+    the line carries the evidence (roofline.power, extra.*.avg_watts).  None wherever the library or the counter is missing."""
+    _lib = None
+
+    def __init__(self, device_index):
+        import ctypes as C
+        self.C, self.dev, self.ok, self.cap = C, int(device_index), False, None
+        try:
+            if EnergyProbe._lib is None:
+                lib = C.CDLL("librocm_smi64.so")
+                if lib.rsmi_init(C.c_uint64(0)) != 0:
+                    return
+                EnergyProbe._lib = lib
+            self.ok = self._read() is not None
+            cap = C.c_uint64(0)
+            if self.ok and EnergyProbe._lib.rsmi_dev_power_cap_get(C.c_uint32(self.dev), C.c_uint32(0), C.byref(cap)) == 0:
+                self.cap = cap.value / 1e6                      # microwatts
+        except (OSError, AttributeError):
+            self.ok = False
+
+    def _read(self):
+        C = self.C
+        e, res, ts = C.c_uint64(0), C.c_float(0.0), C.c_uint64(0)
+        if EnergyProbe._lib.rsmi_dev_energy_count_get(C.c_uint32(self.dev), C.byref(e), C.byref(res), C.byref(ts)) != 0:
+            return None
+        return e.value * float(res.value) * 1e-6               # joules
+
+    def start(self):
+        self.e0 = self._read() if self.ok else None
+
+    def stop(self, seconds, steps):
+        e1 = self._read() if self.ok and self.e0 is not None else None
+        if e1 is None or seconds <= 0 or e1 < self.e0:
+            return None
+        j = e1 - self.e0
+        return {"avg_watts": round(j / seconds, 1), "joules_per_step": round(j / steps, 4), "cap_watts": self.cap,
+                "source": "rocm_smi energy accumulator of this rank's GPU over the timed region"}
+
+
 def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sframes, steps, warmup, spinup,
             concurrent=0, host_feed=0, hop=1024, fused=1, exact=0, first_channel_id=None, overlap=1):
     """Spin the clocks up, W warm-up steps, then exactly `steps` timed steps between barrier + synchronize pairs.
@@ -505,8 +546,10 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     eng.set_profiling(True)                 # HIP-event pair around every launch, on the launch stream, no host sync
     for k in (L.K_WF, L.K_AUDIO, L.K_FUSED):
         eng.kernel_stats(k, reset=True)
+    probe = EnergyProbe(local_rank)
     rdv.barrier()
     torch.cuda.synchronize()
+    probe.start()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -516,6 +559,7 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     eng.sync()
     torch.cuda.synchronize()
     own_wall = time.perf_counter() - t0                        # this rank's own time (reported per rank, never the value)
+    power = probe.stop(own_wall, steps)
     rdv.barrier()
     wall = rdv.max_over_ranks(time.perf_counter() - t0)
 
@@ -562,7 +606,7 @@ def measure(S, L, torch, rdv, rank, world, local_rank, workload, channels, sfram
     for st in stages.values():
         st["side_by_side"] = side                       # the two stages ran beside each other: their durations overlap
     return {"value": units / wall / RT_SUPERFRAMES_PER_S, "ms_per_step": wall / steps * 1e3, "stages": stages,
-            "n_avg": n_avg, "paths": paths, "decim": decim, "side_by_side": side, "chain_kind": chain_kind[0],
+            "n_avg": n_avg, "paths": paths, "decim": decim, "side_by_side": side, "chain_kind": chain_kind[0], "power": power,
             "own_value": channels * sframes * steps / own_wall / RT_SUPERFRAMES_PER_S}
 
 
@@ -1054,6 +1098,9 @@ def main():
                      "note": "each rank's own channel-superframes / its own wall time; `value` uses the max wall over ranks"},
         "roofline": roofline(stages[dom], stage_traffic(traffic, stages[dom]), src),
     }
+    if m.get("power"):
+        # what the chain is bound by: the board's power cap.  Socket power of rank 0's GPU over the timed region
+        full["roofline"]["power"] = m["power"]
     # every measured kernel on every configuration, one short entry each: what the driver's record keeps of the line
     summary = {}
 
@@ -1127,6 +1174,9 @@ def main():
                           "input_decimation": e["decim"],
                           "audio_paths": {PATH_TEXT[p]: e["paths"][p] for p in range(3) if e["paths"][p]} if WORKLOADS[wl][5] else {},
                           "rooflines": [note("%s.%s" % (key, sk), sv, tr, tsrc) for sk, sv in e["stages"].items()]}
+            if e.get("power"):
+                extra[key]["avg_watts"] = e["power"]["avg_watts"]
+                extra[key]["joules_per_step"] = e["power"]["joules_per_step"]
             if WORKLOADS[wl][4] and WORKLOADS[wl][5]:
                 extra[key].update(chain_frac(e, ch, sf, e["n_avg"], kw.get("hop", 1024)))
             return e
@@ -1223,7 +1273,7 @@ def compact_line(full):
     out["roofline"] = {k: r[k] for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_hbm", "frac_of_measured_stream", "measured_stream_GBps",
                                           "measured_stream_mix", "measured_stream_source", "traffic", "traffic_source",
                                           "traffic_commit", "traffic_csrc_sha256", "traffic_matches_this_build", "avg_kernel_ms",
-                                          "algorithmic_bytes_per_launch", "stages") if k in r}
+                                          "algorithmic_bytes_per_launch", "stages", "power") if k in r}
     out["build"] = full.get("build")
     if "cpu_baseline" in full:
         cb = full["cpu_baseline"]
@@ -1245,7 +1295,7 @@ def compact_line(full):
                 out["extra"][k] = {"error": v["error"]}
             elif "value" in v:
                 out["extra"][k] = {kk: (round(v[kk], 4) if isinstance(v[kk], float) else v[kk])
-                                   for kk in ("value", "ms_per_step", "chain_frac", "scaling", "n_gpus", "channels_total", "channels_per_gpu", "kernels", "parity") if kk in v}
+                                   for kk in ("value", "ms_per_step", "chain_frac", "avg_watts", "joules_per_step", "scaling", "n_gpus", "channels_total", "channels_per_gpu", "kernels", "parity") if kk in v}
                 if "per_rank" in v:
                     out["extra"][k]["per_rank"] = {kk: v["per_rank"][kk] for kk in ("value_min", "value_max", "values")}
             elif k == "ui_hub":
