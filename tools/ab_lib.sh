@@ -10,6 +10,6 @@ for round in $(seq 1 $R); do for spec in $W; do
     printf "%-22s %-10s " "$spec" $v
     SSDR_LIB_PATH=$lib python bench.py --workload $wl $fl --steps $STEPS --warmup 2 --no-cpu-baseline --verbose-line --no-extra --no-parity-probe 2>/dev/null | python -c "
 import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e6,3), 'M', round(d['ms_per_step'],3), 'ms')"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e6,3), 'M', round(d['ms_per_step'],3), 'ms', (d.get('roofline') or {}).get('power', {}).get('avg_watts'), 'W', (d.get('roofline') or {}).get('power', {}).get('joules_per_step'), 'J')"
   done
 done; done

@@ -8,7 +8,7 @@ run() {  # label lib fused spec
   printf "%-20s %-12s " $4 $1
   SSDR_LIB_PATH=$2 python bench.py --workload $wl $fl --fused $3 --steps $STEPS --warmup 2 --no-cpu-baseline --verbose-line --no-extra --no-parity-probe 2>/dev/null | python -c "
 import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e6,2), 'M', round(d['ms_per_step'],3), 'ms', d['config']['chain'][:34])"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e6,2), 'M', round(d['ms_per_step'],3), 'ms', d['config']['chain'][:34], (d.get('roofline') or {}).get('power', {}).get('avg_watts'), 'W', (d.get('roofline') or {}).get('power', {}).get('joules_per_step'), 'J')"
 }
 for round in $(seq 1 $R); do for spec in $W; do
   run side_by_side $PWD/supersdr_amd/libssdr.so 0 $spec        # (--fused 0: the two stages side by side on two streams)
