@@ -204,3 +204,24 @@ def test_numa_cpulist_parser():
     spec.loader.exec_module(b)
     assert b.parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11} and b.parse_cpulist("") == set()
     assert b.bind_to_numa_node(None) == {"gpu_numa_node": None, "bound": False}
+
+
+def test_energy_probe_is_silent_where_there_is_no_counter():
+    """bench.py's roofline.power comes from the board's energy accumulator (rocm_smi); on a host without a GPU, without the library or for a
+    device index that does not exist the probe yields None -- it never raises and never holds the line up"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    for dev in (0, 63):
+        p = bench.EnergyProbe(dev)
+        p.start()
+        r = p.stop(0.5, 10)
+        assert r is None or (r["avg_watts"] >= 0 and r["joules_per_step"] >= 0)
+    q = bench.EnergyProbe(0)
+    q.start()
+    assert q.stop(0.0, 10) is None                        # no time, no figure
