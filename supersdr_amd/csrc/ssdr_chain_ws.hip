@@ -12,8 +12,8 @@
 // SIMD at any time instead of following each other.
 //   * an AUDIO wave IS ssdr_audio.hip's kernel for its channel -- ssdr_audio_chan.h:channel_frames<PATH>, carried state in registers
 //     for the whole call, the general path's FIR work area at the stand-alone kernel's conflict-free 80-byte lane stride -- and does
-//     one thing more: the 32 bytes of raw samples a lane has just loaded for a frame go into the channel's RING (SSDR_WS_RING_FRAMES
-//     frames of 2 KB per channel, natural order) as well.  Two frames make a line.
+//     one thing more: the 32 bytes of raw samples a lane has just loaded for a frame go into the channel's RING (three frames
+//     of 2 KB per channel, natural order) as well.  Two frames make a line.
 //   * an FFT wave is ssdr_wf.hip's kernel body for a channel pair (one FFT per 32-lane half, ssdr_wf_dev.h), except that a line's
 //     samples come out of the two rings (ds_read_b32, lane-consecutive) instead of out of HBM.  It owns its pair for the whole call,
 //     so with N > 1 the N-line sums stay in its registers across the group's lines.
@@ -48,7 +48,8 @@ constexpr int NF = NA / 2;                                       // FFT waves = 
 constexpr int WAVES = NA + NF;
 static_assert(NA % 2 == 0 && WAVES * 64 == SSDR_WS_BLOCK, "workgroup shape");
 constexpr int A_BYTES = NOCT * OCT * 8 + (SSDR_NTAP_MAX + 8) * 4; // FIR work area 6400 + taps 544 per audio wave
-constexpr int RF = SSDR_WS_RING_FRAMES;                          // frames a channel's ring holds (1: half a line, 2: a line)
+constexpr int RF = 3;                                            // 512-sample frames of raw IQ a channel's ring holds (6 KB; four do not fit the LDS)
+constexpr int NAP_SHORT = 1, NAP_LONG = 8, SHORT_LOOKS = 3;      // s_sleep arguments of a waiting wave (units of 64 clocks): its first looks, the later ones
 constexpr int FRAME_BYTES = SSDR_FRAME * 4;
 constexpr int RING_BYTES = RF * FRAME_BYTES;
 constexpr int LDS_FFT = LDS_XCH;                                 // [NF] transposes, 2 x 4224 B each
@@ -70,8 +71,8 @@ SSDR_DEV void flag_wait(const uint32_t *p, uint32_t need)
     // (a look costs an LDS read and a vector instruction -- v_readfirstlane -- on a port the other waves want: a few short naps for the
     //  hand-over that is almost there, long ones for a consumer that is a frame ahead of its producers)
     for (uint32_t looks = 0; (int32_t)(flag_read(p) - need) < 0; looks++) {
-        if (looks < SSDR_WS_SHORT_LOOKS) __builtin_amdgcn_s_sleep(SSDR_WS_SLEEP);
-        else __builtin_amdgcn_s_sleep(SSDR_WS_SLEEP_LONG);
+        if (looks < SHORT_LOOKS) __builtin_amdgcn_s_sleep(NAP_SHORT);
+        else __builtin_amdgcn_s_sleep(NAP_LONG);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
@@ -83,7 +84,7 @@ SSDR_DEV void flag_publish(uint32_t *p, uint32_t v, int lane)
 
 // what an audio wave does with a frame's raw samples besides using them
 struct RingTap {
-    static constexpr bool PREFETCH = SSDR_WS_PREFETCH != 0;
+    static constexpr bool PREFETCH = true;
     unsigned char *ring;                    // the channel's RF frames of raw samples
     uint32_t *prod;
     const uint32_t *cons;
@@ -123,7 +124,6 @@ __global__ __launch_bounds__(SSDR_WS_BLOCK) void ssdr_chain_ws_kernel(SsdrFusedA
 
     if (wave < NA) {
         // ------------------------------------------------------------------ audio wave: one side of trio `wave / 2`
-        if (SSDR_WS_PRIO_AUDIO) __builtin_amdgcn_s_setprio(SSDR_WS_PRIO_AUDIO);
         unsigned char *mine = smem + LDS_AUD + wave * A_BYTES;
         float2 *s_z = reinterpret_cast<float2 *>(mine);
         float *s_taps = reinterpret_cast<float *>(mine + NOCT * OCT * 8);
@@ -195,11 +195,11 @@ __global__ __launch_bounds__(SSDR_WS_BLOCK) void ssdr_chain_ws_kernel(SsdrFusedA
                 if (lane < 2) __hip_atomic_store(cons_a + lane, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
             SCHED_FENCE();
-            if (SSDR_PRIO_WF) __builtin_amdgcn_s_setprio(SSDR_WS_PRIO_FFT);
+            if (SSDR_PRIO_WF) prio_compute_phase();
             f32x2 z[32];
             window_line(raw, smem, l, z);
             SCHED_FENCE();
-            fft_line<AVG && SSDR_WS_FFT_TIGHT>(z, smem, xch_wave, h, l);
+            fft_line<AVG>(z, smem, xch_wave, h, l);
             if (SSDR_PRIO_WF) prio_latency_phase();              // quantiser look-ups, the line's store, the next line's hand-shake
             uint32_t qn[16];
             if (AVG) quantise32(z, calq, lut, [&](int j, uint32_t q01) { acc[j] += q01; });

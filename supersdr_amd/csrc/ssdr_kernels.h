@@ -157,35 +157,11 @@ struct SsdrFusedArgs { SsdrWfArgs wf; SsdrAudioArgs au; uint32_t *ticket; uint32
 // ticket: ssdr_chain_ws_kernel's pair counter; it stands at ticket_base at launch and is never reset: every trio draws its pairs and one ticket
 // beyond the last pair, so a launch of `grid` workgroups leaves it at ticket_base + pairs + grid * SSDR_WS_AUDIO_WAVES / 2 (ssdr_api.cpp)
 // the wave-specialised chain kernel (ssdr_chain_ws.hip): a workgroup of SSDR_WS_AUDIO_WAVES audio waves (one receiver each) and half as
-// many FFT waves (one channel pair each); one workgroup per CU
-#ifndef SSDR_WS_AUDIO_WAVES
+// many FFT waves (one channel pair each); one workgroup per CU.  (The kernel's tuning knobs -- ring depth, prefetch, poll naps, priorities -- are
+// constants in ssdr_chain_ws.hip; the A/B trail of each is in profiles/r06_ab_chain_ws.txt, the switchable version in
+// tools/experiments/ssdr_chain_ws_knobs.patch.)
 #define SSDR_WS_AUDIO_WAVES 8
-#endif
 #define SSDR_WS_BLOCK (64 * (SSDR_WS_AUDIO_WAVES + SSDR_WS_AUDIO_WAVES / 2))
-#ifndef SSDR_WS_RING_FRAMES
-#define SSDR_WS_RING_FRAMES 3                // 512-sample frames of raw IQ a channel's ring holds (6 KB; 4 would not fit the LDS)
-#endif
-#ifndef SSDR_WS_PREFETCH
-#define SSDR_WS_PREFETCH 1                   // audio waves request frame f + 1 before they work on frame f
-#endif
-#ifndef SSDR_WS_PRIO_FFT
-#define SSDR_WS_PRIO_FFT 0                   // s_setprio level of an FFT wave in its butterflies (3 in its look-ups, stores and hand-shakes)
-#endif
-#ifndef SSDR_WS_FFT_TIGHT
-#define SSDR_WS_FFT_TIGHT 1                  // N > 1: the FFT waves use the averaging kernel's twiddle schedule (fewer registers in flight)
-#endif
-#ifndef SSDR_WS_SLEEP
-#define SSDR_WS_SLEEP 1                      // s_sleep argument of a waiting wave (units of 64 clocks): its first looks ...
-#endif
-#ifndef SSDR_WS_SLEEP_LONG
-#define SSDR_WS_SLEEP_LONG 8                 // ... and the later ones
-#endif
-#ifndef SSDR_WS_SHORT_LOOKS
-#define SSDR_WS_SHORT_LOOKS 3
-#endif
-#ifndef SSDR_WS_PRIO_AUDIO
-#define SSDR_WS_PRIO_AUDIO 0                 // s_setprio level of the audio waves (the FFT waves: 0 in their butterflies, 3 elsewhere)
-#endif
 hipError_t ssdr_launch_chain_ws(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream);
 hipError_t ssdr_chain_ws_blocks_per_cu(int *blocks);
 hipError_t ssdr_launch_fused_am(const SsdrFusedArgs &a, uint32_t grid, hipStream_t stream);

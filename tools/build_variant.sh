@@ -3,7 +3,7 @@
 # experiment patches (tools/experiments/*.patch), compile with the given -D flags into supersdr_amd/libssdr_<name>.so
 # (git-ignored; travels to the GPU box; selected with SSDR_LIB_PATH, see tools/ab_bench.sh).
 #   tools/build_variant.sh <name> "<-D flags>" [patch ...]
-#   tools/build_variant.sh mfma   "-DSSDR_FIR_MFMA=1 -DSSDR_WS_RING_FRAMES=2"  ssdr_audio_switches    (the tap table of the matrix form: the wave-specialised kernel's ring gives a frame up for it)
+#   tools/build_variant.sh mfma   "-DSSDR_FIR_MFMA=1"      ssdr_audio_switches
 #   tools/build_variant.sh abl1   "-DSSDR_FUSED_ABLATE=1"  ssdr_wf_switches
 # The experiment switches the patches restore (each measured and recorded in profiles/HISTORY.md; none ships):
 #   ssdr_audio_switches: SSDR_FIR_MFMA (channel FIR on the f32 MFMA), SSDR_AUDIO_PREFETCH (the stand-alone audio kernels; the wave-specialised kernel prefetches as shipped)
