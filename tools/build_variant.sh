@@ -8,6 +8,7 @@
 # The experiment switches the patches restore (each measured and recorded in profiles/HISTORY.md; none ships):
 #   ssdr_audio_switches: SSDR_FIR_MFMA (channel FIR on the f32 MFMA), SSDR_AUDIO_PREFETCH (the stand-alone audio kernels; the wave-specialised kernel prefetches as shipped)
 #   ssdr_chain_ws_hop512: the wave-specialised kernel at hop 512 (profiles/r06_ab_chain_ws.txt: 0 to -3.7 %)
+#   ssdr_chain_ws_knobs: that kernel's tuning constants as -DSSDR_WS_... switches (ring depth, prefetch, poll naps, priorities, workgroup shape)
 #   ssdr_wf_switches:    SSDR_WF_ABLATE, SSDR_FUSED_ABLATE (timing ablations), SSDR_WF_PAIR_MAJOR, SSDR_WF_BLOCKED_ITEMS, SSDR_FUSED_WIDE_LOADS=0
 set -e
 NAME=$1; FLAGS=$2; shift; shift
