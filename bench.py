@@ -384,6 +384,8 @@ def multi_rank_extras(rdv, rank, world, run_one, probe=None):
                                  "note": "each rank's own channel-superframes / its own wall time; `value` uses the max wall over ranks"}}
         if "kernels" in e:
             out[key]["kernels"] = e["kernels"]
+        if e.get("power"):                                           # (rank 0's GPU)
+            out[key]["avg_watts"], out[key]["joules_per_step"] = e["power"]["avg_watts"], e["power"]["joules_per_step"]
         if probe is not None:
             own, cross = probe(wl, first, 1), probe(wl, firsts[(rank + 1) % world], 0)
             par = parity_report(rdv, world, firsts, own, cross, "as the main parity ring, on this workload's channel blocks")
